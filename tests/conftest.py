@@ -1,0 +1,24 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+    return np.load(os.path.join(REPO, "tests", "golden", "reference_eval.npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def smpl_tables():
+    from multiply_amd.synthetic import make_smpl_tables
+    return make_smpl_tables(0)
