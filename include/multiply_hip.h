@@ -1,0 +1,189 @@
+/* multiply_hip.h — C ABI of libmultiply_hip.so (gfx950 / MI355X).
+ *
+ * The reference (eth-ait/MultiPly) has no FFI: its hot path is PyTorch code under
+ * code/lib/model/ that is entered through Multiply.forward (code/lib/model/multiply.py:174).
+ * This library is the boundary introduced BELOW that Python signature: every entry point
+ * takes raw device pointers, sizes and a hipStream_t (as void*), allocates nothing, never
+ * throws, and returns 0 on success or a hipError_t / negative argument-error code.
+ * multiply_amd/hip.py is the ctypes binding a maintainer would add to the reference
+ * (see INTEGRATION.md); each entry point names the reference code it replaces.
+ *
+ * All float tensors are fp32, row-major, contiguous.  "count pointers" are device ints so that
+ * data-dependent sizes never need a host round trip: kernels are launched for the upper bound
+ * and read the real count on the device.
+ */
+#ifndef MULTIPLY_HIP_H
+#define MULTIPLY_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MP_MAX_LAYERS 10
+#define MP_MAX_CHUNKS 9
+#define MP_BIAS_STRIDE 288 /* floats per layer in a packed bias table */
+#define MP_SMPL_V 6890
+#define MP_SMPL_J 24
+#define MP_KNN_CLUSTER 64   /* vertices per nearest-neighbour cluster */
+#define MP_KNN_NC 108       /* clusters (108*64 = 6912 >= 6890, padded) */
+
+enum { MP_ACT_NONE = 0, MP_ACT_SOFTPLUS = 1, MP_ACT_RELU = 2 };
+
+typedef struct {
+    int n_chunk;   /* chunks of 32 output rows */
+    int use_reg;   /* layer consumes the 256 register-fed K slots (previous layer output) */
+    int use_in;    /* layer consumes the 64/96 input-fed K slots (encoded network input) */
+    int act;       /* MP_ACT_* */
+    int out_chunk; /* chunk returned in fp32 instead of feeding the next layer, -1 = none */
+} MpLayer;
+
+typedef struct {
+    int n_layers;
+    int total_chunks;
+    MpLayer layer[MP_MAX_LAYERS];
+} MpNet;
+
+/* ---- weights -------------------------------------------------------------------------------
+ * Packs one linear layer (optionally weight-normalised: w = g * v / ||v||_row,
+ * networks.py:82-83) into the bf16 MFMA-fragment layout of csrc/mlp_core.hpp and writes its
+ * fp32 bias row, with an optional hoisted contribution  bias[r] += sum_c W[r][hoist_col0+c] *
+ * hoist_vec[c]  (the pose / frame conditioning that the reference concatenates to every point,
+ * networks.py:164-165, 279-281, 275-276, is the same for all points of a call).
+ *   v [out_dim][in_dim], g [out_dim] or NULL, b [out_dim]
+ *   rowmap [n_rows] : source row of packed row r, -1 = zero row   (n_rows multiple of 32)
+ *   colmap [(8+ks_in)*32], colscale [...] : source column of K slot s (-1 = zero) and a factor
+ *   wpack_layer : destination (n_rows/32 chunks of (8+ks_in)*2 KiB) or NULL to only write the bias
+ *   bias_layer  : destination, MP_BIAS_STRIDE floats (rows >= n_rows are zeroed) */
+int mp_pack_layer(const float* v, const float* g, const float* b, int out_dim, int in_dim, const int* rowmap,
+                  int n_rows, const int* colmap, const float* colscale, int ks_in, int hoist_col0, int hoist_n,
+                  const float* hoist_vec, void* wpack_layer, float* bias_layer, void* stream);
+
+/* ---- fused MLP evaluation -------------------------------------------------------------------
+ * mp_mlp_sdf: ImplicitNet.forward restricted to the sdf column (networks.py:126-181; caller:
+ * multiply.py:140-141 inside the sampler, ray_sampler.py:85-88).
+ *   xc [*][3] canonical points, worklist[i] = point id (NULL: id = i), *count work items
+ *   sdf_out[point id] <- sdf.  multires = 6 Fourier encoding of 3-D input. */
+int mp_mlp_sdf(const MpNet* net, const void* wpack, const float* bias, const float* xc, const int* worklist,
+               const int* count, int max_count, float* sdf_out, void* stream);
+
+/* mp_mlp_full: ImplicitNet.forward, all 1+256 outputs, for callers outside the fused renderer
+ * (multiply_model.py:941-945 query_oc).  d_in = 3 (multires 6) or 4 (multires 10). out [n][257]. */
+int mp_mlp_full(const MpNet* net, const void* wpack, const float* bias, const float* x, int d_in, int n,
+                float* out, void* stream);
+
+/* mp_mlp_shade: value + forward-mode tangents of the foreground ImplicitNet, i.e. sdf, d sdf/d x_c and the
+ * 256 features in one pass (replaces the second forward + autograd.grad of multiply.py:643-659), then
+ * normal = normalize(normalize(grad . Jinv), eps=1e-6) (multiply.py:661, :606).
+ *   worklist[i] = point id; xc [*][3]; jinv [*][9] (row-major inverse of d x_d / d x_c)
+ *   sdf_out[id], normal_out[id][3]; feat_frag: bf16 B-fragments, 512 B per WORK INDEX (consumed by mp_mlp_color) */
+int mp_mlp_shade(const MpNet* net, const void* wpack, const float* bias, const float* xc, const float* jinv,
+                 const int* worklist, const int* count, int max_count, float* sdf_out, float* normal_out,
+                 void* feat_frag, void* stream);
+
+/* mp_mlp_color: RenderingNet.forward mode 'pose_no_view' (networks.py:277-281, 305-311):
+ * sigmoid(MLP([x_c, n, lin_pose(pose) (hoisted), feat])) -> rgb_out[id][3]. */
+int mp_mlp_color(const MpNet* net, const void* wpack, const float* bias, const float* xc, const float* normal,
+                 const void* feat_frag, const int* worklist, const int* count, int max_count, float* rgb_out,
+                 void* stream);
+
+/* mp_background: NeRF++ inverted-sphere background (multiply.py:514-539, 682-726): for every ray, n_bg depths
+ * -> depth2pts_outside -> bg ImplicitNet (frame code hoisted) -> bg RenderingNet ('nerf_frame_encoding') ->
+ * bg_volume_rendering with AbsDensity -> bg_rgb[R][3].  z_bg [n_bg] are the (shared) inverse depths in
+ * DESCENDING order as after the flip of multiply.py:516, or per ray [R][n_bg] if z_per_ray. */
+int mp_background(const MpNet* net_imp, const void* wpack_imp, const float* bias_imp, const MpNet* net_ren,
+                  const void* wpack_ren, const float* bias_ren, const float* dirs, const float* cam, const float* z_bg,
+                  int z_per_ray, int n_rays, float radius, float* bg_rgb, void* stream);
+
+/* ---- SMPL ------------------------------------------------------------------------------------
+ * SMPLServer.forward (lib/model/smpl.py:50-94) -> lbs (lib/smpl/lbs.py:136-229): posed vertices, bone
+ * transforms relative to the canonical pose (tfs_c_inv, may be NULL for absolute), posed joints.
+ *   params [86] = scale, transl3, thetas72, betas10 (device).  work: >= 3*V + 24*16 + 207 + 64 floats. */
+int mp_smpl_pose(const float* v_template, const float* shapedirs, const float* posedirs, const float* j_regressor,
+                 const float* lbs_weights, const int* parents, const float* params, const float* tfs_c_inv,
+                 float* verts, float* tfs, float* joints, float* work, void* stream);
+
+/* Nearest-neighbour acceleration structure over one vertex set (exact K=1 search, replaces
+ * pytorch3d.ops.knn_points, deformer.py:39): vertices gathered in cluster order + bounding spheres.
+ *   perm [NC*64] vertex ids in cluster order (-1 = padding); vsorted [NC*64][4] = x,y,z,id-as-int-bits;
+ *   cbound [NC][4] = centre, radius. */
+int mp_knn_build(const float* verts, const int* perm, float* vsorted, float* cbound, void* stream);
+
+/* Oriented box of the posed vertices inflated by `inflate` (multiply.py:208-214; PCA axes instead of trimesh's
+ * minimum-volume box).  obb [15] = centre3, axes (3 rows), half extents3. */
+int mp_obb(const float* verts, float inflate, float* obb, void* stream);
+
+/* ---- rays -------------------------------------------------------------------------------------
+ * rend_util.get_camera_params (lib/utils/rend_util.py:45-87) + far sphere root (:131-147).
+ *   uv [R][2], intrinsics [16], pose [16] -> dirs [R][3], far [R]; cam is pose[:3,3]. */
+int mp_ray_setup(const float* uv, const float* intrinsics, const float* pose, int n_rays, float radius, float* dirs,
+                 float* far, void* stream);
+/* Ray / box test and ordered compaction (multiply.py:256-266): hit_index [<=R] ascending ray ids, *hit_count;
+ * inv_index [R] = position in hit_index or -1.  group_size: rays of a convergence group without a hit get their
+ * first ray as fallback (multiply.py:262-263 applied per chunk). scan_tmp: >= R+1 ints. */
+int mp_ray_cull(const float* dirs, const float* pose, const float* obb, int n_rays, int group_size, int* hit_index,
+                int* hit_count, int* inv_index, int* scan_tmp, void* stream);
+/* Explicit hit set (parity tests): fills hit_count / inv_index from a given ascending hit_index [n_hit]. */
+int mp_ray_hits_from_index(const int* hit_index, int n_hit, int n_rays, int* hit_count, int* inv_index, void* stream);
+
+/* ---- canonical warp ---------------------------------------------------------------------------
+ * SMPLDeformer.forward(inverse=True) (deformer.py:19-50, 72-88): nearest posed vertex -> its skinning weights ->
+ * x_c = (sum_j w_j T_j)^-1 x ; outlier = dist > 0.1.
+ * Points are either explicit (pts [n][3]) or implicit samples of hit rays: point id = k*n_s + s,
+ * x = cam + z[k*z_stride + s] * dirs[hit_index[k]].
+ *   mode 0 (training): every point is written to xc and appended to worklist.
+ *   mode 1 (eval): outliers get sdf_out = 4 (multiply.py:142-143) and are NOT appended.
+ *   active [ceil(n_hit/group)] per-group flag or NULL.  Outputs: xc [n][3], worklist, *work_count (atomic, must be 0). */
+int mp_warp_inverse(const float* pts, const float* dirs, const float* pose, const int* hit_index, const int* hit_count,
+                    const float* z, int z_stride, int n_s, int max_rays, const float* vsorted, const float* cbound,
+                    const float* skin_w, const float* tfs, int mode, const int* ray_active, float* xc,
+                    unsigned char* outlier, float* sdf_out, int* worklist, int* work_count, void* stream);
+/* Jacobian of forward skinning at canonical points (deformer.py:31-35 + multiply.py:625-641): nearest CANONICAL
+ * vertex -> weights -> J = (sum_j w_j T_j)[:3,:3] -> jinv [id][9].  Only ids in worklist. */
+int mp_warp_jacobian(const float* xc, const int* worklist, const int* count, int max_count, const float* vsorted_c,
+                     const float* cbound_c, const float* skin_w, const float* tfs, float* jinv, void* stream);
+
+/* ---- VolSDF error-bound sampler (ray_sampler.py:66-220), split at the SDF queries ---------------
+ * State per hit ray k (row stride zmax = 640): zs/sdfs sorted samples and their sdf, nz count, znew/sdfnew [128]
+ * the samples whose sdf is being queried, beta, done flag.  Per group: not_converged flags.
+ * cfg = {N_samples, N_samples_eval, N_samples_extra, beta_iters, max_total_iters} ints, {eps, add_tiny, near} floats. */
+typedef struct {
+    int n_samples, n_samples_eval, n_samples_extra, beta_iters, max_total_iters;
+    float eps, add_tiny, near_;
+} MpSamplerCfg;
+typedef struct {
+    float* zs; float* sdfs; int* nz; float* znew; float* sdfnew; float* beta; int* ray_active;
+    int* group_flag;   /* [max_total_iters+1][n_groups] */
+    float* zfinal;     /* [max_rays][n_samples + n_samples_extra + 2] */
+    int* iters;        /* [n_groups] iterations run (diagnostics) */
+} MpSamplerState;
+/* uniform start (ray_sampler.py:21-42, 70-76); t_rand [max_rays][n_eval] or NULL (eval: no jitter) */
+int mp_sampler_init(const MpSamplerCfg* cfg, const MpSamplerState* st, const float* far, const int* hit_index,
+                    const int* hit_count, int max_rays, int group_size, const float* t_rand, void* stream);
+/* merge the queried samples, d*, error bound, beta bisection, group convergence vote (ray_sampler.py:89-137) */
+int mp_sampler_bound(const MpSamplerCfg* cfg, const MpSamplerState* st, const float* beta0, const int* hit_index,
+                     const int* hit_count, int max_rays, int group_size, int iter, void* stream);
+/* up-sample from the error-bound pdf, or draw the final samples and assemble zfinal (ray_sampler.py:139-209);
+ * u_final [max_rays][n_samples] / extra_idx [n_extra] supply the training randomness, NULL = eval linspace */
+int mp_sampler_resample(const MpSamplerCfg* cfg, const MpSamplerState* st, const float* beta0, const float* far,
+                        const int* hit_index, const int* hit_count, int max_rays, int group_size, int iter,
+                        const float* u_final, const int* extra_idx, void* stream);
+
+/* ---- compositing (multiply.py:425-480, 544-545, 590) ---------------------------------------------
+ * Per ray: merge the persons' samples by t_end (ties: lower person first), Laplace density (density.py:20-29),
+ * alpha = 1-exp(-sigma dt), T = exp(-exclusive cumsum), sums; bg transmittance = exclusive T of the last sample.
+ *   per person p: inv_index[p] [R], z[p] [*][n_z] (n_z = S+1 depths, last = z_max), sdf[p] [*][S], rgb[p] [*][S][3],
+ *   normal[p] [*][S][3]  (pointer tables live in device memory, P entries each)
+ * Outputs [R]: fg_rgb[3], normal[3], acc, acc_person[P], bg_T; rgb = fg + bg_T*bg_rgb; fg_out = fg + bg_T. */
+int mp_composite(int n_rays, int n_person, int n_z, const int* const* inv_index, const float* const* z,
+                 const float* const* sdf, const float* const* rgb, const float* const* normal, const float* beta,
+                 const float* bg_rgb, float* rgb_values, float* fg_rgb_values, float* normal_values, float* acc_map,
+                 float* acc_person, float* bg_T, void* stream);
+
+/* library / device info: returns the gfx arch string compiled in, and checks the current device */
+const char* mp_arch(void);
+int mp_device_ok(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

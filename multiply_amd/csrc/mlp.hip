@@ -1,0 +1,467 @@
+// Fused MLP kernels built on mlp_core.hpp.  Entry points: see include/multiply_hip.h.
+//   mp_mlp_sdf    foreground ImplicitNet, sdf column only (sampler queries; ray_sampler.py:85-88)
+//   mp_mlp_full   ImplicitNet, all outputs (query_oc callers; multiply_model.py:941-945)
+//   mp_mlp_shade  foreground ImplicitNet in forward mode: sdf, d sdf/d x_c, features (multiply.py:643-661)
+//   mp_mlp_color  foreground RenderingNet 'pose_no_view' (networks.py:277-281)
+//   mp_background NeRF++ background branch (multiply.py:514-539, 682-726)
+#include <hip/hip_runtime.h>
+#include "../../include/multiply_hip.h"
+#include "mlp_core.hpp"
+
+using namespace mp;
+
+namespace {
+
+static_assert(sizeof(MpNet) == sizeof(NetDesc), "host / device net descriptors must match");
+static_assert(MP_BIAS_STRIDE == BIAS_STRIDE && MP_MAX_LAYERS == MAX_LAYERS && MP_MAX_CHUNKS == MAX_CHUNKS, "abi");
+
+constexpr int BIAS_BYTES = MAX_LAYERS * BIAS_STRIDE * 4;
+
+template <int KS_IN>
+struct Lds {
+    static constexpr int ring = 0;
+    static constexpr int bias0 = 2 * chunk_bytes(KS_IN);
+    static constexpr int bias1 = bias0 + BIAS_BYTES;
+    static constexpr int stage = bias1 + BIAS_BYTES;
+    static constexpr int scratch = stage + 4 * 64 * in_stride(KS_IN) * 2;
+    static constexpr int total = scratch + 4 * 64 * 16;  // 4 floats per point per wave
+};
+
+// Fourier features of a D-vector into one staging row (bf16): [x, sin(2^0 x), cos(2^0 x), ...]  (embedders.py)
+template <int D, int L, int KS_IN>
+__device__ __forceinline__ void stage_pe(__bf16* row, const float (&x)[D]) {
+    constexpr int NF = D + 2 * D * L;
+    static_assert(NF <= KS_IN * 32, "encoding does not fit the input K steps");
+#pragma unroll
+    for (int a = 0; a < D; ++a) row[a] = (__bf16)x[a];
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+        float s, c;
+        sincosf(x[a], &s, &c);
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+            row[D + 2 * D * k + a] = (__bf16)s;
+            row[D + 2 * D * k + D + a] = (__bf16)c;
+            const float s2 = 2.0f * s * c, c2 = 1.0f - 2.0f * s * s;  // angle doubling: next octave
+            s = s2;
+            c = c2;
+        }
+    }
+#pragma unroll
+    for (int f = NF; f < KS_IN * 32; ++f) row[f] = (__bf16)0.0f;
+}
+
+// d/dx_axis of the 3-D, L-octave Fourier features (tangent row for forward mode)
+template <int L, int KS_IN>
+__device__ __forceinline__ void stage_pe_tangent(__bf16* row, const float (&x)[3], int axis) {
+    constexpr int D = 3, NF = D + 2 * D * L;
+#pragma unroll
+    for (int f = 0; f < KS_IN * 32; ++f) row[f] = (__bf16)0.0f;
+    float s, c;
+    const float xa = axis == 0 ? x[0] : (axis == 1 ? x[1] : x[2]);
+    sincosf(xa, &s, &c);
+    row[axis] = (__bf16)1.0f;
+    float f = 1.0f;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        row[D + 2 * D * k + axis] = (__bf16)(f * c);
+        row[D + 2 * D * k + D + axis] = (__bf16)(-f * s);
+        const float s2 = 2.0f * s * c, c2 = 1.0f - 2.0f * s * s;
+        s = s2;
+        c = c2;
+        f *= 2.0f;
+    }
+    (void)NF;
+}
+
+template <int NB, int KS_IN>
+__device__ __forceinline__ void read_bin(const __bf16* stage_wave, bf16x8 (&Bin)[KS_IN][NB], int lane) {
+    const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < KS_IN; ++ks)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            Bin[ks][nb] = *(const bf16x8*)(stage_wave + (nb * 16 + j) * in_stride(KS_IN) + ks * 32 + g * 8);
+}
+
+template <int NB>
+__device__ __forceinline__ void zero_b(bf16x8 (&B)[KS_REG][NB]) {
+#pragma unroll
+    for (int k = 0; k < KS_REG; ++k)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) B[k][nb] = (bf16x8)(__bf16)0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------ sdf only
+__global__ __launch_bounds__(256) void k_mlp_sdf(const NetDesc net, const char* __restrict__ wpack,
+                                                 const float* __restrict__ bias, const float* __restrict__ xc,
+                                                 const int* __restrict__ worklist, const int* __restrict__ count_p,
+                                                 int max_count, float* __restrict__ sdf_out) {
+    constexpr int KS_IN = 2, NB = 4;
+    using L = Lds<KS_IN>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int count = count_p ? min(*count_p, max_count) : max_count;
+    float* bias_lds = (float*)(smem + L::bias0);
+    __bf16* stage = (__bf16*)(smem + L::stage) + wave * 64 * in_stride(KS_IN);
+    load_bias(net, bias, bias_lds);
+    for (int t = blockIdx.x; t * 256 < count; t += gridDim.x) {
+        const int w = t * 256 + wave * 64 + lane;
+        const int id = w < count ? (worklist ? worklist[w] : w) : -1;
+        float x[3] = {0.f, 0.f, 0.f};
+        if (id >= 0) { x[0] = xc[3 * (size_t)id]; x[1] = xc[3 * (size_t)id + 1]; x[2] = xc[3 * (size_t)id + 2]; }
+        stage_pe<3, 6, KS_IN>(stage + lane * in_stride(KS_IN), x);
+        bf16x8 Bcur[KS_REG][NB], Bin[KS_IN][NB];
+        f32x4 out[NB];
+        zero_b<NB>(Bcur);
+        __syncthreads();  // staging rows are written by other lanes
+        read_bin<NB, KS_IN>(stage, Bin, lane);
+        prologue<KS_IN>(net, wpack, smem + L::ring, wave, lane);
+        run_net<NB, false, KS_IN>(net, wpack, bias_lds, smem + L::ring, Bcur, Bin, out, wave, lane);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int pid = __shfl(id, nb * 16 + (lane & 15));
+            if (lane < 16 && pid >= 0) sdf_out[pid] = out[nb][0];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ all outputs
+template <int D_IN, int LFREQ, int KS_IN>
+__global__ __launch_bounds__(256) void k_mlp_full(const NetDesc net, const char* __restrict__ wpack,
+                                                  const float* __restrict__ bias, const float* __restrict__ x, int n,
+                                                  float* __restrict__ outp) {
+    constexpr int NB = 4;
+    using L = Lds<KS_IN>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* bias_lds = (float*)(smem + L::bias0);
+    __bf16* stage = (__bf16*)(smem + L::stage) + wave * 64 * in_stride(KS_IN);
+    load_bias(net, bias, bias_lds);
+    for (int t = blockIdx.x; t * 256 < n; t += gridDim.x) {
+        const int id0 = t * 256 + wave * 64;
+        const int id = id0 + lane < n ? id0 + lane : -1;
+        float xi[D_IN];
+#pragma unroll
+        for (int a = 0; a < D_IN; ++a) xi[a] = id >= 0 ? x[(size_t)id * D_IN + a] : 0.f;
+        stage_pe<D_IN, LFREQ, KS_IN>(stage + lane * in_stride(KS_IN), xi);
+        bf16x8 Bcur[KS_REG][NB], Bin[KS_IN][NB];
+        f32x4 out[NB];
+        zero_b<NB>(Bcur);
+        __syncthreads();  // staging rows are written by other lanes
+        read_bin<NB, KS_IN>(stage, Bin, lane);
+        prologue<KS_IN>(net, wpack, smem + L::ring, wave, lane);
+        run_net<NB, false, KS_IN>(net, wpack, bias_lds, smem + L::ring, Bcur, Bin, out, wave, lane);
+        const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int pid = id0 + nb * 16 + j;
+            if (pid < n) {
+                float* o = outp + (size_t)pid * 257;
+                if (g == 0) o[0] = out[nb][0];
+#pragma unroll
+                for (int ks = 0; ks < KS_REG; ++ks)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)  // inverse of the K-slot permutation (mlp_core.hpp header)
+                        o[1 + 32 * ks + (e < 4 ? 4 * g + e : 16 + 4 * g + e - 4)] = (float)Bcur[ks][nb][e];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ shading: fwd mode
+__global__ __launch_bounds__(256) void k_mlp_shade(const NetDesc net, const char* __restrict__ wpack,
+                                                   const float* __restrict__ bias, const float* __restrict__ xc,
+                                                   const float* __restrict__ jinv, const int* __restrict__ worklist,
+                                                   const int* __restrict__ count_p, int max_count,
+                                                   float* __restrict__ sdf_out, float* __restrict__ normal_out,
+                                                   char* __restrict__ feat_frag) {
+    constexpr int KS_IN = 2, NB = 4;
+    using L = Lds<KS_IN>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = lane & 15, role = lane >> 4;
+    const int count = count_p ? min(*count_p, max_count) : max_count;
+    float* bias_lds = (float*)(smem + L::bias0);
+    __bf16* stage = (__bf16*)(smem + L::stage) + wave * 64 * in_stride(KS_IN);
+    load_bias(net, bias, bias_lds);
+    for (int t = blockIdx.x; t * 64 < count; t += gridDim.x) {
+        const int w = t * 64 + wave * 16 + j;
+        const int id = w < count ? (worklist ? worklist[w] : w) : -1;
+        float x[3] = {0.f, 0.f, 0.f};
+        if (id >= 0) { x[0] = xc[3 * (size_t)id]; x[1] = xc[3 * (size_t)id + 1]; x[2] = xc[3 * (size_t)id + 2]; }
+        __bf16* row = stage + (role * 16 + j) * in_stride(KS_IN);
+        if (role == 0) stage_pe<3, 6, KS_IN>(row, x);
+        else stage_pe_tangent<6, KS_IN>(row, x, role - 1);
+        bf16x8 Bcur[KS_REG][NB], Bin[KS_IN][NB];
+        f32x4 out[NB];
+        zero_b<NB>(Bcur);
+        __syncthreads();  // staging rows are written by other lanes
+        read_bin<NB, KS_IN>(stage, Bin, lane);
+        prologue<KS_IN>(net, wpack, smem + L::ring, wave, lane);
+        run_net<NB, true, KS_IN>(net, wpack, bias_lds, smem + L::ring, Bcur, Bin, out, wave, lane);
+        // features of block 0 -> B fragments of the colour kernel's tile t, column block `wave`
+#pragma unroll
+        for (int ks = 0; ks < KS_REG; ++ks)
+            *(bf16x8*)(feat_frag + (((size_t)t * KS_REG + ks) * 4 + wave) * 1024 + lane * 16) = Bcur[ks][0];
+        if (role == 0 && id >= 0) {
+            const float gx = out[1][0], gy = out[2][0], gz = out[3][0];
+            const float* Ji = jinv + 9 * (size_t)id;
+            float n0 = gx * Ji[0] + gy * Ji[3] + gz * Ji[6];
+            float n1 = gx * Ji[1] + gy * Ji[4] + gz * Ji[7];
+            float n2 = gx * Ji[2] + gy * Ji[5] + gz * Ji[8];
+            float inv = 1.0f / fmaxf(sqrtf(n0 * n0 + n1 * n1 + n2 * n2), 1e-12f);  // F.normalize default eps
+            n0 *= inv; n1 *= inv; n2 *= inv;
+            inv = 1.0f / fmaxf(sqrtf(n0 * n0 + n1 * n1 + n2 * n2), 1e-6f);         // multiply.py:606
+            sdf_out[id] = out[0][0];
+            normal_out[3 * (size_t)id] = n0 * inv;
+            normal_out[3 * (size_t)id + 1] = n1 * inv;
+            normal_out[3 * (size_t)id + 2] = n2 * inv;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ colour
+__global__ __launch_bounds__(256) void k_mlp_color(const NetDesc net, const char* __restrict__ wpack,
+                                                   const float* __restrict__ bias, const float* __restrict__ xc,
+                                                   const float* __restrict__ normal, const char* __restrict__ feat_frag,
+                                                   const int* __restrict__ worklist, const int* __restrict__ count_p,
+                                                   int max_count, float* __restrict__ rgb_out) {
+    constexpr int KS_IN = 2, NB = 4;
+    using L = Lds<KS_IN>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int count = count_p ? min(*count_p, max_count) : max_count;
+    float* bias_lds = (float*)(smem + L::bias0);
+    __bf16* stage = (__bf16*)(smem + L::stage) + wave * 64 * in_stride(KS_IN);
+    load_bias(net, bias, bias_lds);
+    // shade tiles hold 64 work items; this kernel's wave `wave` of block-tile T consumes shade tile 4T+wave
+    for (int t = blockIdx.x; t * 256 < count; t += gridDim.x) {
+        const int tile = t * 4 + wave;
+        const int w = tile * 64 + lane;
+        const int id = w < count ? (worklist ? worklist[w] : w) : -1;
+        __bf16* row = stage + lane * in_stride(KS_IN);
+#pragma unroll
+        for (int f = 0; f < KS_IN * 32; ++f) row[f] = (__bf16)0.0f;
+        if (id >= 0) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                row[a] = (__bf16)xc[3 * (size_t)id + a];
+                row[3 + a] = (__bf16)normal[3 * (size_t)id + a];
+            }
+        }
+        bf16x8 Bcur[KS_REG][NB], Bin[KS_IN][NB];
+        f32x4 out[NB];
+        const bool live = tile * 64 < count;
+#pragma unroll
+        for (int ks = 0; ks < KS_REG; ++ks)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                Bcur[ks][nb] = live ? *(const bf16x8*)(feat_frag + (((size_t)tile * KS_REG + ks) * 4 + nb) * 1024 + lane * 16)
+                                    : (bf16x8)(__bf16)0.0f;
+        __syncthreads();
+        read_bin<NB, KS_IN>(stage, Bin, lane);
+        prologue<KS_IN>(net, wpack, smem + L::ring, wave, lane);
+        run_net<NB, false, KS_IN>(net, wpack, bias_lds, smem + L::ring, Bcur, Bin, out, wave, lane);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int pid = __shfl(id, nb * 16 + (lane & 15));
+            if (lane < 16 && pid >= 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) rgb_out[3 * (size_t)pid + c] = 1.0f / (1.0f + __expf(-out[nb][c]));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ background
+// One wave = 64 samples = 64/n_bg rays (n_bg = 32: two rays).  multiply.py:698-726 for the points.
+__global__ __launch_bounds__(256) void k_background(const NetDesc net_imp, const char* __restrict__ wp_imp,
+                                                    const float* __restrict__ bias_imp,
+                                                    const NetDesc net_ren, const char* __restrict__ wp_ren,
+                                                    const float* __restrict__ bias_ren, const float* __restrict__ dirs,
+                                                    const float* __restrict__ cam, const float* __restrict__ z_bg,
+                                                    int z_per_ray, int n_rays, float radius, float* __restrict__ bg_rgb) {
+    constexpr int KS_IN = 3, NB = 4, NBG = 32;
+    using L = Lds<KS_IN>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* bias_lds0 = (float*)(smem + L::bias0);
+    float* bias_lds1 = (float*)(smem + L::bias1);
+    __bf16* stage = (__bf16*)(smem + L::stage) + wave * 64 * in_stride(KS_IN);
+    float* scr = (float*)(smem + L::scratch) + wave * 64 * 4;
+    load_bias(net_imp, bias_imp, bias_lds0);
+    load_bias(net_ren, bias_ren, bias_lds1);
+    const int n_pts = n_rays * NBG;
+    const float ox = cam[0], oy = cam[1], oz = cam[2];
+    for (int t = blockIdx.x; t * 256 < n_pts; t += gridDim.x) {
+        const int q = t * 256 + wave * 64 + lane;
+        const int ray = q / NBG, s = q % NBG;
+        const bool ok = ray < n_rays;
+        float d[3] = {0.f, 0.f, 1.f};
+        float depth = 0.1f;
+        if (ok) {
+            d[0] = dirs[3 * ray]; d[1] = dirs[3 * ray + 1]; d[2] = dirs[3 * ray + 2];
+            depth = z_per_ray ? z_bg[(size_t)ray * NBG + s] : z_bg[s];
+        }
+        // depth2pts_outside
+        const float o_dot_d = d[0] * ox + d[1] * oy + d[2] * oz;
+        const float under = o_dot_d * o_dot_d - ((ox * ox + oy * oy + oz * oz) - radius * radius);
+        const float d_sphere = sqrtf(under) - o_dot_d;
+        const float ps[3] = {ox + d_sphere * d[0], oy + d_sphere * d[1], oz + d_sphere * d[2]};
+        const float pm[3] = {ox - o_dot_d * d[0], oy - o_dot_d * d[1], oz - o_dot_d * d[2]};
+        const float pm_n = sqrtf(pm[0] * pm[0] + pm[1] * pm[1] + pm[2] * pm[2]);
+        float ax[3] = {oy * ps[2] - oz * ps[1], oz * ps[0] - ox * ps[2], ox * ps[1] - oy * ps[0]};
+        const float an = sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+        ax[0] /= an; ax[1] /= an; ax[2] /= an;
+        const float phi = asinf(pm_n / radius), theta = asinf(pm_n * depth);
+        float sa, ca;
+        sincosf(phi - theta, &sa, &ca);
+        const float cr[3] = {ax[1] * ps[2] - ax[2] * ps[1], ax[2] * ps[0] - ax[0] * ps[2], ax[0] * ps[1] - ax[1] * ps[0]};
+        const float adp = ax[0] * ps[0] + ax[1] * ps[1] + ax[2] * ps[2];
+        float pn[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) pn[a] = ps[a] * ca + cr[a] * sa + ax[a] * adp * (1.0f - ca);
+        const float pnn = sqrtf(pn[0] * pn[0] + pn[1] * pn[1] + pn[2] * pn[2]);
+        const float x4[4] = {pn[0] / pnn, pn[1] / pnn, pn[2] / pnn, depth};
+        stage_pe<4, 10, KS_IN>(stage + lane * in_stride(KS_IN), x4);
+        bf16x8 Bcur[KS_REG][NB], Bin[KS_IN][NB];
+        f32x4 out[NB];
+        zero_b<NB>(Bcur);
+        __syncthreads();  // staging rows are written by other lanes
+        read_bin<NB, KS_IN>(stage, Bin, lane);
+        prologue<KS_IN>(net_imp, wp_imp, smem + L::ring, wave, lane);
+        run_net<NB, false, KS_IN>(net_imp, wp_imp, bias_lds0, smem + L::ring, Bcur, Bin, out, wave, lane);
+        if (lane < 16) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) scr[(nb * 16 + lane) * 4 + 3] = fabsf(out[nb][0]);  // AbsDensity (density.py:32-34)
+        }
+        // colour net: [PE_4(view dir) (27), frame code (hoisted), features (registers)]
+        stage_pe<3, 4, KS_IN>(stage + lane * in_stride(KS_IN), d);
+        __syncthreads();
+        read_bin<NB, KS_IN>(stage, Bin, lane);
+        prologue<KS_IN>(net_ren, wp_ren, smem + L::ring, wave, lane);
+        run_net<NB, false, KS_IN>(net_ren, wp_ren, bias_lds1, smem + L::ring, Bcur, Bin, out, wave, lane);
+        if (lane < 16) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) scr[(nb * 16 + lane) * 4 + c] = 1.0f / (1.0f + __expf(-out[nb][c]));
+        }
+        __syncthreads();
+        // bg_volume_rendering (multiply.py:682-696): lanes 0..(64/NBG-1) composite one ray each
+        if (lane < 64 / NBG) {
+            const int r = (t * 256 + wave * 64) / NBG + lane;
+            if (r < n_rays) {
+                float T = 1.0f, acc[3] = {0.f, 0.f, 0.f}, csum = 0.0f;
+                for (int i = 0; i < NBG; ++i) {
+                    const float zi = z_per_ray ? z_bg[(size_t)r * NBG + i] : z_bg[i];
+                    const float zn = i + 1 < NBG ? (z_per_ray ? z_bg[(size_t)r * NBG + i + 1] : z_bg[i + 1]) : 0.f;
+                    const float dist = i + 1 < NBG ? zi - zn : 1e10f;
+                    const float* sp = scr + (lane * NBG + i) * 4;
+                    const float fe = dist * sp[3];
+                    const float alpha = 1.0f - expf(-fe);
+                    T = expf(-csum);
+                    const float wgt = alpha * T;
+                    acc[0] += wgt * sp[0]; acc[1] += wgt * sp[1]; acc[2] += wgt * sp[2];
+                    csum += fe;
+                }
+                bg_rgb[3 * r] = acc[0]; bg_rgb[3 * r + 1] = acc[1]; bg_rgb[3 * r + 2] = acc[2];
+            }
+        }
+    }
+}
+
+template <typename K>
+int set_lds(K kernel, int bytes) {
+    return (int)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+int grid_for(int work_blocks) {
+    // persistent grid: one 256-thread block per CU (register budget allows exactly one), grid-stride over tiles
+    const int cus = 256;
+    return work_blocks < cus ? (work_blocks > 0 ? work_blocks : 1) : cus;
+}
+
+NetDesc as_desc(const MpNet* net) {
+    NetDesc d;
+    __builtin_memcpy(&d, net, sizeof(d));
+    return d;
+}
+
+}  // namespace
+
+extern "C" int mp_mlp_sdf(const MpNet* net, const void* wpack, const float* bias, const float* xc,
+                          const int* worklist, const int* count, int max_count, float* sdf_out, void* stream) {
+    if (max_count <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    static int once = set_lds(k_mlp_sdf, Lds<2>::total);
+    (void)once;
+    const NetDesc d = as_desc(net);
+    hipLaunchKernelGGL(k_mlp_sdf, dim3(grid_for((max_count + 255) / 256)), dim3(256), Lds<2>::total, st, d,
+                       (const char*)wpack, bias, xc, worklist, count, max_count, sdf_out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_mlp_full(const MpNet* net, const void* wpack, const float* bias, const float* x, int d_in, int n,
+                           float* out, void* stream) {
+    if (n <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const NetDesc d = as_desc(net);
+    const int grid = grid_for((n + 255) / 256);
+    if (d_in == 3) {
+        static int once = set_lds(k_mlp_full<3, 6, 2>, Lds<2>::total);
+        (void)once;
+        hipLaunchKernelGGL((k_mlp_full<3, 6, 2>), dim3(grid), dim3(256), Lds<2>::total, st, d, (const char*)wpack, bias, x,
+                           n, out);
+    } else if (d_in == 4) {
+        static int once = set_lds(k_mlp_full<4, 10, 3>, Lds<3>::total);
+        (void)once;
+        hipLaunchKernelGGL((k_mlp_full<4, 10, 3>), dim3(grid), dim3(256), Lds<3>::total, st, d, (const char*)wpack, bias,
+                           x, n, out);
+    } else {
+        return -1;
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_mlp_shade(const MpNet* net, const void* wpack, const float* bias, const float* xc,
+                            const float* jinv, const int* worklist, const int* count, int max_count, float* sdf_out,
+                            float* normal_out, void* feat_frag, void* stream) {
+    if (max_count <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    static int once = set_lds(k_mlp_shade, Lds<2>::total);
+    (void)once;
+    const NetDesc d = as_desc(net);
+    hipLaunchKernelGGL(k_mlp_shade, dim3(grid_for((max_count + 63) / 64)), dim3(256), Lds<2>::total, st, d,
+                       (const char*)wpack, bias, xc, jinv, worklist, count, max_count, sdf_out, normal_out,
+                       (char*)feat_frag);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_mlp_color(const MpNet* net, const void* wpack, const float* bias, const float* xc,
+                            const float* normal, const void* feat_frag, const int* worklist, const int* count,
+                            int max_count, float* rgb_out, void* stream) {
+    if (max_count <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    static int once = set_lds(k_mlp_color, Lds<2>::total);
+    (void)once;
+    const NetDesc d = as_desc(net);
+    hipLaunchKernelGGL(k_mlp_color, dim3(grid_for((max_count + 255) / 256)), dim3(256), Lds<2>::total, st, d,
+                       (const char*)wpack, bias, xc, normal, (const char*)feat_frag, worklist, count, max_count, rgb_out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_background(const MpNet* net_imp, const void* wpack_imp, const float* bias_imp, const MpNet* net_ren,
+                             const void* wpack_ren, const float* bias_ren, const float* dirs, const float* cam,
+                             const float* z_bg, int z_per_ray, int n_rays, float radius, float* bg_rgb, void* stream) {
+    if (n_rays <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    static int once = set_lds(k_background, Lds<3>::total);
+    (void)once;
+    const NetDesc d0 = as_desc(net_imp), d1 = as_desc(net_ren);
+    hipLaunchKernelGGL(k_background, dim3(grid_for((n_rays * 32 + 255) / 256)), dim3(256), Lds<3>::total, st, d0,
+                       (const char*)wpack_imp, bias_imp, d1, (const char*)wpack_ren, bias_ren, dirs, cam, z_bg, z_per_ray,
+                       n_rays, radius, bg_rgb);
+    return (int)hipGetLastError();
+}

@@ -32,16 +32,15 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int KS_REG = 8;   // K steps (32 slots each) fed from registers = previous layer output (<=256 feats)
-constexpr int KS_IN = 2;    // K steps fed from the encoded network input (<=64 feats: PE, normals, view PE ...)
-constexpr int KS_ALL = KS_REG + KS_IN;
+// KS_IN (template parameter, 2 or 3): K steps fed from the encoded network input (<=64 / 96 feats: PE, normals ...)
 constexpr int TILE_BYTES = 1024;                  // one 16x32 bf16 A tile, fragment order: [lane][8]
-constexpr int MB_BYTES = KS_ALL * TILE_BYTES;     // 10 KiB: all K steps of 16 output rows
 constexpr int CHUNK_MB = 2;                       // 32 output rows = one K step of the next layer
-constexpr int CHUNK_BYTES = CHUNK_MB * MB_BYTES;  // 20 KiB
 constexpr int MAX_CHUNKS = 9;                     // 8 chunks = 256 rows, +1 "extra output" chunk
-constexpr int MAX_LAYERS = 12;
+constexpr int MAX_LAYERS = 10;
 constexpr int BIAS_STRIDE = MAX_CHUNKS * 32;      // 288 floats per layer
-constexpr int IN_STRIDE = 72;                     // bf16 elements per point row of the input staging tile (64 + pad)
+__host__ __device__ constexpr int mb_bytes(int ks_in) { return (KS_REG + ks_in) * TILE_BYTES; }  // all K steps of 16 rows
+__host__ __device__ constexpr int chunk_bytes(int ks_in) { return CHUNK_MB * mb_bytes(ks_in); }  // 20 / 22 KiB
+__host__ __device__ constexpr int in_stride(int ks_in) { return ks_in * 32 + 8; }  // bf16 per staging row (+pad)
 
 enum Act : int { ACT_NONE = 0, ACT_SOFTPLUS = 1, ACT_RELU = 2 };
 
@@ -76,12 +75,16 @@ __device__ __forceinline__ float softplus100_grad(float z) {
     return t > 20.0f ? 1.0f : s;
 }
 
+template <int KS_IN>
 __device__ __forceinline__ void issue_chunk(const char* __restrict__ wpack, char* wring, int ci, int wave, int lane) {
-    const char* src = wpack + (size_t)ci * CHUNK_BYTES;
-    char* dst = wring + (ci & 1) * CHUNK_BYTES;
+    constexpr int CB = chunk_bytes(KS_IN);
+    constexpr int NP = CB / TILE_BYTES;   // 1 KiB pieces, dealt round-robin to the 4 waves
+    const char* src = wpack + (size_t)ci * CB;
+    char* dst = wring + (ci & 1) * CB;
 #pragma unroll
-    for (int i = 0; i < CHUNK_BYTES / TILE_BYTES / 4; ++i) {
-        int piece = wave * (CHUNK_BYTES / TILE_BYTES / 4) + i;
+    for (int i = 0; i < (NP + 3) / 4; ++i) {
+        const int piece = wave + 4 * i;
+        if (piece < NP)
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(src + piece * TILE_BYTES + lane * 16),
             (__attribute__((address_space(3))) void*)(dst + piece * TILE_BYTES), 16, 0, 0);
@@ -102,8 +105,8 @@ __device__ __forceinline__ void store_bhalf(bf16x8& b, int half, const f32x4& v)
 //          if layer 0 has use_reg = 0); on return holds the last layer's (bf16) output blocks.
 //   Bin  : encoded-input K operand (K steps 8,9 of every layer with use_in).
 //   out  : fp32 rows 0..15 of the `out_chunk` of the layer that declares one.
-// The caller must have issued chunk `ci0` into slot (ci0&1) and synchronised (see prologue()).
-template <int NB, bool FWD>
+// The caller must have issued chunk 0 into ring slot 0 and synchronised (see prologue()).
+template <int NB, bool FWD, int KS_IN>
 __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restrict__ wpack, const float* bias_lds,
                                         char* wring, bf16x8 (&Bcur)[KS_REG][NB], const bf16x8 (&Bin)[KS_IN][NB],
                                         f32x4 (&out)[NB], int wave, int lane) {
@@ -121,15 +124,15 @@ __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restri
 #pragma unroll
         for (int c = 0; c < MAX_CHUNKS; ++c) {
             if (c < L.n_chunk) {
-                if (ci + 1 < net.total_chunks) issue_chunk(wpack, wring, ci + 1, wave, lane);
-                const char* slot = wring + (ci & 1) * CHUNK_BYTES;
+                if (ci + 1 < net.total_chunks) issue_chunk<KS_IN>(wpack, wring, ci + 1, wave, lane);
+                const char* slot = wring + (ci & 1) * chunk_bytes(KS_IN);
 #pragma unroll
                 for (int mbl = 0; mbl < CHUNK_MB; ++mbl) {
                     f32x4 acc[NB];
                     const f32x4 bv = *(const f32x4*)(bl + c * 32 + mbl * 16 + g * 4);
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) acc[nb] = (FWD && nb > 0) ? (f32x4){0, 0, 0, 0} : bv;
-                    const char* tile = slot + mbl * MB_BYTES + lane * 16;
+                    const char* tile = slot + mbl * mb_bytes(KS_IN) + lane * 16;
                     if (L.use_reg) {
 #pragma unroll
                         for (int ks = 0; ks < KS_REG; ++ks) {
@@ -193,12 +196,14 @@ __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restri
 }
 
 // Loads the per-layer biases into LDS and the first weight chunk into ring slot 0.
-__device__ __forceinline__ void prologue(const NetDesc& net, const char* __restrict__ wpack,
-                                         const float* __restrict__ bias, float* bias_lds, char* wring, int wave,
+template <int KS_IN>
+__device__ __forceinline__ void prologue(const NetDesc& net, const char* __restrict__ wpack, char* wring, int wave,
                                          int lane) {
-    for (int i = threadIdx.x; i < net.n_layers * BIAS_STRIDE; i += blockDim.x) bias_lds[i] = bias[i];
-    issue_chunk(wpack, wring, 0, wave, lane);
+    issue_chunk<KS_IN>(wpack, wring, 0, wave, lane);
     __syncthreads();
+}
+__device__ __forceinline__ void load_bias(const NetDesc& net, const float* __restrict__ bias, float* bias_lds) {
+    for (int i = threadIdx.x; i < net.n_layers * BIAS_STRIDE; i += blockDim.x) bias_lds[i] = bias[i];
 }
 
 }  // namespace mp

@@ -1,0 +1,89 @@
+// Weight packing: fp32 (optionally weight-normalised) nn.Linear parameters -> bf16 MFMA A-fragments.
+// Replaces nothing arithmetic in the reference except the weight-norm reparametrisation
+// w = g * v / ||v|| (torch.nn.utils.weight_norm, reference networks.py:82-83) and hoists the per-call
+// constant conditioning (networks.py:164-165) into the bias.  See include/multiply_hip.h: mp_pack_layer.
+#include <hip/hip_runtime.h>
+#include "../../include/multiply_hip.h"
+#include "mlp_core.hpp"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k_pack_layer(const float* __restrict__ v, const float* __restrict__ g,
+                                                   const float* __restrict__ b, int out_dim, int in_dim,
+                                                   const int* __restrict__ rowmap, const int* __restrict__ colmap,
+                                                   const float* __restrict__ colscale, int ks_in, int hoist_col0,
+                                                   int hoist_n, const float* __restrict__ hoist_vec,
+                                                   __bf16* __restrict__ wpack, float* __restrict__ bias_out) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    const int src = rowmap[r];
+    const int n_slots = (mp::KS_REG + ks_in) * 32;
+    const int mb = r >> 4, i = r & 15;
+    float scale = 1.0f;
+    const float* row = nullptr;
+    if (src >= 0) {
+        row = v + (size_t)src * in_dim;
+        if (g) {
+            float ss = 0.0f;
+            for (int c = lane; c < in_dim; c += 64) ss += row[c] * row[c];
+            ss = wave_sum(ss);
+            scale = g[src] / sqrtf(ss);
+        }
+    }
+    if (wpack) {
+        for (int s = lane; s < n_slots; s += 64) {
+            float val = 0.0f;
+            if (src >= 0) {
+                const int col = colmap[s];
+                if (col >= 0) val = row[col] * scale * colscale[s];
+            }
+            const int ks = s >> 5, sl = s & 31, gg = sl >> 3, e = sl & 7;
+            const size_t off = ((size_t)(mb * (mp::KS_REG + ks_in) + ks) * 64 + (i + 16 * gg)) * 8 + e;
+            wpack[off] = (__bf16)val;
+        }
+    }
+    if (bias_out) {
+        float h = 0.0f;
+        if (src >= 0 && hoist_n > 0) {
+            for (int c = lane; c < hoist_n; c += 64) h += (row[hoist_col0 + c] * scale) * hoist_vec[c];
+            h = wave_sum(h);
+        }
+        if (lane == 0) bias_out[r] = src >= 0 ? b[src] + h : 0.0f;
+    }
+}
+
+__global__ void k_zero_f(float* p, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.0f;
+}
+
+}  // namespace
+
+extern "C" int mp_pack_layer(const float* v, const float* g, const float* b, int out_dim, int in_dim,
+                             const int* rowmap, int n_rows, const int* colmap, const float* colscale, int ks_in,
+                             int hoist_col0, int hoist_n, const float* hoist_vec, void* wpack_layer,
+                             float* bias_layer, void* stream) {
+    if (n_rows <= 0 || n_rows % 32 || n_rows > MP_BIAS_STRIDE || (ks_in != 2 && ks_in != 3)) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    if (bias_layer && n_rows < MP_BIAS_STRIDE)
+        hipLaunchKernelGGL(k_zero_f, dim3(1), dim3(MP_BIAS_STRIDE), 0, st, bias_layer + n_rows, MP_BIAS_STRIDE - n_rows);
+    hipLaunchKernelGGL(k_pack_layer, dim3(n_rows), dim3(64), 0, st, v, g, b, out_dim, in_dim, rowmap, colmap,
+                       colscale, ks_in, hoist_col0, hoist_n, hoist_vec, (__bf16*)wpack_layer, bias_layer);
+    return (int)hipGetLastError();
+}
+
+extern "C" const char* mp_arch(void) { return "gfx950"; }
+
+extern "C" int mp_device_ok(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    const char* a = prop.gcnArchName;
+    return (a[0] == 'g' && a[1] == 'f' && a[2] == 'x' && a[3] == '9' && a[4] == '5' && a[5] == '0') ? 1 : 0;
+}

@@ -1,0 +1,337 @@
+"""ctypes binding of libmultiply_hip.so (include/multiply_hip.h) + weight packing helpers.
+
+This is the only place the Python host side touches the C ABI.  There is NO fallback: if the shared library is
+missing or the device is not a gfx950, importing/using this module raises.
+PyTorch is used for device memory and streams only (tensor.data_ptr(), torch.cuda.current_stream()).
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmultiply_hip.so")
+
+MAX_LAYERS, MAX_CHUNKS, BIAS_STRIDE = 10, 9, 288
+ACT_NONE, ACT_SOFTPLUS, ACT_RELU = 0, 1, 2
+KNN_CLUSTER, KNN_NC = 64, 108
+
+
+class MpLayer(C.Structure):
+    _fields_ = [("n_chunk", C.c_int), ("use_reg", C.c_int), ("use_in", C.c_int), ("act", C.c_int),
+                ("out_chunk", C.c_int)]
+
+
+class MpNet(C.Structure):
+    _fields_ = [("n_layers", C.c_int), ("total_chunks", C.c_int), ("layer", MpLayer * MAX_LAYERS)]
+
+
+class MpSamplerCfg(C.Structure):
+    _fields_ = [("n_samples", C.c_int), ("n_samples_eval", C.c_int), ("n_samples_extra", C.c_int),
+                ("beta_iters", C.c_int), ("max_total_iters", C.c_int), ("eps", C.c_float), ("add_tiny", C.c_float),
+                ("near_", C.c_float)]
+
+
+class MpSamplerState(C.Structure):
+    _fields_ = [("zs", C.c_void_p), ("sdfs", C.c_void_p), ("nz", C.c_void_p), ("znew", C.c_void_p),
+                ("sdfnew", C.c_void_p), ("beta", C.c_void_p), ("ray_active", C.c_void_p), ("group_flag", C.c_void_p),
+                ("zfinal", C.c_void_p), ("iters", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    """Loads the HIP library; raises loudly when it is absent (no CPU / PyTorch fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                               f"g.build()'` (hipcc --offload-arch=gfx950). The MultiPly hot path has no fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.mp_arch.restype = C.c_char_p
+    return _lib
+
+
+def require_device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("multiply_amd needs a ROCm device (MI355X / gfx950); none is visible")
+    if not lib().mp_device_ok():
+        raise RuntimeError("multiply_amd kernels are built for gfx950 only; the current device is not a gfx950")
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensors only"
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError(f"{what} failed with code {code}")
+
+
+# ------------------------------------------------------------------------------------------------ packing
+def reg_slot_feature(s):
+    """K slot s (0..255) of a register-fed K step -> index of the previous layer's output row it multiplies
+    (the permutation documented in csrc/mlp_core.hpp)."""
+    ks, sl = divmod(s, 32)
+    g, e = divmod(sl, 8)
+    return 32 * ks + (4 * g + e if e < 4 else 16 + 4 * g + e - 4)
+
+
+_REG_FEATURE = np.array([reg_slot_feature(s) for s in range(256)], dtype=np.int64)
+
+
+class LayerPlan:
+    """How one nn.Linear maps onto the packed layout."""
+
+    def __init__(self, lin, rowmap, reg_cols=None, in_cols=None, scale=1.0, hoist=None, act=ACT_NONE, out_chunk=-1):
+        self.lin, self.act, self.out_chunk = lin, act, out_chunk
+        rowmap = list(rowmap)
+        while len(rowmap) % 32:
+            rowmap.append(-1)
+        self.rowmap = np.array(rowmap, dtype=np.int32)
+        self.reg_cols = None if reg_cols is None else np.asarray(reg_cols, dtype=np.int64)
+        self.in_cols = None if in_cols is None else np.asarray(in_cols, dtype=np.int64)
+        self.scale = float(scale)
+        self.hoist = hoist  # (col0, n) or None
+
+    def colmap(self, ks_in):
+        n = (8 + ks_in) * 32
+        cm = -np.ones(n, dtype=np.int32)
+        if self.reg_cols is not None:
+            f = _REG_FEATURE
+            ok = f < len(self.reg_cols)
+            cm[:256][ok] = self.reg_cols[f[ok]]
+        if self.in_cols is not None:
+            assert len(self.in_cols) <= ks_in * 32
+            cm[256:256 + len(self.in_cols)] = self.in_cols
+        return cm
+
+
+class PackedNet:
+    """bf16 fragment-ordered weights + fp32 bias table of one network role on the device."""
+
+    def __init__(self, plans, ks_in, device):
+        assert len(plans) <= MAX_LAYERS
+        self.plans, self.ks_in, self.device = plans, ks_in, device
+        self.chunk_bytes = 2 * (8 + ks_in) * 1024
+        self.net = MpNet()
+        self.net.n_layers = len(plans)
+        off, self.offsets = 0, []
+        for i, p in enumerate(plans):
+            nch = len(p.rowmap) // 32
+            assert 1 <= nch <= MAX_CHUNKS
+            L = self.net.layer[i]
+            L.n_chunk, L.use_reg, L.use_in = nch, int(p.reg_cols is not None), int(p.in_cols is not None)
+            L.act, L.out_chunk = p.act, p.out_chunk
+            self.offsets.append(off)
+            off += nch
+        self.net.total_chunks = off
+        self.wpack = torch.zeros(off * self.chunk_bytes, dtype=torch.uint8, device=device)
+        self.bias = torch.zeros(MAX_LAYERS * BIAS_STRIDE, dtype=torch.float32, device=device)
+        self.rowmaps = [torch.from_numpy(p.rowmap).to(device) for p in plans]
+        self.colmaps = [torch.from_numpy(p.colmap(ks_in)).to(device) for p in plans]
+        self.colscales = [torch.full(((8 + ks_in) * 32,), p.scale, dtype=torch.float32, device=device) for p in plans]
+        self.version = None
+
+    def _params(self, lin):
+        if hasattr(lin, "weight_g"):
+            return lin.weight_v, lin.weight_g, lin.bias
+        return lin.weight, None, lin.bias
+
+    def _pack_layer(self, i, weights, hoist_vec):
+        p = self.plans[i]
+        v, g, b = self._params(p.lin)
+        v, b = v.detach().contiguous(), b.detach().contiguous()
+        g = None if g is None else g.detach().reshape(-1).contiguous()
+        h0, hn = p.hoist if (p.hoist is not None and hoist_vec is not None) else (0, 0)
+        wp = C.c_void_p(self.wpack.data_ptr() + self.offsets[i] * self.chunk_bytes) if weights else None
+        bp = C.c_void_p(self.bias.data_ptr() + 4 * i * BIAS_STRIDE)
+        check(lib().mp_pack_layer(ptr(v), ptr(g), ptr(b), v.shape[0], v.shape[1], ptr(self.rowmaps[i]),
+                                  len(p.rowmap), ptr(self.colmaps[i]), ptr(self.colscales[i]), self.ks_in, h0, hn,
+                                  ptr(hoist_vec) if hn else None, wp, bp, stream()), "mp_pack_layer")
+
+    def param_version(self):
+        vs = []
+        for p in self.plans:
+            for t in self._params(p.lin):
+                if t is not None:
+                    vs.append((t.data_ptr(), t._version))
+        return tuple(vs)
+
+    def refresh(self, hoist_vec=None):
+        """(Re)packs the weights if a parameter changed, and the hoisted layer-0 bias for this call's conditioning."""
+        ver = self.param_version()
+        full = ver != self.version
+        for i, p in enumerate(self.plans):
+            if full:
+                self._pack_layer(i, True, hoist_vec if p.hoist is not None else None)
+            elif p.hoist is not None:
+                self._pack_layer(i, False, hoist_vec)
+        self.version = ver
+
+
+def implicit_plans(net, variant):
+    """LayerPlans of an ImplicitNet (fg: d_in 3, L 6, cond 69; bg: d_in 4, L 10, cond 32).
+    variant 'sdf': last layer = sdf row only; 'full': 256 feature rows then the sdf row as the extra out chunk."""
+    E, nl = net.embed_dim, net.num_layers - 1
+    plans = []
+    for l, lin in enumerate(net.layers()):
+        out_dim = (lin.weight_v if hasattr(lin, "weight_v") else lin.weight).shape[0]
+        last = l == nl - 1
+        act = ACT_NONE if last else ACT_SOFTPLUS
+        if last:
+            if variant == "sdf":
+                plans.append(LayerPlan(lin, [0], reg_cols=np.arange(256), act=act, out_chunk=0))
+            else:
+                plans.append(LayerPlan(lin, list(range(1, out_dim)) + [0], reg_cols=np.arange(256), act=act,
+                                       out_chunk=8))
+        elif l == 0:
+            hoist = (E, net.cond_dim) if net.cond_dim > 0 else None
+            plans.append(LayerPlan(lin, range(out_dim), in_cols=np.arange(E), hoist=hoist, act=act))
+        elif l in net.skip_in:
+            prev = net.dims[l] - E   # width of the previous layer's output
+            plans.append(LayerPlan(lin, range(out_dim), reg_cols=np.arange(prev), in_cols=prev + np.arange(E),
+                                   scale=1.0 / math.sqrt(2.0), act=act))
+        else:
+            plans.append(LayerPlan(lin, range(out_dim), reg_cols=np.arange(net.dims[l]), act=act))
+    return plans
+
+
+def rendering_plans(net):
+    """LayerPlans of a RenderingNet: 'pose_no_view' = [x_c3, n3 | pose8 hoisted | feat256]; 'nerf_frame_encoding' =
+    [PE4(view) 27 | frame32 hoisted | feat256]."""
+    plans, nl = [], net.num_layers - 1
+    for l, lin in enumerate(net.layers()):
+        out_dim = (lin.weight_v if hasattr(lin, "weight_v") else lin.weight).shape[0]
+        last = l == nl - 1
+        act = ACT_NONE if last else ACT_RELU
+        rows = range(out_dim)
+        if l == 0:
+            if net.mode == "pose_no_view":
+                plans.append(LayerPlan(lin, rows, reg_cols=14 + np.arange(256), in_cols=np.arange(6), hoist=(6, 8),
+                                       act=act, out_chunk=0 if last else -1))
+            else:
+                plans.append(LayerPlan(lin, rows, reg_cols=59 + np.arange(256), in_cols=np.arange(27), hoist=(27, 32),
+                                       act=act, out_chunk=0 if last else -1))
+        else:
+            plans.append(LayerPlan(lin, rows, reg_cols=np.arange(net.dims[l]), act=act, out_chunk=0 if last else -1))
+    return plans
+
+
+def packed(module, role, ks_in):
+    """Per-module cache of PackedNet objects."""
+    cache = module.__dict__.setdefault("_mp_packed", {})
+    dev = next(module.parameters()).device
+    key = (role, ks_in, str(dev))
+    if key not in cache:
+        from .networks import ImplicitNet
+        plans = implicit_plans(module, role) if isinstance(module, ImplicitNet) else rendering_plans(module)
+        cache[key] = PackedNet(plans, ks_in, dev)
+    return cache[key]
+
+
+class PoseEmbed:
+    """lin_pose(cond) of RenderingNet 'pose_no_view' (networks.py:279-280) computed by the bias path of mp_pack_layer."""
+
+    def __init__(self, net):
+        self.net = net
+        dev = net.lin_pose.weight.device
+        self.rowmap = torch.tensor(list(range(8)) + [-1] * 24, dtype=torch.int32, device=dev)
+        self.colmap = -torch.ones(10 * 32, dtype=torch.int32, device=dev)
+        self.colscale = torch.ones(10 * 32, dtype=torch.float32, device=dev)
+        self.out = torch.zeros(BIAS_STRIDE, dtype=torch.float32, device=dev)
+
+    def __call__(self, cond_vec):
+        lp = self.net.lin_pose
+        w, b = lp.weight.detach().contiguous(), lp.bias.detach().contiguous()
+        check(lib().mp_pack_layer(ptr(w), None, ptr(b), 8, 69, ptr(self.rowmap), 32, ptr(self.colmap),
+                                  ptr(self.colscale), 2, 0, 69, ptr(cond_vec), None, ptr(self.out), stream()),
+              "mp_pack_layer(lin_pose)")
+        return self.out  # first 8 floats
+
+
+# ------------------------------------------------------------------------------------------------ module-level ops
+def implicit_forward(net, x, cond_vec):
+    """ImplicitNet.forward for external callers: (N, d_in) -> (N, 257) fp32 (features are bf16-rounded)."""
+    require_device()
+    x = x.detach().float().contiguous()
+    ks_in = 2 if net.d_in == 3 else 3
+    pk = packed(net, "full", ks_in)
+    pk.refresh(None if cond_vec is None else cond_vec.detach().float().contiguous())
+    out = torch.empty(x.shape[0], 257, dtype=torch.float32, device=x.device)
+    check(lib().mp_mlp_full(C.byref(pk.net), ptr(pk.wpack), ptr(pk.bias), ptr(x), net.d_in, x.shape[0], ptr(out),
+                            stream()), "mp_mlp_full")
+    return out
+
+
+def implicit_sdf(net, x_c, cond_vec):
+    """sdf column of the foreground ImplicitNet at canonical points (N,3) -> (N,)."""
+    require_device()
+    x_c = x_c.detach().float().contiguous()
+    pk = packed(net, "sdf", 2)
+    pk.refresh(cond_vec.detach().float().contiguous())
+    out = torch.empty(x_c.shape[0], dtype=torch.float32, device=x_c.device)
+    check(lib().mp_mlp_sdf(C.byref(pk.net), ptr(pk.wpack), ptr(pk.bias), ptr(x_c), None, None, x_c.shape[0],
+                           ptr(out), stream()), "mp_mlp_sdf")
+    return out
+
+
+def shade_points(imp, ren, x_c, jinv, cond_vec):
+    """sdf, normals, rgb at canonical points (forward-mode ImplicitNet + RenderingNet 'pose_no_view')."""
+    require_device()
+    n = x_c.shape[0]
+    x_c = x_c.detach().float().contiguous()
+    jinv = jinv.detach().float().contiguous()
+    cond_vec = cond_vec.detach().float().contiguous()
+    pki = packed(imp, "full", 2)
+    pki.refresh(cond_vec)
+    pkr = packed(ren, "color", 2)
+    pe = ren.__dict__.setdefault("_mp_pose_embed", None) or PoseEmbed(ren)
+    ren.__dict__["_mp_pose_embed"] = pe
+    pkr.refresh(pe(cond_vec))
+    dev = x_c.device
+    sdf = torch.empty(n, dtype=torch.float32, device=dev)
+    nrm = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    rgb = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    tiles = (n + 255) // 256 * 4
+    feat = torch.empty(tiles * 8 * 4 * 1024, dtype=torch.uint8, device=dev)
+    check(lib().mp_mlp_shade(C.byref(pki.net), ptr(pki.wpack), ptr(pki.bias), ptr(x_c), ptr(jinv), None, None, n,
+                             ptr(sdf), ptr(nrm), ptr(feat), stream()), "mp_mlp_shade")
+    check(lib().mp_mlp_color(C.byref(pkr.net), ptr(pkr.wpack), ptr(pkr.bias), ptr(x_c), ptr(nrm), ptr(feat), None,
+                             None, n, ptr(rgb), stream()), "mp_mlp_color")
+    return sdf, nrm, rgb
+
+
+def rendering_forward(net, points, normals, view_dirs, body_pose, feature_vectors, frame_latent_code):
+    raise NotImplementedError("RenderingNet is evaluated inside the fused kernels (hip.shade_points / background); "
+                              "a standalone forward with externally supplied fp32 features is not part of the hot path")
+
+
+def background(bg_imp, bg_ren, dirs, cam, z_bg, frame_code, radius=3.0):
+    """bg_rgb (R,3) of the NeRF++ background branch. z_bg: (n_bg,) shared or (R,n_bg) per-ray inverse depths, descending."""
+    require_device()
+    dirs = dirs.detach().float().contiguous()
+    cam = cam.detach().float().contiguous()
+    z_bg = z_bg.detach().float().contiguous()
+    code = frame_code.detach().float().reshape(-1).contiguous()
+    pki = packed(bg_imp, "full", 3)
+    pki.refresh(code)
+    pkr = packed(bg_ren, "color", 3)
+    pkr.refresh(code)
+    R = dirs.shape[0]
+    assert z_bg.shape[-1] == 32, "the background kernel is specialised for 32 inverse-sphere samples"
+    out = torch.empty(R, 3, dtype=torch.float32, device=dirs.device)
+    check(lib().mp_background(C.byref(pki.net), ptr(pki.wpack), ptr(pki.bias), C.byref(pkr.net), ptr(pkr.wpack),
+                              ptr(pkr.bias), ptr(dirs), ptr(cam), ptr(z_bg), int(z_bg.dim() == 2), R,
+                              C.c_float(radius), ptr(out), stream()), "mp_background")
+    return out
