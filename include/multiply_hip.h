@@ -128,8 +128,8 @@ int mp_ray_hits_from_index(const int* hit_index, int n_hit, int n_rays, int* hit
 /* ---- canonical warp ---------------------------------------------------------------------------
  * SMPLDeformer.forward(inverse=True) (deformer.py:19-50, 72-88): nearest posed vertex -> its skinning weights ->
  * x_c = (sum_j w_j T_j)^-1 x ; outlier = dist > 0.1.
- * Points are either explicit (pts [n][3]) or implicit samples of hit rays: point id = k*n_s + s,
- * x = cam + z[k*z_stride + s] * dirs[hit_index[k]].
+ * Points are either explicit (pts [max_rays][3], dirs, pose, hit_index, hit_count and z unused) or implicit samples of hit rays:
+ * point id = k*n_s + s, x = cam + z[k*z_stride + s] * dirs[hit_index[k]], cam = pose[:3,3].
  *   mode 0 (training): every point is written to xc and appended to worklist.
  *   mode 1 (eval): outliers get sdf_out = 4 (multiply.py:142-143) and are NOT appended.
  *   active [ceil(n_hit/group)] per-group flag or NULL.  Outputs: xc [n][3], worklist, *work_count (atomic, must be 0). */
@@ -137,6 +137,12 @@ int mp_warp_inverse(const float* pts, const float* dirs, const float* pose, cons
                     const float* z, int z_stride, int n_s, int max_rays, const float* vsorted, const float* cbound,
                     const float* skin_w, const float* tfs, int mode, const int* ray_active, float* xc,
                     unsigned char* outlier, float* sdf_out, int* worklist, int* work_count, void* stream);
+/* The same for the final samples of the shading pass (z rows hold n_s+1 depths).  eval_mode: outliers get sdf 4 and are
+ * dropped from the worklist only when their compositing alpha 1-exp(-sigma(4) dt) is exactly 0 in fp32. */
+int mp_warp_inverse_shade(const float* dirs, const float* pose, const int* hit_index, const int* hit_count,
+                          const float* z, int z_stride, int n_s, int max_rays, const float* vsorted, const float* cbound,
+                          const float* skin_w, const float* tfs, int eval_mode, const float* beta, float* xc,
+                          unsigned char* outlier, float* sdf_out, int* worklist, int* work_count, void* stream);
 /* Jacobian of forward skinning at canonical points (deformer.py:31-35 + multiply.py:625-641): nearest CANONICAL
  * vertex -> weights -> J = (sum_j w_j T_j)[:3,:3] -> jinv [id][9].  Only ids in worklist. */
 int mp_warp_jacobian(const float* xc, const int* worklist, const int* count, int max_count, const float* vsorted_c,
@@ -145,7 +151,10 @@ int mp_warp_jacobian(const float* xc, const int* worklist, const int* count, int
 /* ---- VolSDF error-bound sampler (ray_sampler.py:66-220), split at the SDF queries ---------------
  * State per hit ray k (row stride zmax = 640): zs/sdfs sorted samples and their sdf, nz count, znew/sdfnew [128]
  * the samples whose sdf is being queried, beta, done flag.  Per group: not_converged flags.
- * cfg = {N_samples, N_samples_eval, N_samples_extra, beta_iters, max_total_iters} ints, {eps, add_tiny, near} floats. */
+ * cfg = {N_samples, N_samples_eval, N_samples_extra, beta_iters, max_total_iters} ints, {eps, add_tiny, near} floats.
+ * A convergence group = the hit rays whose ray id falls in one block of `group_size` consecutive rays of the call
+ * (n_rays_total rays): the reference's `beta.max() > beta0` vote (ray_sampler.py:137) is taken per group, so that a
+ * whole-frame call with group_size = pixel_per_batch reproduces the reference's chunked rendering loop exactly. */
 typedef struct {
     int n_samples, n_samples_eval, n_samples_extra, beta_iters, max_total_iters;
     float eps, add_tiny, near_;
@@ -158,15 +167,16 @@ typedef struct {
 } MpSamplerState;
 /* uniform start (ray_sampler.py:21-42, 70-76); t_rand [max_rays][n_eval] or NULL (eval: no jitter) */
 int mp_sampler_init(const MpSamplerCfg* cfg, const MpSamplerState* st, const float* far, const int* hit_index,
-                    const int* hit_count, int max_rays, int group_size, const float* t_rand, void* stream);
+                    const int* hit_count, int max_rays, int group_size, int n_rays_total, const float* t_rand,
+                    void* stream);
 /* merge the queried samples, d*, error bound, beta bisection, group convergence vote (ray_sampler.py:89-137) */
 int mp_sampler_bound(const MpSamplerCfg* cfg, const MpSamplerState* st, const float* beta0, const int* hit_index,
-                     const int* hit_count, int max_rays, int group_size, int iter, void* stream);
+                     const int* hit_count, int max_rays, int group_size, int n_rays_total, int iter, void* stream);
 /* up-sample from the error-bound pdf, or draw the final samples and assemble zfinal (ray_sampler.py:139-209);
  * u_final [max_rays][n_samples] / extra_idx [n_extra] supply the training randomness, NULL = eval linspace */
 int mp_sampler_resample(const MpSamplerCfg* cfg, const MpSamplerState* st, const float* beta0, const float* far,
-                        const int* hit_index, const int* hit_count, int max_rays, int group_size, int iter,
-                        const float* u_final, const int* extra_idx, void* stream);
+                        const int* hit_index, const int* hit_count, int max_rays, int group_size, int n_rays_total,
+                        int iter, const float* u_final, const int* extra_idx, void* stream);
 
 /* ---- compositing (multiply.py:425-480, 544-545, 590) ---------------------------------------------
  * Per ray: merge the persons' samples by t_end (ties: lower person first), Laplace density (density.py:20-29),

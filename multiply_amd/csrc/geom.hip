@@ -1,0 +1,699 @@
+// Geometry kernels: SMPL posing, nearest-vertex structure, canonical warp, rays and box culling.
+// Entry points and the reference code they replace: include/multiply_hip.h.
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <limits.h>
+#include "../../include/multiply_hip.h"
+#include "common.hpp"
+
+namespace {
+
+constexpr int V = MP_SMPL_V, NJ = MP_SMPL_J, NC = MP_KNN_NC, CL = MP_KNN_CLUSTER;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// block-wide sum for blockDim.x = 256 (4 waves)
+__device__ __forceinline__ float block_sum256(float v, float* sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// ------------------------------------------------------------------------------------------------ SMPL (lbs.py)
+// work layout (floats): v_shaped [3V] | J [72] | A [24*16] | pose_feature [207]
+constexpr int W_VS = 0, W_J = 3 * V, W_A = W_J + 72 + 8, W_PF = W_A + NJ * 16;
+
+__global__ void k_smpl_shape(const float* __restrict__ v_template, const float* __restrict__ shapedirs,
+                             const float* __restrict__ params, float* __restrict__ work) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over V*3
+    if (i >= 3 * V) return;
+    const float* betas = params + 76;
+    float acc = 0.0f;
+#pragma unroll
+    for (int l = 0; l < 10; ++l) acc += betas[l] * shapedirs[(size_t)i * 10 + l];  // blend_shapes, lbs.py:252-273
+    work[W_VS + i] = v_template[i] + acc;
+}
+
+__global__ __launch_bounds__(256) void k_smpl_joints(const float* __restrict__ j_regressor, float* __restrict__ work) {
+    __shared__ float sh[4];
+    const int j = blockIdx.x;  // joint
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int i = threadIdx.x; i < V; i += 256) {  // vertices2joints, lbs.py:232-249
+        const float w = j_regressor[(size_t)j * V + i];
+        a0 += w * work[W_VS + 3 * i];
+        a1 += w * work[W_VS + 3 * i + 1];
+        a2 += w * work[W_VS + 3 * i + 2];
+    }
+    a0 = block_sum256(a0, sh);
+    a1 = block_sum256(a1, sh);
+    a2 = block_sum256(a2, sh);
+    if (threadIdx.x == 0) { work[W_J + 3 * j] = a0; work[W_J + 3 * j + 1] = a1; work[W_J + 3 * j + 2] = a2; }
+}
+
+__device__ void mat4_mul(const float* a, const float* b, float* c) {
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float s = 0.f;
+            for (int k = 0; k < 4; ++k) s += a[4 * i + k] * b[4 * k + j];
+            c[4 * i + j] = s;
+        }
+}
+
+__global__ __launch_bounds__(64) void k_smpl_chain(const int* __restrict__ parents, const float* __restrict__ params,
+                                                   const float* __restrict__ tfs_c_inv, float* __restrict__ work,
+                                                   float* __restrict__ tfs, float* __restrict__ joints) {
+    __shared__ float R[NJ][9];
+    __shared__ float G[NJ][16];
+    const int t = threadIdx.x;
+    const float scale = params[0];
+    const float* transl = params + 1;
+    const float* thetas = params + 4;
+    const float* J = work + W_J;
+    if (t < NJ) {  // batch_rodrigues, lbs.py:276-307
+        const float rx0 = thetas[3 * t], ry0 = thetas[3 * t + 1], rz0 = thetas[3 * t + 2];
+        const float ax = rx0 + 1e-8f, ay = ry0 + 1e-8f, az = rz0 + 1e-8f;
+        const float angle = sqrtf(ax * ax + ay * ay + az * az);
+        const float rx = rx0 / angle, ry = ry0 / angle, rz = rz0 / angle;
+        float s, c;
+        sincosf(angle, &s, &c);
+        const float K[9] = {0.f, -rz, ry, rz, 0.f, -rx, -ry, rx, 0.f};
+        float KK[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                float a = 0.f;
+                for (int k = 0; k < 3; ++k) a += K[3 * i + k] * K[3 * k + j];
+                KK[3 * i + j] = a;
+            }
+        for (int i = 0; i < 9; ++i) R[t][i] = ((i % 4 == 0) ? 1.0f : 0.0f) + s * K[i] + (1.0f - c) * KK[i];
+    }
+    __syncthreads();
+    // pose_feature = (R[1:] - I).flatten (lbs.py:199)
+    for (int i = t; i < 207; i += 64) {
+        const int j = i / 9 + 1, e = i % 9;
+        work[W_PF + i] = R[j][e] - ((e % 4 == 0) ? 1.0f : 0.0f);
+    }
+    if (t == 0) {  // batch_rigid_transform, lbs.py:323-377 (24 tiny sequential 4x4 products)
+        for (int j = 0; j < NJ; ++j) {
+            const int p = parents[j];
+            float rel[3];
+            for (int a = 0; a < 3; ++a) rel[a] = J[3 * j + a] - (j > 0 ? J[3 * p + a] : 0.0f);
+            float tm[16];
+            for (int a = 0; a < 3; ++a) {
+                for (int b = 0; b < 3; ++b) tm[4 * a + b] = R[j][3 * a + b];
+                tm[4 * a + 3] = rel[a];
+            }
+            tm[12] = tm[13] = tm[14] = 0.f;
+            tm[15] = 1.f;
+            if (j == 0) for (int i = 0; i < 16; ++i) G[0][i] = tm[i];
+            else mat4_mul(G[p], tm, G[j]);
+        }
+    }
+    __syncthreads();
+    if (t < NJ) {
+        float A[16];
+        for (int i = 0; i < 16; ++i) A[i] = G[t][i];
+        // rel_transforms = G - pad(G @ [J;0])  (lbs.py:372-375)
+        for (int a = 0; a < 4; ++a) {
+            float s = 0.f;
+            for (int k = 0; k < 3; ++k) s += G[t][4 * a + k] * J[3 * t + k];
+            A[4 * a + 3] -= s;
+        }
+        for (int i = 0; i < 16; ++i) work[W_A + 16 * t + i] = A[i];
+        // SMPLServer.forward scaling (smpl.py:80-91)
+        float tf[16];
+        for (int i = 0; i < 16; ++i) tf[i] = A[i];
+        for (int a = 0; a < 3; ++a) {
+            for (int b = 0; b < 4; ++b) tf[4 * a + b] *= scale;
+            tf[4 * a + 3] += transl[a] * scale;
+        }
+        if (tfs_c_inv) {
+            float o[16];
+            mat4_mul(tf, tfs_c_inv + 16 * t, o);
+            for (int i = 0; i < 16; ++i) tfs[16 * t + i] = o[i];
+        } else {
+            for (int i = 0; i < 16; ++i) tfs[16 * t + i] = tf[i];
+        }
+        for (int a = 0; a < 3; ++a) joints[3 * t + a] = G[t][4 * a + 3] * scale + transl[a] * scale;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_smpl_verts(const float* __restrict__ posedirs,
+                                                    const float* __restrict__ lbs_weights,
+                                                    const float* __restrict__ params, const float* __restrict__ work,
+                                                    float* __restrict__ verts) {
+    __shared__ float pf[207];
+    __shared__ float A[NJ * 16];
+    for (int i = threadIdx.x; i < 207; i += 256) pf[i] = work[W_PF + i];
+    for (int i = threadIdx.x; i < NJ * 16; i += 256) A[i] = work[W_A + i];
+    __syncthreads();
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    float p[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float acc = 0.f;
+        for (int q = 0; q < 207; ++q) acc += pf[q] * posedirs[(size_t)q * (3 * V) + 3 * v + k];  // lbs.py:201-202
+        p[k] = acc + work[W_VS + 3 * v + k];
+    }
+    float T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = 0.f;
+    for (int j = 0; j < NJ; ++j) {  // lbs.py:217-221
+        const float w = lbs_weights[(size_t)v * NJ + j];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] += w * A[16 * j + i];
+    }
+    const float scale = params[0];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float x = T[4 * a] * p[0] + T[4 * a + 1] * p[1] + T[4 * a + 2] * p[2] + T[4 * a + 3];
+        verts[3 * v + a] = x * scale + params[1 + a] * scale;  // smpl.py:77-78
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ KNN structure
+__global__ __launch_bounds__(64) void k_knn_build(const float* __restrict__ verts, const int* __restrict__ perm,
+                                                  float4* __restrict__ vsorted, float4* __restrict__ cbound) {
+    const int c = blockIdx.x, l = threadIdx.x;
+    const int id = perm[c * CL + l];
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (id >= 0) { x = verts[3 * id]; y = verts[3 * id + 1]; z = verts[3 * id + 2]; }
+    const float n = wave_sum(id >= 0 ? 1.f : 0.f);
+    const float cx = wave_sum(x) / n, cy = wave_sum(y) / n, cz = wave_sum(z) / n;
+    const float dx = x - cx, dy = y - cy, dz = z - cz;
+    const float r = wave_max(id >= 0 ? sqrtf(dx * dx + dy * dy + dz * dz) : 0.f);
+    float4 o;
+    if (id >= 0) { o.x = x; o.y = y; o.z = z; o.w = __int_as_float(id); }
+    else { o.x = 1e18f; o.y = 1e18f; o.z = 1e18f; o.w = __int_as_float(INT_MAX - 1); }
+    vsorted[c * CL + l] = o;
+    if (l == 0) cbound[c] = make_float4(cx, cy, cz, r * 1.00001f + 1e-7f);
+}
+
+// Exact nearest vertex among the clustered set held in LDS (vs, cb).  cap2: search radius^2 (FLT_MAX = unbounded).
+// Returns the original vertex id (INT_MAX when nothing lies within the cap) and the squared distance.
+// Ties -> lowest vertex id, like an argmin over the original order (pytorch3d knn_points / deformer.py:39).
+__device__ __forceinline__ void knn_query(const float4* vs, const float4* cb, float px, float py, float pz, float cap2,
+                                          float& best, int& bi) {
+    float ub2 = FLT_MAX;
+    for (int c = 0; c < NC; ++c) {
+        const float4 b = cb[c];
+        const float dx = px - b.x, dy = py - b.y, dz = pz - b.z;
+        const float u = sqrtf(dx * dx + dy * dy + dz * dz) + b.w;
+        ub2 = fminf(ub2, u * u);
+    }
+    best = fminf(ub2 * 1.0001f + 1e-12f, cap2);
+    bi = INT_MAX;
+    for (int c = 0; c < NC; ++c) {
+        const float4 b = cb[c];
+        const float dx = px - b.x, dy = py - b.y, dz = pz - b.z;
+        const float lb = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz) - b.w, 0.0f);
+        if (__any(lb * lb * 0.9999f <= best)) {
+            const float4* cv = vs + c * CL;
+#pragma unroll 8
+            for (int k = 0; k < CL; ++k) {
+                const float4 v = cv[k];
+                const float ex = px - v.x, ey = py - v.y, ez = pz - v.z;
+                const float d2 = ex * ex + ey * ey + ez * ez;
+                const int id = __float_as_int(v.w);
+                const bool upd = d2 < best || (d2 == best && id < bi);
+                best = upd ? d2 : best;
+                bi = upd ? id : bi;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void load_knn_lds(float4* vs, float4* cb, const float* vsorted, const float* cbound) {
+    const float4* gv = (const float4*)vsorted;
+    const float4* gc = (const float4*)cbound;
+    for (int i = threadIdx.x; i < NC * CL; i += blockDim.x) vs[i] = gv[i];
+    for (int i = threadIdx.x; i < NC; i += blockDim.x) cb[i] = gc[i];
+}
+
+// blended bone transform rows 0..2 (T[12]) and T[3][3] (s) of vertex `vid`
+__device__ __forceinline__ void blend_tf(const float* __restrict__ skin_w, const float* tfs_lds, int vid, float (&T)[12],
+                                         float& s33) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = 0.f;
+    s33 = 0.f;
+    const float* w = skin_w + (size_t)vid * NJ;
+    for (int j = 0; j < NJ; ++j) {
+        const float wj = w[j];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] += wj * tfs_lds[16 * j + i];
+        s33 += wj * tfs_lds[16 * j + 15];
+    }
+}
+
+__device__ __forceinline__ void inv3(const float (&T)[12], float (&I)[9]) {
+    const float a = T[0], b = T[1], c = T[2], d = T[4], e = T[5], f = T[6], g = T[8], h = T[9], i = T[10];
+    const float c0 = e * i - f * h, c1 = f * g - d * i, c2 = d * h - e * g;
+    const float det = a * c0 + b * c1 + c * c2;
+    const float r = 1.0f / det;
+    I[0] = c0 * r; I[1] = (c * h - b * i) * r; I[2] = (b * f - c * e) * r;
+    I[3] = c1 * r; I[4] = (a * i - c * g) * r; I[5] = (c * d - a * f) * r;
+    I[6] = c2 * r; I[7] = (b * g - a * h) * r; I[8] = (a * e - b * d) * r;
+}
+
+constexpr int WARP_THREADS = 512;
+constexpr int WARP_LDS = NC * CL * 16 + NC * 16 + NJ * 16 * 4;
+
+// mode 0: all points -> xc + worklist; mode 1: eval, outliers get sdf 4 and are skipped;
+// mode 2: eval shading, outliers get sdf 4 and are skipped only when their alpha is exactly 0 in fp32
+__global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
+    const float* __restrict__ pts, const float* __restrict__ dirs, const float* __restrict__ pose,
+    const int* __restrict__ hit_index, const int* __restrict__ hit_count, const float* __restrict__ z, int z_stride,
+    int n_s, int max_rays, int n_pts, const float* __restrict__ vsorted, const float* __restrict__ cbound,
+    const float* __restrict__ skin_w, const float* __restrict__ tfs, int mode, const int* __restrict__ ray_active,
+    const float* __restrict__ beta_p, float* __restrict__ xc, unsigned char* __restrict__ outlier,
+    float* __restrict__ sdf_out, int* __restrict__ worklist, int* __restrict__ work_count) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* vs = (float4*)smem;
+    float4* cb = vs + NC * CL;
+    float* tl = (float*)(cb + NC);
+    load_knn_lds(vs, cb, vsorted, cbound);
+    for (int i = threadIdx.x; i < NJ * 16; i += blockDim.x) tl[i] = tfs[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const bool rays = pts == nullptr;
+    const int n_rays = rays ? min(*hit_count, max_rays) : 0;
+    const int n_slab = rays ? ((n_rays + 63) / 64) * n_s : (n_pts + 63) / 64;
+    float cam[3] = {0.f, 0.f, 0.f};
+    if (rays) { cam[0] = pose[3]; cam[1] = pose[7]; cam[2] = pose[11]; }
+    const float cap2 = mode == 0 ? FLT_MAX : 0.0101f;  // eval only needs neighbours within the 0.1 outlier radius
+    for (int slab = blockIdx.x * nw + wave; slab < n_slab; slab += gridDim.x * nw) {
+        int pid = -1;
+        float x = 0.f, y = 0.f, zz = 0.f, dt = 0.f;
+        if (rays) {
+            const int k = (slab / n_s) * 64 + lane, s = slab % n_s;
+            if (k < n_rays && (!ray_active || ray_active[k])) {
+                const int r = hit_index[k];
+                const float t = z[(size_t)k * z_stride + s];
+                x = cam[0] + t * dirs[3 * r]; y = cam[1] + t * dirs[3 * r + 1]; zz = cam[2] + t * dirs[3 * r + 2];
+                pid = k * n_s + s;
+                if (mode == 2) dt = z[(size_t)k * z_stride + s + 1] - t;
+            }
+        } else {
+            const int i = slab * 64 + lane;
+            if (i < n_pts) { x = pts[3 * i]; y = pts[3 * i + 1]; zz = pts[3 * i + 2]; pid = i; }
+        }
+        float best; int bi;
+        knn_query(vs, cb, x, y, zz, pid >= 0 ? cap2 : -1.0f, best, bi);  // idle lanes never open a cluster
+        bool append = false;
+        if (pid >= 0) {
+            // outlier = sqrt(min(d2, 4)) > 0.1 (deformer.py:41-49)
+            const bool is_out = bi == INT_MAX || sqrtf(fminf(best, 4.0f)) > 0.1f;
+            if (outlier) outlier[pid] = is_out ? 1 : 0;
+            bool need = true;
+            if (mode != 0 && is_out) {
+                sdf_out[pid] = 4.0f;  // multiply.py:142-143
+                need = false;
+                if (mode == 2) {  // keep it only if its compositing weight can be non-zero
+                    need = mp::alpha_of(4.0f, *beta_p, dt) != 0.0f;
+                }
+            }
+            if (need && bi == INT_MAX) {  // rare: outlier that still has weight -> exact unbounded search
+                knn_query(vs, cb, x, y, zz, FLT_MAX, best, bi);
+            }
+            if (need) {
+                float T[12], s33, I[9];
+                blend_tf(skin_w, tl, bi, T, s33);
+                inv3(T, I);
+                const float qx = x - T[3] / s33, qy = y - T[7] / s33, qz = zz - T[11] / s33;
+                xc[3 * (size_t)pid] = I[0] * qx + I[1] * qy + I[2] * qz;
+                xc[3 * (size_t)pid + 1] = I[3] * qx + I[4] * qy + I[5] * qz;
+                xc[3 * (size_t)pid + 2] = I[6] * qx + I[7] * qy + I[8] * qz;
+                append = worklist != nullptr;
+            }
+        }
+        if (worklist) {
+            const unsigned long long m = __ballot(append);
+            if (m) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(work_count, __popcll(m));
+                base = __shfl(base, 0);
+                if (append) worklist[base + __popcll(m & ((1ull << lane) - 1ull))] = pid;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(WARP_THREADS) void k_warp_jacobian(const float* __restrict__ xc,
+                                                                const int* __restrict__ worklist,
+                                                                const int* __restrict__ count_p, int max_count,
+                                                                const float* __restrict__ vsorted_c,
+                                                                const float* __restrict__ cbound_c,
+                                                                const float* __restrict__ skin_w,
+                                                                const float* __restrict__ tfs, float* __restrict__ jinv) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* vs = (float4*)smem;
+    float4* cb = vs + NC * CL;
+    float* tl = (float*)(cb + NC);
+    load_knn_lds(vs, cb, vsorted_c, cbound_c);
+    for (int i = threadIdx.x; i < NJ * 16; i += blockDim.x) tl[i] = tfs[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int count = count_p ? min(*count_p, max_count) : max_count;
+    for (int slab = blockIdx.x * nw + wave; slab * 64 < count; slab += gridDim.x * nw) {
+        const int w = slab * 64 + lane;
+        const int id = w < count ? (worklist ? worklist[w] : w) : -1;
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (id >= 0) { x = xc[3 * (size_t)id]; y = xc[3 * (size_t)id + 1]; z = xc[3 * (size_t)id + 2]; }
+        float best; int bi;
+        knn_query(vs, cb, x, y, z, id >= 0 ? FLT_MAX : -1.0f, best, bi);
+        if (id >= 0) {
+            float T[12], s33, I[9];
+            blend_tf(skin_w, tl, bi, T, s33);
+            inv3(T, I);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) jinv[9 * (size_t)id + i] = I[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ oriented box (PCA)
+__device__ void jacobi3(float a[3][3], float v[3][3]) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) v[i][j] = i == j ? 1.f : 0.f;
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (fabsf(a[p][q]) < 1e-20f) continue;
+                const float th = (a[q][q] - a[p][p]) / (2.f * a[p][q]);
+                const float t = (th >= 0.f ? 1.f : -1.f) / (fabsf(th) + sqrtf(th * th + 1.f));
+                const float c = 1.f / sqrtf(t * t + 1.f), s = t * c;
+                for (int k = 0; k < 3; ++k) {
+                    const float akp = a[k][p], akq = a[k][q];
+                    a[k][p] = c * akp - s * akq;
+                    a[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const float apk = a[p][k], aqk = a[q][k];
+                    a[p][k] = c * apk - s * aqk;
+                    a[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const float vkp = v[k][p], vkq = v[k][q];
+                    v[k][p] = c * vkp - s * vkq;
+                    v[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_obb(const float* __restrict__ verts, float inflate, float* __restrict__ obb) {
+    __shared__ float sh[4];
+    __shared__ float ax[9], mean[3];
+    const int t = threadIdx.x;
+    float m[3] = {0.f, 0.f, 0.f};
+    for (int i = t; i < V; i += 256) { m[0] += verts[3 * i]; m[1] += verts[3 * i + 1]; m[2] += verts[3 * i + 2]; }
+    for (int a = 0; a < 3; ++a) m[a] = block_sum256(m[a], sh) / V;
+    float cv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = t; i < V; i += 256) {
+        const float x = verts[3 * i] - m[0], y = verts[3 * i + 1] - m[1], z = verts[3 * i + 2] - m[2];
+        cv[0] += x * x; cv[1] += x * y; cv[2] += x * z; cv[3] += y * y; cv[4] += y * z; cv[5] += z * z;
+    }
+    for (int a = 0; a < 6; ++a) cv[a] = block_sum256(cv[a], sh);
+    if (t == 0) {
+        float A[3][3] = {{cv[0], cv[1], cv[2]}, {cv[1], cv[3], cv[4]}, {cv[2], cv[4], cv[5]}}, Vv[3][3];
+        jacobi3(A, Vv);
+        for (int a = 0; a < 3; ++a)
+            for (int k = 0; k < 3; ++k) ax[3 * a + k] = Vv[k][a];  // row a = eigenvector a
+        for (int a = 0; a < 3; ++a) mean[a] = m[a];
+    }
+    __syncthreads();
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = t; i < V; i += 256) {
+        const float x = verts[3 * i] - mean[0], y = verts[3 * i + 1] - mean[1], z = verts[3 * i + 2] - mean[2];
+        for (int a = 0; a < 3; ++a) {
+            const float p = ax[3 * a] * x + ax[3 * a + 1] * y + ax[3 * a + 2] * z;
+            lo[a] = fminf(lo[a], p);
+            hi[a] = fmaxf(hi[a], p);
+        }
+    }
+    __shared__ float slo[4][3], shi[4][3];
+    for (int a = 0; a < 3; ++a) { lo[a] = wave_min(lo[a]); hi[a] = wave_max(hi[a]); }
+    if ((t & 63) == 0) for (int a = 0; a < 3; ++a) { slo[t >> 6][a] = lo[a]; shi[t >> 6][a] = hi[a]; }
+    __syncthreads();
+    if (t == 0) {
+        float mid[3], half[3];
+        for (int a = 0; a < 3; ++a) {
+            const float l = fminf(fminf(slo[0][a], slo[1][a]), fminf(slo[2][a], slo[3][a]));
+            const float h = fmaxf(fmaxf(shi[0][a], shi[1][a]), fmaxf(shi[2][a], shi[3][a]));
+            mid[a] = 0.5f * (l + h);
+            half[a] = 0.5f * (h - l) * inflate;
+        }
+        for (int k = 0; k < 3; ++k) obb[k] = mean[k] + ax[k] * mid[0] + ax[3 + k] * mid[1] + ax[6 + k] * mid[2];
+        for (int i = 0; i < 9; ++i) obb[3 + i] = ax[i];
+        for (int a = 0; a < 3; ++a) obb[12 + a] = half[a];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ rays
+__global__ void k_ray_setup(const float* __restrict__ uv, const float* __restrict__ K, const float* __restrict__ P,
+                            int n, float radius, float* __restrict__ dirs, float* __restrict__ far) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float fx = K[0], fy = K[5], cx = K[2], cy = K[6], sk = K[1];
+    const float x = uv[2 * i], y = uv[2 * i + 1];
+    // lift (rend_util.py:73-87) with z = 1
+    const float xl = (x - cx + cy * sk / fy - sk * y / fy) / fx;
+    const float yl = (y - cy) / fy;
+    float w[3], d[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        w[a] = P[4 * a] * xl + P[4 * a + 1] * yl + P[4 * a + 2] + P[4 * a + 3];
+        d[a] = w[a] - P[4 * a + 3];
+    }
+    const float nrm = fmaxf(sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e-12f);  // F.normalize
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { d[a] /= nrm; dirs[3 * i + a] = d[a]; }
+    // far root of the bounding sphere (rend_util.py:131-147)
+    const float ox = P[3], oy = P[7], oz = P[11];
+    const float b = d[0] * ox + d[1] * oy + d[2] * oz;
+    const float under = b * b - ((ox * ox + oy * oy + oz * oz) - radius * radius);
+    far[i] = fmaxf(sqrtf(under) - b, 0.0f);
+}
+
+__global__ void k_ray_box(const float* __restrict__ dirs, const float* __restrict__ P, const float* __restrict__ obb,
+                          int n, int* __restrict__ flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float o[3] = {P[3] - obb[0], P[7] - obb[1], P[11] - obb[2]};
+    const float d[3] = {dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]};
+    float tmin = -FLT_MAX, tmax = FLT_MAX;
+    bool hit = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float* ax = obb + 3 + 3 * a;
+        const float oo = ax[0] * o[0] + ax[1] * o[1] + ax[2] * o[2];
+        const float dd = ax[0] * d[0] + ax[1] * d[1] + ax[2] * d[2];
+        const float h = obb[12 + a];
+        if (fabsf(dd) < 1e-12f) {
+            hit = hit && fabsf(oo) <= h;
+        } else {
+            const float t0 = (-h - oo) / dd, t1 = (h - oo) / dd;
+            tmin = fmaxf(tmin, fminf(t0, t1));
+            tmax = fminf(tmax, fmaxf(t0, t1));
+        }
+    }
+    flag[i] = (hit && tmax >= fmaxf(tmin, 0.0f)) ? 1 : 0;
+}
+
+// a convergence group without any hit gets its first ray (multiply.py:262-263 applied per group)
+__global__ __launch_bounds__(256) void k_group_fallback(int* __restrict__ flag, int n, int group_size) {
+    __shared__ int any;
+    const int g0 = blockIdx.x * group_size;
+    if (threadIdx.x == 0) any = 0;
+    __syncthreads();
+    int a = 0;
+    for (int i = g0 + threadIdx.x; i < min(n, g0 + group_size); i += 256) a |= flag[i];
+    if (a) any = 1;
+    __syncthreads();
+    if (threadIdx.x == 0 && !any) flag[g0] = 1;
+}
+
+constexpr int SCAN_BLOCK = 1024;
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_blocks(const int* __restrict__ flag, int n, int* __restrict__ bsum) {
+    __shared__ int sh[SCAN_BLOCK / 64];
+    const int i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    const int f = i < n ? flag[i] : 0;
+    const int c = __popcll(__ballot(f != 0));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int w = 0; w < SCAN_BLOCK / 64; ++w) s += sh[w];
+        bsum[blockIdx.x] = s;
+    }
+}
+__global__ void k_scan_top(int* __restrict__ bsum, int nb, int* __restrict__ total) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int s = 0;
+        for (int b = 0; b < nb; ++b) { const int c = bsum[b]; bsum[b] = s; s += c; }
+        *total = s;
+    }
+}
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_scatter(const int* __restrict__ flag, int n,
+                                                             const int* __restrict__ bsum, int* __restrict__ hit_index,
+                                                             int* __restrict__ inv_index) {
+    __shared__ int sh[SCAN_BLOCK / 64];
+    const int i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    const int f = i < n ? flag[i] : 0;
+    const unsigned long long m = __ballot(f != 0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sh[wave] = __popcll(m);
+    __syncthreads();
+    int base = bsum[blockIdx.x];
+    for (int w = 0; w < wave; ++w) base += sh[w];
+    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (i < n) {
+        inv_index[i] = f ? pos : -1;
+        if (f) hit_index[pos] = i;
+    }
+}
+
+__global__ void k_hits_from_index(const int* __restrict__ hit_index, int n_hit, int n_rays, int* __restrict__ hit_count,
+                                  int* __restrict__ inv_index, int phase) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (phase == 0) {
+        if (i < n_rays) inv_index[i] = -1;
+        if (i == 0) *hit_count = n_hit;
+    } else if (i < n_hit) {
+        inv_index[hit_index[i]] = i;
+    }
+}
+
+int warp_grid(int n_slab, int nw) {
+    int g = (n_slab + nw - 1) / nw;
+    return g < 1 ? 1 : (g > 256 ? 256 : g);
+}
+
+}  // namespace
+
+extern "C" int mp_smpl_pose(const float* v_template, const float* shapedirs, const float* posedirs,
+                            const float* j_regressor, const float* lbs_weights, const int* parents, const float* params,
+                            const float* tfs_c_inv, float* verts, float* tfs, float* joints, float* work, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_smpl_shape, dim3((3 * V + 255) / 256), dim3(256), 0, st, v_template, shapedirs, params, work);
+    hipLaunchKernelGGL(k_smpl_joints, dim3(NJ), dim3(256), 0, st, j_regressor, work);
+    hipLaunchKernelGGL(k_smpl_chain, dim3(1), dim3(64), 0, st, parents, params, tfs_c_inv, work, tfs, joints);
+    hipLaunchKernelGGL(k_smpl_verts, dim3((V + 255) / 256), dim3(256), 0, st, posedirs, lbs_weights, params, work, verts);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_knn_build(const float* verts, const int* perm, float* vsorted, float* cbound, void* stream) {
+    hipLaunchKernelGGL(k_knn_build, dim3(NC), dim3(CL), 0, (hipStream_t)stream, verts, perm, (float4*)vsorted,
+                       (float4*)cbound);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_obb(const float* verts, float inflate, float* obb, void* stream) {
+    hipLaunchKernelGGL(k_obb, dim3(1), dim3(256), 0, (hipStream_t)stream, verts, inflate, obb);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_ray_setup(const float* uv, const float* intrinsics, const float* pose, int n_rays, float radius,
+                            float* dirs, float* far, void* stream) {
+    if (n_rays <= 0) return 0;
+    hipLaunchKernelGGL(k_ray_setup, dim3((n_rays + 255) / 256), dim3(256), 0, (hipStream_t)stream, uv, intrinsics, pose,
+                       n_rays, radius, dirs, far);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_ray_cull(const float* dirs, const float* pose, const float* obb, int n_rays, int group_size,
+                           int* hit_index, int* hit_count, int* inv_index, int* scan_tmp, void* stream) {
+    if (n_rays <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    int* flag = scan_tmp;                 // [n_rays]
+    int* bsum = scan_tmp + n_rays;        // [nb]
+    const int nb = (n_rays + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    if (group_size <= 0) group_size = n_rays;
+    hipLaunchKernelGGL(k_ray_box, dim3((n_rays + 255) / 256), dim3(256), 0, st, dirs, pose, obb, n_rays, flag);
+    hipLaunchKernelGGL(k_group_fallback, dim3((n_rays + group_size - 1) / group_size), dim3(256), 0, st, flag, n_rays,
+                       group_size);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(SCAN_BLOCK), 0, st, flag, n_rays, bsum);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(64), 0, st, bsum, nb, hit_count);
+    hipLaunchKernelGGL(k_scan_scatter, dim3(nb), dim3(SCAN_BLOCK), 0, st, flag, n_rays, bsum, hit_index, inv_index);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_ray_hits_from_index(const int* hit_index, int n_hit, int n_rays, int* hit_count, int* inv_index,
+                                      void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_hits_from_index, dim3((n_rays + 255) / 256), dim3(256), 0, st, hit_index, n_hit, n_rays,
+                       hit_count, inv_index, 0);
+    if (n_hit > 0)
+        hipLaunchKernelGGL(k_hits_from_index, dim3((n_hit + 255) / 256), dim3(256), 0, st, hit_index, n_hit, n_rays,
+                           hit_count, inv_index, 1);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_warp_inverse(const float* pts, const float* dirs, const float* pose, const int* hit_index,
+                               const int* hit_count, const float* z, int z_stride, int n_s, int max_rays,
+                               const float* vsorted, const float* cbound, const float* skin_w, const float* tfs,
+                               int mode, const int* ray_active, float* xc, unsigned char* outlier, float* sdf_out,
+                               int* worklist, int* work_count, void* stream) {
+    // when pts != NULL, max_rays carries the number of explicit points and sdf_out may carry beta for mode 2 (unused)
+    if (max_rays <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    static int once = (int)hipFuncSetAttribute((const void*)k_warp_inverse, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               WARP_LDS);
+    (void)once;
+    const int nw = WARP_THREADS / 64;
+    const int n_slab = pts ? (max_rays + 63) / 64 : ((max_rays + 63) / 64) * n_s;
+    hipLaunchKernelGGL(k_warp_inverse, dim3(warp_grid(n_slab, nw)), dim3(WARP_THREADS), WARP_LDS, st, pts, dirs, pose,
+                       hit_index, hit_count, z, z_stride, n_s, max_rays, pts ? max_rays : 0, vsorted, cbound, skin_w, tfs,
+                       mode & 3, ray_active, (const float*)nullptr, xc, outlier, sdf_out, worklist, work_count);
+    return (int)hipGetLastError();
+}
+
+// eval-shading variant (mode 2) needs beta; exported separately to keep mp_warp_inverse's signature small
+extern "C" int mp_warp_inverse_shade(const float* dirs, const float* pose, const int* hit_index, const int* hit_count,
+                                     const float* z, int z_stride, int n_s, int max_rays, const float* vsorted,
+                                     const float* cbound, const float* skin_w, const float* tfs, int eval_mode,
+                                     const float* beta, float* xc, unsigned char* outlier, float* sdf_out,
+                                     int* worklist, int* work_count, void* stream) {
+    if (max_rays <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    static int once = (int)hipFuncSetAttribute((const void*)k_warp_inverse, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               WARP_LDS);
+    (void)once;
+    const int nw = WARP_THREADS / 64;
+    const int n_slab = ((max_rays + 63) / 64) * n_s;
+    hipLaunchKernelGGL(k_warp_inverse, dim3(warp_grid(n_slab, nw)), dim3(WARP_THREADS), WARP_LDS, st,
+                       (const float*)nullptr, dirs, pose, hit_index, hit_count, z, z_stride, n_s, max_rays, 0, vsorted,
+                       cbound, skin_w, tfs, eval_mode ? 2 : 0, (const int*)nullptr, beta, xc, outlier, sdf_out, worklist,
+                       work_count);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_warp_jacobian(const float* xc, const int* worklist, const int* count, int max_count,
+                                const float* vsorted_c, const float* cbound_c, const float* skin_w, const float* tfs,
+                                float* jinv, void* stream) {
+    if (max_count <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    static int once = (int)hipFuncSetAttribute((const void*)k_warp_jacobian, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               WARP_LDS);
+    (void)once;
+    const int nw = WARP_THREADS / 64;
+    hipLaunchKernelGGL(k_warp_jacobian, dim3(warp_grid((max_count + 63) / 64, nw)), dim3(WARP_THREADS), WARP_LDS, st, xc,
+                       worklist, count, max_count, vsorted_c, cbound_c, skin_w, tfs, jinv);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,355 @@
+// VolSDF error-bound sampler (reference code/lib/model/ray_sampler.py:66-230), split at the SDF queries.
+// One wave (64 lanes) owns one ray; its sorted sample list (<= n_eval * max_iters entries) lives in LDS and the
+// cumulative sums of Algorithm 1 are wave-level scans.  Entry points: include/multiply_hip.h.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "../../include/multiply_hip.h"
+#include "common.hpp"
+
+using namespace mp;
+
+namespace {
+
+constexpr int WAVES = 4;
+
+// orders this wave's LDS traffic: writes by any lane before, reads by any lane after
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct Arr {
+    float *Z, *S, *D, *A, *B;
+};
+
+__device__ __forceinline__ Arr wave_arrays(char* smem, int zm) {
+    float* base = (float*)smem + (size_t)(threadIdx.x >> 6) * 5 * zm;
+    return Arr{base, base + zm, base + 2 * zm, base + 3 * zm, base + 4 * zm};
+}
+
+// torch.linspace(start, end, steps)[i] in fp32 (symmetric evaluation used by ATen's CPU and CUDA kernels)
+__device__ __forceinline__ float linspace_at(float start, float end, int steps, int i) {
+    if (steps == 1) return start;
+    const float step = (end - start) / (float)(steps - 1);
+    return i < steps / 2 ? start + step * (float)i : end - step * (float)(steps - 1 - i);
+}
+
+// number of entries of sorted a[0..n) that are < v (strict) or <= v
+__device__ __forceinline__ int count_less(const float* a, int n, float v, bool or_equal) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const bool go = or_equal ? (a[mid] <= v) : (a[mid] < v);
+        if (go) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// d* of Theorem 1 (ray_sampler.py:98-110) for interval i, from Z/S
+__device__ __forceinline__ float d_star(const float* Z, const float* S, int i) {
+    const float a = Z[i + 1] - Z[i], s0 = S[i], s1 = S[i + 1];
+    const float b = fabsf(s0), c = fabsf(s1);
+    const bool first = a * a + b * b <= c * c, second = a * a + c * c <= b * b;
+    float d = 0.0f;
+    if (first) d = b;
+    if (second) d = c;
+    if (!first && !second && (b + c - a > 0.0f)) {
+        const float s = (a + b + c) / 2.0f;
+        const float area = s * (s - a) * (s - b) * (s - c);
+        d = (2.0f * sqrtf(area)) / a;
+    }
+    const float sg0 = s0 > 0.f ? 1.f : (s0 < 0.f ? -1.f : 0.f), sg1 = s1 > 0.f ? 1.f : (s1 < 0.f ? -1.f : 0.f);
+    return (sg1 * sg0 == 1.0f) ? d : 0.0f * d;  // (sign product == 1) * d_star; keeps NaN like the reference
+}
+
+__device__ __forceinline__ float nan_max(float m, float v) { return (m != m || v != v) ? NAN : fmaxf(m, v); }
+
+// get_error_bound (ray_sampler.py:222-230): max over the n-1 intervals; wave-uniform result
+__device__ float error_bound(const Arr& r, int n, float beta) {
+    const int lane = threadIdx.x & 63, ni = n - 1;
+    const int ch = (ni + 63) / 64, i0 = min(lane * ch, ni), i1 = min(i0 + ch, ni);
+    const float inv4b2 = 1.0f / (4.0f * beta * beta);
+    float sfe = 0.f, serr = 0.f;
+    for (int i = i0; i < i1; ++i) {
+        const float dist = r.Z[i + 1] - r.Z[i];
+        sfe += dist * laplace_density(r.S[i], beta);
+        serr += expf(-r.D[i] / beta) * (dist * dist) * inv4b2;
+    }
+    float tot;
+    float integ = wave_excl_scan(sfe, tot);
+    float errint = wave_excl_scan(serr, tot);
+    float m = -INFINITY;
+    for (int i = i0; i < i1; ++i) {
+        const float dist = r.Z[i + 1] - r.Z[i];
+        errint += expf(-r.D[i] / beta) * (dist * dist) * inv4b2;
+        const float bound = (fminf(expf(errint), 1.0e6f) - 1.0f) * expf(-integ);
+        m = nan_max(m, bound);
+        integ += dist * laplace_density(r.S[i], beta);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = nan_max(m, __shfl_xor(m, o));
+    return m;
+}
+
+// ------------------------------------------------------------------------------------------------ init
+__global__ __launch_bounds__(256) void k_sampler_init(MpSamplerCfg cfg, MpSamplerState st, const float* __restrict__ far,
+                                                      const int* __restrict__ hit_index,
+                                                      const int* __restrict__ hit_count, int max_rays, int n_groups,
+                                                      const float* __restrict__ t_rand) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int n_rays = min(*hit_count, max_rays);
+    const int NE = cfg.n_samples_eval;
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < (cfg.max_total_iters + 1) * n_groups; i += 256) st.group_flag[i] = 0;
+    float* zl = (float*)smem + (threadIdx.x >> 6) * NE;   // wave-private
+    for (int k = blockIdx.x * WAVES + (threadIdx.x >> 6); k < n_rays; k += gridDim.x * WAVES) {
+        const float fr = far[hit_index[k]], nr = cfg.near_;
+        for (int i = lane; i < NE; i += 64) {
+            const float t = linspace_at(0.0f, 1.0f, NE, i);
+            zl[i] = nr * (1.0f - t) + fr * t;  // ray_sampler.py:29-30
+        }
+        wave_sync();
+        float zj[4];  // NE <= 256
+        for (int q = 0, i = lane; i < NE; i += 64, ++q) {
+            float z = zl[i];
+            if (t_rand) {  // stratified jitter, ray_sampler.py:32-40
+                const float lower = i == 0 ? zl[0] : 0.5f * (zl[i] + zl[i - 1]);
+                const float upper = i == NE - 1 ? zl[NE - 1] : 0.5f * (zl[i + 1] + zl[i]);
+                z = lower + (upper - lower) * t_rand[(size_t)k * NE + i];
+            }
+            zj[q] = z;
+            st.znew[(size_t)k * NE + i] = z;
+        }
+        wave_sync();
+        for (int q = 0, i = lane; i < NE; i += 64, ++q) zl[i] = zj[q];
+        wave_sync();
+        // beta from the upper bound (ray_sampler.py:74-76) on the (jittered) depths
+        float ss = 0.f;
+        for (int i = lane; i < NE - 1; i += 64) { const float d = zl[i + 1] - zl[i]; ss += d * d; }
+        ss = wsum(ss);
+        if (lane == 0) {
+            st.beta[k] = sqrtf((1.0f / (4.0f * logf(cfg.eps + 1.0f))) * ss);
+            st.nz[k] = 0;
+            st.ray_active[k] = 1;
+        }
+        wave_sync();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ bound
+__global__ __launch_bounds__(256) void k_sampler_bound(MpSamplerCfg cfg, MpSamplerState st,
+                                                       const float* __restrict__ beta0_p,
+                                                       const int* __restrict__ hit_index,
+                                                       const int* __restrict__ hit_count, int max_rays,
+                                                       int group_size, int n_groups, int iter, int zm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Arr r = wave_arrays(smem, zm);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_rays = min(*hit_count, max_rays);
+    const int NE = cfg.n_samples_eval;
+    const float beta0 = *beta0_p;
+    const int k = blockIdx.x * WAVES + wave;
+    if (k >= n_rays || !st.ray_active[k]) return;  // waves are independent: no block-level barrier below
+    const int n_old = st.nz[k];
+    const int n = n_old + NE;
+    // merge the queried samples into the sorted list (ray_sampler.py:89-94, 191: sort of cat == merge)
+    for (int i = lane; i < n_old; i += 64) { r.A[i] = st.zs[(size_t)k * zm + i]; r.B[i] = st.sdfs[(size_t)k * zm + i]; }
+    for (int i = lane; i < NE; i += 64) {
+        r.A[n_old + i] = st.znew[(size_t)k * NE + i];
+        r.B[n_old + i] = st.sdfnew[(size_t)k * NE + i];
+    }
+    wave_sync();
+    for (int i = lane; i < n; i += 64) {
+        const float zi = r.A[i];
+        const int rank = i < n_old ? i + count_less(r.A + n_old, NE, zi, false)
+                                   : (i - n_old) + count_less(r.A, n_old, zi, true);
+        r.Z[rank] = zi;
+        r.S[rank] = r.B[i];
+    }
+    wave_sync();
+    for (int i = lane; i < n; i += 64) { st.zs[(size_t)k * zm + i] = r.Z[i]; st.sdfs[(size_t)k * zm + i] = r.S[i]; }
+    for (int i = lane; i < n - 1; i += 64) r.D[i] = d_star(r.Z, r.S, i);
+    wave_sync();
+    // line search on beta (ray_sampler.py:113-122)
+    float beta = st.beta[k];
+    float curr = error_bound(r, n, beta0);
+    if (curr <= cfg.eps) beta = beta0;
+    float bmin = beta0, bmax = beta;
+    for (int j = 0; j < cfg.beta_iters; ++j) {
+        const float mid = (bmin + bmax) / 2.0f;
+        curr = error_bound(r, n, mid);
+        if (curr <= cfg.eps) bmax = mid;
+        if (curr > cfg.eps) bmin = mid;
+    }
+    beta = bmax;
+    if (lane == 0) {
+        st.beta[k] = beta;
+        st.nz[k] = n;
+        if (beta > beta0) atomicOr(&st.group_flag[iter * n_groups + hit_index[k] / group_size], 1);  // :137
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ resample
+__global__ __launch_bounds__(256) void k_sampler_resample(MpSamplerCfg cfg, MpSamplerState st,
+                                                          const float* __restrict__ beta0_p,
+                                                          const float* __restrict__ far,
+                                                          const int* __restrict__ hit_index,
+                                                          const int* __restrict__ hit_count, int max_rays,
+                                                          int group_size, int n_groups, int iter, int zm,
+                                                          const float* __restrict__ u_final,
+                                                          const int* __restrict__ extra_idx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Arr r = wave_arrays(smem, zm);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_rays = min(*hit_count, max_rays);
+    const int k = blockIdx.x * WAVES + wave;
+    if (k >= n_rays || !st.ray_active[k]) return;
+    const int NE = cfg.n_samples_eval, NS = cfg.n_samples, NX = cfg.n_samples_extra;
+    const int grp = hit_index[k] / group_size;
+    const bool more = st.group_flag[iter * n_groups + grp] != 0 && (iter + 1 < cfg.max_total_iters);
+    const int n = st.nz[k], ni = n - 1;
+    const float beta = st.beta[k];
+    for (int i = lane; i < n; i += 64) { r.Z[i] = st.zs[(size_t)k * zm + i]; r.S[i] = st.sdfs[(size_t)k * zm + i]; }
+    wave_sync();
+    // chunked scans over the n samples: free energy -> transmittance (ray_sampler.py:126-133)
+    const int ch = (n + 63) / 64, i0 = min(lane * ch, n), i1 = min(i0 + ch, n);
+    const float inv4b2 = 1.0f / (4.0f * beta * beta);
+    float sfe = 0.f, serr = 0.f;
+    for (int i = i0; i < i1; ++i) {
+        const float dist = i < ni ? r.Z[i + 1] - r.Z[i] : 1e10f;
+        sfe += dist * laplace_density(r.S[i], beta);
+        if (more && i < ni) {
+            r.D[i] = d_star(r.Z, r.S, i);
+            serr += expf(-r.D[i] / beta) * (dist * dist) * inv4b2;
+        }
+    }
+    float tot;
+    float integ = wave_excl_scan(sfe, tot);
+    float errint = wave_excl_scan(serr, tot);
+    float psum = 0.f;
+    for (int i = i0; i < i1; ++i) {
+        const float dist = i < ni ? r.Z[i + 1] - r.Z[i] : 1e10f;
+        const float fe = dist * laplace_density(r.S[i], beta);
+        const float trans = expf(-integ);
+        float pdf;
+        if (more) {  // error-bound pdf (ray_sampler.py:142-149)
+            if (i < ni) errint += expf(-r.D[i] / beta) * (dist * dist) * inv4b2;
+            pdf = (fminf(expf(errint), 1.0e6f) - 1.0f) * trans + cfg.add_tiny;
+        } else {     // final pdf from the weights (ray_sampler.py:157-161)
+            pdf = (1.0f - expf(-fe)) * trans + 1e-5f;
+        }
+        if (i < ni) { r.A[i] = pdf; psum += pdf; }
+        integ += fe;
+    }
+    const float total = wsum(psum);
+    wave_sync();
+    // cdf over the n bins edges: B[0] = 0, B[i+1] = cumsum(pdf/total)[i]
+    const int chi = (ni + 63) / 64, j0 = min(lane * chi, ni), j1 = min(j0 + chi, ni);
+    float loc = 0.f;
+    for (int i = j0; i < j1; ++i) loc += r.A[i] / total;
+    float run = wave_excl_scan(loc, tot);
+    for (int i = j0; i < j1; ++i) { run += r.A[i] / total; r.B[i + 1] = run; }
+    if (lane == 0) r.B[0] = 0.0f;
+    wave_sync();
+    // invert the cdf (ray_sampler.py:168-186)
+    const int N = more ? NE : NS;
+    float* outv = r.D;  // reuse: samples (and, for the final set, the extras) are collected here
+    for (int j = lane; j < N; j += 64) {
+        const float u = (more || !u_final) ? linspace_at(0.0f, 1.0f, N, j) : u_final[(size_t)k * NS + j];
+        const int inds = count_less(r.B, n, u, true);  // searchsorted(right=True)
+        const int below = max(inds - 1, 0), above = min(inds, n - 1);
+        const float cb = r.B[below], ca = r.B[above];
+        float denom = ca - cb;
+        denom = denom < 1e-5f ? 1.0f : denom;
+        const float t = (u - cb) / denom;
+        outv[j] = r.Z[below] + t * (r.Z[above] - r.Z[below]);
+    }
+    wave_sync();
+    if (more) {
+        for (int j = lane; j < NE; j += 64) st.znew[(size_t)k * NE + j] = outv[j];
+        return;
+    }
+    // final set: samples + near + far + N_extra of the current depths, sorted (ray_sampler.py:194-209)
+    const int NF = NS + 2 + NX;
+    if (lane == 0) { outv[NS] = cfg.near_; outv[NS + 1] = far[hit_index[k]]; }
+    for (int j = lane; j < NX; j += 64) {
+        const int idx = extra_idx ? extra_idx[j] : (int)linspace_at(0.0f, (float)(n - 1), NX, j);
+        outv[NS + 2 + j] = r.Z[min(max(idx, 0), n - 1)];
+    }
+    wave_sync();
+    for (int j = lane; j < NF; j += 64) {  // rank sort (stable)
+        const float v = outv[j];
+        int rank = 0;
+        for (int q = 0; q < NF; ++q) {
+            const float w = outv[q];
+            rank += (w < v || (w == v && q < j)) ? 1 : 0;
+        }
+        st.zfinal[(size_t)k * NF + rank] = v;
+    }
+    if (lane == 0) {
+        st.ray_active[k] = 0;
+        st.iters[grp] = iter + 1;
+    }
+}
+
+int check_cfg(const MpSamplerCfg* c) {
+    if (c->n_samples_eval < 2 || c->n_samples_eval > 256 || c->n_samples < 1 || c->n_samples > 256 ||
+        c->n_samples_extra < 0 || c->n_samples_extra > 256 || c->max_total_iters < 1 || c->max_total_iters > 8)
+        return -1;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int mp_sampler_init(const MpSamplerCfg* cfg, const MpSamplerState* st, const float* far,
+                               const int* hit_index, const int* hit_count, int max_rays, int group_size,
+                               int n_rays_total, const float* t_rand, void* stream) {
+    if (check_cfg(cfg)) return -1;
+    if (max_rays <= 0) return 0;
+    const int n_groups = (n_rays_total + group_size - 1) / group_size;
+    int grid = (max_rays + WAVES - 1) / WAVES;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k_sampler_init, dim3(grid), dim3(256), WAVES * cfg->n_samples_eval * 4, (hipStream_t)stream, *cfg,
+                       *st, far, hit_index, hit_count, max_rays, n_groups, t_rand);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_sampler_bound(const MpSamplerCfg* cfg, const MpSamplerState* st, const float* beta0,
+                                const int* hit_index, const int* hit_count, int max_rays, int group_size,
+                                int n_rays_total, int iter, void* stream) {
+    if (check_cfg(cfg)) return -1;
+    if (max_rays <= 0) return 0;
+    const int zm = cfg->n_samples_eval * cfg->max_total_iters;
+    const int lds = WAVES * 5 * zm * 4;
+    static int set_for = 0;
+    if (lds > set_for) {
+        hipFuncSetAttribute((const void*)k_sampler_bound, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        set_for = lds;
+    }
+    const int n_groups = (n_rays_total + group_size - 1) / group_size;
+    hipLaunchKernelGGL(k_sampler_bound, dim3((max_rays + WAVES - 1) / WAVES), dim3(256), lds, (hipStream_t)stream, *cfg,
+                       *st, beta0, hit_index, hit_count, max_rays, group_size, n_groups, iter, zm);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_sampler_resample(const MpSamplerCfg* cfg, const MpSamplerState* st, const float* beta0,
+                                   const float* far, const int* hit_index, const int* hit_count, int max_rays,
+                                   int group_size, int n_rays_total, int iter, const float* u_final,
+                                   const int* extra_idx, void* stream) {
+    if (check_cfg(cfg)) return -1;
+    if (max_rays <= 0) return 0;
+    const int zm = cfg->n_samples_eval * cfg->max_total_iters;
+    const int lds = WAVES * 5 * zm * 4;
+    static int set_for = 0;
+    if (lds > set_for) {
+        hipFuncSetAttribute((const void*)k_sampler_resample, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        set_for = lds;
+    }
+    const int n_groups = (n_rays_total + group_size - 1) / group_size;
+    hipLaunchKernelGGL(k_sampler_resample, dim3((max_rays + WAVES - 1) / WAVES), dim3(256), lds, (hipStream_t)stream, *cfg,
+                       *st, beta0, far, hit_index, hit_count, max_rays, group_size, n_groups, iter, zm, u_final,
+                       extra_idx);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,67 @@
+"""SMPLDeformer with the reference's attribute surface (code/lib/model/deformer.py:6-50).
+
+The canonical<->deformed warp of the hot path (nearest posed vertex -> its skinning weights -> inverse of the blended
+bone transform) runs in csrc/geom.hip (mp_warp_inverse / mp_warp_jacobian).  This module owns the static data those
+kernels need: the canonical vertices of this person's shape, the skinning weights and the nearest-neighbour cluster
+order (computed once from the canonical vertices; clusters stay compact under posing because nearby vertices move
+almost rigidly together)."""
+import torch
+import torch.nn as nn
+
+from . import hip
+from .smpl import knn_cluster_perm
+
+
+class SMPLDeformer(nn.Module):
+    def __init__(self, max_dist=0.05, K=1, gender="male", betas=None, server=None):
+        super().__init__()
+        if server is None:
+            from .smpl import SMPLServer
+            server = SMPLServer(gender=gender, betas=betas)
+        self.max_dist = max_dist
+        self.K = K
+        self.smpl = server
+        # canonical ("A-pose") vertices of this shape = SMPLServer(betas).verts_c (deformer.py:12-18)
+        self.smpl_verts = server.verts_c
+        self.smpl_weights = server.tables.lbs_weights[None]
+        dev = self.smpl_verts.device
+        self.knn_perm = torch.from_numpy(knn_cluster_perm(self.smpl_verts[0].cpu().numpy())).to(dev)
+        self.vsorted_c = torch.empty(hip.KNN_NC * hip.KNN_CLUSTER, 4, dtype=torch.float32, device=dev)
+        self.cbound_c = torch.empty(hip.KNN_NC, 4, dtype=torch.float32, device=dev)
+        hip.check(hip.lib().mp_knn_build(hip.ptr(self.smpl_verts[0].contiguous()), hip.ptr(self.knn_perm),
+                                         hip.ptr(self.vsorted_c), hip.ptr(self.cbound_c), hip.stream()), "mp_knn_build")
+
+    def forward(self, x, smpl_tfs, return_weights=True, inverse=False, smpl_verts=None):
+        """deformer.py:19-30 for the hot-path call pattern (inverse=True, K=1): returns (x_c, outlier_mask)."""
+        if x.shape[0] == 0:
+            return x
+        if return_weights or not inverse or self.K != 1:
+            raise NotImplementedError("only forward(..., return_weights=False, inverse=True) with K=1 is on the hot path; "
+                                      "K>1 skinning-weight queries (mesh export) are a 'next' row (SURVEY.md §8f)")
+        L = hip.lib()
+        dev = x.device
+        x = x.detach().float().contiguous()
+        verts = (self.smpl_verts if smpl_verts is None else smpl_verts)[0].detach().float().contiguous()
+        vs = torch.empty(hip.KNN_NC * hip.KNN_CLUSTER, 4, dtype=torch.float32, device=dev)
+        cb = torch.empty(hip.KNN_NC, 4, dtype=torch.float32, device=dev)
+        hip.check(L.mp_knn_build(hip.ptr(verts), hip.ptr(self.knn_perm), hip.ptr(vs), hip.ptr(cb), hip.stream()),
+                  "mp_knn_build")
+        n = x.shape[0]
+        xc = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        outl = torch.empty(n, dtype=torch.uint8, device=dev)
+        tfs = smpl_tfs.detach().float().reshape(24, 16).contiguous()
+        hip.check(L.mp_warp_inverse(hip.ptr(x), None, None, None, None, None, 0, 1, n, hip.ptr(vs), hip.ptr(cb),
+                                    hip.ptr(self.smpl_weights[0].contiguous()), hip.ptr(tfs), 0, None, hip.ptr(xc),
+                                    hip.ptr(outl), None, None, None, hip.stream()), "mp_warp_inverse")
+        return xc, outl.bool()
+
+    def forward_skinning_jacobian_inverse(self, xc, smpl_tfs):
+        """inverse of d(forward_skinning)/d x_c at canonical points (deformer.py:31-35 + multiply.py:625-641)."""
+        xc = xc.detach().float().contiguous()
+        n = xc.shape[0]
+        jinv = torch.empty(n, 9, dtype=torch.float32, device=xc.device)
+        tfs = smpl_tfs.detach().float().reshape(24, 16).contiguous()
+        hip.check(hip.lib().mp_warp_jacobian(hip.ptr(xc), None, None, n, hip.ptr(self.vsorted_c), hip.ptr(self.cbound_c),
+                                             hip.ptr(self.smpl_weights[0].contiguous()), hip.ptr(tfs), hip.ptr(jinv),
+                                             hip.stream()), "mp_warp_jacobian")
+        return jinv.reshape(n, 3, 3)

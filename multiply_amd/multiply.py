@@ -1,0 +1,283 @@
+"""Multiply scene model: the reference's nn.Module API over the HIP hot path.
+
+Drop-in for `lib.model.multiply.Multiply` (reference code/lib/model/multiply.py:23-598):
+  * constructor Multiply(opt, betas_path) building the same sub-module tree, in the same order and with the same
+    state-dict names (multiply.py:35-100), so checkpoints load and seeded initialisation is bit-identical;
+  * forward(input, id=-1, cond_zero_shit=False, canonical_pose=False) -> the reference's output dict
+    (multiply.py:566-597);
+  * the attributes the Lightning module reaches into.
+Everything between the input dict and the output dict runs in hand-written HIP kernels (multiply_amd/csrc) through
+the C ABI of include/multiply_hip.h.  There is no PyTorch / CPU fallback: without the library or a gfx950 device the
+forward raises.
+
+Extensions that do not exist in the reference (all optional, defaults reproduce the reference):
+  * input['hit_index'] : list of per-person ascending ray-id tensors replacing the box cull (parity tests; the
+    reference's trimesh box, multiply.py:208-214, 256-266, is third-party code);
+  * self.convergence_group : number of consecutive rays that share the sampler's convergence vote
+    (ray_sampler.py:137).  None = the whole call, exactly like the reference; set it to pixel_per_batch to render a
+    whole frame in one call with the results of the reference's chunked loop (multiply_model.py:1051-1055).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip
+from .density import AbsDensity, LaplaceDensity
+from .networks import ImplicitNet, RenderingNet
+from .ray_sampler import ErrorBoundSampler
+from .smpl import NUM_JOINTS, NUM_VERTS, SMPLDeviceTables, SMPLServer, knn_cluster_perm, load_smpl_tables
+from .deformer import SMPLDeformer
+from .sampler import PointInSpace
+
+
+class Multiply(nn.Module):
+    def __init__(self, opt, betas_path, smpl_tables=None, gender_list=None):
+        super().__init__()
+        hip.require_device()
+        betas = np.load(betas_path) if isinstance(betas_path, str) else np.asarray(betas_path)
+        self.using_nerfacc = True
+        self.smpl_surface_weight = opt.loss.get("smpl_surface_weight", 0)
+        self.zero_pose_weight = opt.loss.get("zero_pose_weight", 0)
+        self.use_person_encoder = opt.get("use_person_encoder", False)
+        if self.use_person_encoder:
+            raise NotImplementedError("use_person_encoder (shared triplane networks) is outside the hot-path scope")
+        betas2 = betas.reshape(-1, 10) if betas.ndim == 2 else betas.reshape(1, 10)
+        self.num_person = betas2.shape[0]
+
+        # same construction order as the reference (multiply.py:35-66): RNG consumption is identical
+        self.foreground_implicit_network_list = nn.ModuleList()
+        self.foreground_rendering_network_list = nn.ModuleList()
+        for _ in range(self.num_person):
+            self.foreground_implicit_network_list.append(ImplicitNet(opt.implicit_network))
+            self.foreground_rendering_network_list.append(RenderingNet(opt.rendering_network))
+        self.with_bkgd = opt.with_bkgd
+        self.bg_implicit_network = ImplicitNet(opt.bg_implicit_network)
+        self.bg_rendering_network = RenderingNet(opt.bg_rendering_network)
+        self.frame_latent_encoder = nn.Embedding(opt.num_training_frames, opt.dim_frame_encoding)
+        self.sampler = PointInSpace()
+        self.use_smpl_deformer = opt.use_smpl_deformer
+        if not self.use_smpl_deformer:
+            raise NotImplementedError("only the SMPL deformer branch exists in the reference's shipped configs")
+
+        if gender_list is None:
+            gpath = betas_path[:-14] + "gender.npy" if isinstance(betas_path, str) else None
+            gender_list = np.load(gpath) if gpath and os.path.exists(gpath) else ["male"] * self.num_person
+        self.gender_list = gender_list
+        device = torch.device("cuda")
+        cache = {}
+
+        def tables_for(gender):
+            g = str(gender)
+            if g not in cache:
+                raw = smpl_tables if smpl_tables is not None else load_smpl_tables(g)
+                cache[g] = raw if isinstance(raw, SMPLDeviceTables) else SMPLDeviceTables(raw, device)
+            return cache[g]
+
+        self.deformer_list = nn.ModuleList()
+        self.smpl_server_list = nn.ModuleList()
+        for i in range(self.num_person):
+            server = SMPLServer(gender=self.gender_list[i], betas=betas2[i], smpl_tables=tables_for(self.gender_list[i]))
+            self.smpl_server_list.append(server)
+            self.deformer_list.append(SMPLDeformer(betas=betas2[i], gender=self.gender_list[i], server=server))
+
+        self.sdf_bounding_sphere = 3.0
+        self.threshold = 0.05
+        self.density = LaplaceDensity(**opt.density)
+        self.bg_density = AbsDensity()
+        self.ray_sampler = ErrorBoundSampler(self.sdf_bounding_sphere, inverse_sphere_bg=True, **opt.ray_sampler)
+        if opt.get("smpl_init", False):
+            import warnings
+            warnings.warn("smpl_init: outputs/smpl_init_male_256.pth is an asset of the reference that is not shipped; "
+                          "load it with load_state_dict(strict=False) on foreground_implicit_network_list if you have it")
+        self.mesh_v_cano_list = [s.verts_c for s in self.smpl_server_list]
+        self.mesh_f_cano_list = [torch.tensor(s.smpl.faces.astype(np.int64), device=device) for s in self.smpl_server_list]
+        self.mesh_face_vertices_list = [v[0][f] [None] for v, f in zip(self.mesh_v_cano_list, self.mesh_f_cano_list)]
+        self.convergence_group = None
+        self.obb_inflate = 1.2
+        self.last_stats = {}
+        self.to(device)
+
+    # ------------------------------------------------------------------ helpers
+    def _sampler_cfg(self):
+        rs = self.ray_sampler
+        return hip.MpSamplerCfg(rs.N_samples, rs.N_samples_eval, rs.N_samples_extra, rs.beta_iters, rs.max_total_iters,
+                                rs.eps, rs.add_tiny, rs.near)
+
+    def forward(self, input, id=-1, cond_zero_shit=False, canonical_pose=False):
+        if self.training:
+            raise NotImplementedError("training-mode forward/backward kernels are not implemented yet (DESIGN.md §scope)")
+        with torch.no_grad():
+            return self._forward_eval(input, id, canonical_pose)
+
+    def _forward_eval(self, input, id, canonical_pose):
+        L = hip.lib()
+        dev = self.density.beta.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        st = hip.stream()
+        uv = input["uv"].to(dev).float().reshape(-1, 2).contiguous()
+        R = uv.shape[0]
+        K = input["intrinsics"].to(dev).float().reshape(16).contiguous()
+        pose = input["pose"].to(dev).float().reshape(16).contiguous()
+        smpl_params = input["smpl_params"].to(dev).float()
+        smpl_pose = input["smpl_pose"].to(dev).float()
+        smpl_shape = input["smpl_shape"].to(dev).float()
+        smpl_trans = input["smpl_trans"].to(dev).float()
+        P = smpl_trans.shape[1]
+        persons = list(range(P)) if id == -1 else [id]
+        rs = self.ray_sampler
+        cfg = self._sampler_cfg()
+        NE, NS, NX = rs.N_samples_eval, rs.N_samples, rs.N_samples_extra
+        NZ = NS + NX + 2
+        S = NZ - 1
+        ZM = NE * rs.max_total_iters
+        group = int(self.convergence_group or R)
+        n_groups = (R + group - 1) // group
+        beta = (self.density.beta.detach().abs() + self.density.beta_min).reshape(1).float().contiguous()
+
+        # rays (rend_util.get_camera_params)
+        dirs = torch.empty(R, 3, **f32)
+        far = torch.empty(R, **f32)
+        hip.check(L.mp_ray_setup(hip.ptr(uv), hip.ptr(K), hip.ptr(pose), R, C.c_float(self.sdf_bounding_sphere),
+                                 hip.ptr(dirs), hip.ptr(far), st), "mp_ray_setup")
+
+        # SMPL posing, nearest-vertex structures, box cull  (multiply.py:196-214, 256-266)
+        per = {}
+        counts = torch.zeros(len(persons), **i32)
+        scan_tmp = torch.empty(R + (R + 1023) // 1024 + 8, **i32)
+        for n, p in enumerate(persons):
+            server = self.smpl_server_list[p]
+            prm = torch.cat([smpl_params[0, p, 0:1], smpl_trans[0, p], smpl_pose[0, p], smpl_shape[0, p]]).contiguous()
+            if canonical_pose:   # multiply.py:197-202
+                prm = prm.clone()
+                prm[1:4] = 0
+                prm[4:76] = 0
+                prm[4 + 5] = np.pi / 6
+                prm[4 + 8] = -np.pi / 6
+            verts = torch.empty(NUM_VERTS, 3, **f32)
+            tfs = torch.empty(NUM_JOINTS, 4, 4, **f32)
+            jnts = torch.empty(NUM_JOINTS, 3, **f32)
+            server.pose_into(prm, verts, tfs, jnts)
+            d = self.deformer_list[p]
+            vsorted = torch.empty(hip.KNN_NC * hip.KNN_CLUSTER, 4, **f32)
+            cbound = torch.empty(hip.KNN_NC, 4, **f32)
+            hip.check(L.mp_knn_build(hip.ptr(verts), hip.ptr(d.knn_perm), hip.ptr(vsorted), hip.ptr(cbound), st),
+                      "mp_knn_build")
+            hit_index = torch.empty(R, **i32)
+            inv_index = torch.empty(R, **i32)
+            if "hit_index" in input and input["hit_index"] is not None:
+                hi = input["hit_index"][p].to(dev).to(torch.int32).contiguous()
+                hit_index[:hi.numel()] = hi
+                hip.check(L.mp_ray_hits_from_index(hip.ptr(hit_index), hi.numel(), R, hip.ptr(counts[n:n + 1]),
+                                                   hip.ptr(inv_index), st), "mp_ray_hits_from_index")
+            else:
+                obb = torch.empty(16, **f32)
+                hip.check(L.mp_obb(hip.ptr(verts), C.c_float(self.obb_inflate), hip.ptr(obb), st), "mp_obb")
+                hip.check(L.mp_ray_cull(hip.ptr(dirs), hip.ptr(pose), hip.ptr(obb), R, group, hip.ptr(hit_index),
+                                        hip.ptr(counts[n:n + 1]), hip.ptr(inv_index), hip.ptr(scan_tmp), st),
+                          "mp_ray_cull")
+            cond = (smpl_pose[0, p, 3:] / np.pi).contiguous()          # multiply.py:270 (eval: never zeroed)
+            per[p] = dict(verts=verts, tfs=tfs, vsorted=vsorted, cbound=cbound, hit_index=hit_index,
+                          inv_index=inv_index, count=counts[n:n + 1], cond=cond)
+        n_hit = counts.tolist()          # the one host sync of the call: sizes the per-person workspaces
+        stats = {"n_hit": n_hit, "iters": [], "n_sdf_evals": [], "n_shaded": []}
+
+        z_l, sdf_l, rgb_l, nrm_l, inv_l = [], [], [], [], []
+        for n, p in enumerate(persons):
+            pp = per[p]
+            Rp = max(int(n_hit[n]), 1)
+            imp, ren, dfm = self.foreground_implicit_network_list[p], self.foreground_rendering_network_list[p], \
+                self.deformer_list[p]
+            skin_w = self.smpl_server_list[p].tables.lbs_weights
+            pk_sdf = hip.packed(imp, "sdf", 2)
+            pk_sdf.refresh(pp["cond"])
+            # ---- sampler state
+            zs = torch.empty(Rp, ZM, **f32); sdfs = torch.empty(Rp, ZM, **f32)
+            nz = torch.empty(Rp, **i32); znew = torch.empty(Rp, NE, **f32); sdfnew = torch.empty(Rp, NE, **f32)
+            betar = torch.empty(Rp, **f32); active = torch.empty(Rp, **i32)
+            gflag = torch.empty((rs.max_total_iters + 1) * n_groups, **i32)
+            zfinal = torch.empty(Rp, NZ, **f32); iters = torch.zeros(n_groups, **i32)
+            state = hip.MpSamplerState(zs.data_ptr(), sdfs.data_ptr(), nz.data_ptr(), znew.data_ptr(),
+                                       sdfnew.data_ptr(), betar.data_ptr(), active.data_ptr(), gflag.data_ptr(),
+                                       zfinal.data_ptr(), iters.data_ptr())
+            hip.check(L.mp_sampler_init(C.byref(cfg), C.byref(state), hip.ptr(far), hip.ptr(pp["hit_index"]),
+                                        hip.ptr(pp["count"]), Rp, group, R, None, st), "mp_sampler_init")
+            xc_new = torch.empty(Rp * NE, 3, **f32)
+            work = torch.empty(Rp * NE, **i32)
+            wcount = torch.zeros(rs.max_total_iters + 1, **i32)
+            for it in range(rs.max_total_iters):
+                hip.check(L.mp_warp_inverse(None, hip.ptr(dirs), hip.ptr(pose), hip.ptr(pp["hit_index"]),
+                                            hip.ptr(pp["count"]), hip.ptr(znew), NE, NE, Rp, hip.ptr(pp["vsorted"]),
+                                            hip.ptr(pp["cbound"]), hip.ptr(skin_w), hip.ptr(pp["tfs"]), 1,
+                                            hip.ptr(active), hip.ptr(xc_new), None, hip.ptr(sdfnew), hip.ptr(work),
+                                            hip.ptr(wcount[it:it + 1]), st), "mp_warp_inverse")
+                hip.check(L.mp_mlp_sdf(C.byref(pk_sdf.net), hip.ptr(pk_sdf.wpack), hip.ptr(pk_sdf.bias), hip.ptr(xc_new),
+                                       hip.ptr(work), hip.ptr(wcount[it:it + 1]), Rp * NE, hip.ptr(sdfnew), st),
+                          "mp_mlp_sdf")
+                hip.check(L.mp_sampler_bound(C.byref(cfg), C.byref(state), hip.ptr(beta), hip.ptr(pp["hit_index"]),
+                                             hip.ptr(pp["count"]), Rp, group, R, it, st), "mp_sampler_bound")
+                hip.check(L.mp_sampler_resample(C.byref(cfg), C.byref(state), hip.ptr(beta), hip.ptr(far),
+                                                hip.ptr(pp["hit_index"]), hip.ptr(pp["count"]), Rp, group, R, it, None,
+                                                None, st), "mp_sampler_resample")
+            # ---- shading of the final samples (multiply.py:294-308, 403-405)
+            npts = Rp * S
+            xc = torch.empty(npts, 3, **f32)
+            sdf = torch.empty(npts, **f32)
+            nrm = torch.zeros(npts, 3, **f32)
+            rgb = torch.zeros(npts, 3, **f32)
+            work2 = torch.empty(npts, **i32)
+            wc2 = wcount[rs.max_total_iters:]
+            hip.check(L.mp_warp_inverse_shade(hip.ptr(dirs), hip.ptr(pose), hip.ptr(pp["hit_index"]), hip.ptr(pp["count"]),
+                                              hip.ptr(zfinal), NZ, S, Rp, hip.ptr(pp["vsorted"]), hip.ptr(pp["cbound"]),
+                                              hip.ptr(skin_w), hip.ptr(pp["tfs"]), 1, hip.ptr(beta), hip.ptr(xc), None,
+                                              hip.ptr(sdf), hip.ptr(work2), hip.ptr(wc2), st), "mp_warp_inverse_shade")
+            jinv = torch.empty(npts, 9, **f32)
+            hip.check(L.mp_warp_jacobian(hip.ptr(xc), hip.ptr(work2), hip.ptr(wc2), npts, hip.ptr(dfm.vsorted_c),
+                                         hip.ptr(dfm.cbound_c), hip.ptr(skin_w), hip.ptr(pp["tfs"]), hip.ptr(jinv), st),
+                      "mp_warp_jacobian")
+            pk_full = hip.packed(imp, "full", 2)
+            pk_full.refresh(pp["cond"])
+            pk_col = hip.packed(ren, "color", 2)
+            pe = ren.__dict__.get("_mp_pose_embed") or hip.PoseEmbed(ren)
+            ren.__dict__["_mp_pose_embed"] = pe
+            pk_col.refresh(pe(pp["cond"]))
+            feat = torch.empty(((npts + 255) // 256) * 4 * 8 * 4 * 1024, dtype=torch.uint8, device=dev)
+            hip.check(L.mp_mlp_shade(C.byref(pk_full.net), hip.ptr(pk_full.wpack), hip.ptr(pk_full.bias), hip.ptr(xc),
+                                     hip.ptr(jinv), hip.ptr(work2), hip.ptr(wc2), npts, hip.ptr(sdf), hip.ptr(nrm),
+                                     hip.ptr(feat), st), "mp_mlp_shade")
+            hip.check(L.mp_mlp_color(C.byref(pk_col.net), hip.ptr(pk_col.wpack), hip.ptr(pk_col.bias), hip.ptr(xc),
+                                     hip.ptr(nrm), hip.ptr(feat), hip.ptr(work2), hip.ptr(wc2), npts, hip.ptr(rgb), st),
+                      "mp_mlp_color")
+            z_l.append(zfinal); sdf_l.append(sdf); rgb_l.append(rgb); nrm_l.append(nrm); inv_l.append(pp["inv_index"])
+            stats["iters"].append(iters); stats["n_sdf_evals"].append(wcount)
+            per[p].update(zfinal=zfinal, sdf=sdf, rgb=rgb, nrm=nrm, xc=xc, work2=work2)
+
+        # ---- background (multiply.py:482-484, 514-539)
+        bg_rgb = None
+        if input.get("idx", None) is not None:
+            key = "image_id" if "image_id" in input else "idx"      # multiply.py:407-410
+            code = self.frame_latent_encoder.weight.detach()[int(torch.as_tensor(input[key]).reshape(-1)[0])]
+            t = torch.linspace(0.0, 1.0, rs.N_samples_inverse_sphere, device=dev)
+            z_bg = torch.flip(t * (1.0 / rs.scene_bounding_sphere), dims=[0]).contiguous()
+            bg_rgb = hip.background(self.bg_implicit_network, self.bg_rendering_network, dirs, pose.reshape(4, 4)[:3, 3],
+                                    z_bg, code, radius=self.sdf_bounding_sphere)
+
+        # ---- compositing (multiply.py:425-480, 544-545)
+        def table(ts):
+            return torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device=dev)
+        t_inv, t_z, t_sdf, t_rgb, t_nrm = table(inv_l), table(z_l), table(sdf_l), table(rgb_l), table(nrm_l)
+        rgb_values = torch.empty(R, 3, **f32); fg_rgb_values = torch.empty(R, 3, **f32)
+        normal_values = torch.empty(R, 3, **f32); acc_map = torch.empty(R, **f32)
+        acc_person = torch.empty(R, len(persons), **f32); bg_T = torch.empty(R, **f32)
+        hip.check(L.mp_composite(R, len(persons), NZ, hip.ptr(t_inv), hip.ptr(t_z), hip.ptr(t_sdf), hip.ptr(t_rgb),
+                                 hip.ptr(t_nrm), hip.ptr(beta), hip.ptr(bg_rgb) if bg_rgb is not None else None,
+                                 hip.ptr(rgb_values), hip.ptr(fg_rgb_values), hip.ptr(normal_values), hip.ptr(acc_map),
+                                 hip.ptr(acc_person), hip.ptr(bg_T), st), "mp_composite")
+        self.last_stats = stats
+        self._last = dict(per=per, dirs=dirs, far=far, bg_T=bg_T, bg_rgb=bg_rgb, persons=persons, keep=(t_inv, t_z, t_sdf,
+                                                                                                        t_rgb, t_nrm))
+        return {"acc_map": acc_map, "acc_person_list": acc_person, "rgb_values": rgb_values,
+                "fg_rgb_values": fg_rgb_values, "normal_values": normal_values}

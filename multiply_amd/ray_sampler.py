@@ -1,0 +1,40 @@
+"""Sampler configuration objects with the reference's names and constructor arguments
+(code/lib/model/ray_sampler.py:14-64).  The algorithm itself (VolSDF Algorithm 1) runs in csrc/sampler.hip, driven by
+Multiply.forward; these classes only carry the hyper-parameters."""
+
+
+class RaySampler:
+    def __init__(self, near, far):
+        self.near = near
+        self.far = far
+
+
+class UniformSampler(RaySampler):
+    def __init__(self, scene_bounding_sphere, near, N_samples, take_sphere_intersection=False, far=-1):
+        super().__init__(near, 2.0 * scene_bounding_sphere if far == -1 else far)
+        self.N_samples = N_samples
+        self.scene_bounding_sphere = scene_bounding_sphere
+        self.take_sphere_intersection = take_sphere_intersection
+
+
+class ErrorBoundSampler(RaySampler):
+    def __init__(self, scene_bounding_sphere, near, N_samples, N_samples_eval, N_samples_extra, eps, beta_iters,
+                 max_total_iters, inverse_sphere_bg=False, N_samples_inverse_sphere=0, add_tiny=0.0):
+        super().__init__(near, 2.0 * scene_bounding_sphere)
+        self.N_samples = int(N_samples)
+        self.N_samples_eval = int(N_samples_eval)
+        self.N_samples_extra = int(N_samples_extra)
+        self.eps = float(eps)
+        self.beta_iters = int(beta_iters)
+        self.max_total_iters = int(max_total_iters)
+        self.scene_bounding_sphere = float(scene_bounding_sphere)
+        self.add_tiny = float(add_tiny)
+        self.inverse_sphere_bg = inverse_sphere_bg
+        self.uniform_sampler = UniformSampler(scene_bounding_sphere, near, N_samples_eval,
+                                              take_sphere_intersection=inverse_sphere_bg)
+        # the reference overrides the configured count with 32 (ray_sampler.py:62-64)
+        self.N_samples_inverse_sphere = 32
+        if inverse_sphere_bg:
+            self.inverse_sphere_sampler = UniformSampler(1.0, 0.0, 32, False, far=1.0)
+        if not inverse_sphere_bg:
+            raise NotImplementedError("the shipped configs always render with the inverted-sphere background")

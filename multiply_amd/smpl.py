@@ -1,0 +1,143 @@
+"""SMPL body model on the device: table loading and the SMPLServer module API.
+
+Mirrors the constructor / attribute / forward contract of the reference's SMPLServer (code/lib/model/smpl.py:6-94) and
+of the SMPL class it wraps (code/lib/smpl/body_models.py:60-365) for what the hot path and its callers read:
+`verts_c`, `joints_c`, `tfs_c_inv`, `faces`, `smpl.faces`, `bone_parents`, `param_canonical`, and
+forward(scale, transl, thetas, betas, absolute=False) -> {'smpl_verts','smpl_tfs','smpl_jnts','smpl_weights'}.
+The arithmetic (blend shapes, Rodrigues, kinematic chain, LBS) runs in csrc/geom.hip (mp_smpl_pose).
+"""
+import os
+import pickle
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip
+
+NUM_VERTS, NUM_JOINTS = 6890, 24
+
+
+def _to_np(a, dtype=np.float32):
+    if "scipy.sparse" in str(type(a)):
+        a = a.todense()
+    if hasattr(a, "r"):  # chumpy arrays of the licensed pickle
+        a = a.r
+    return np.array(a, dtype=dtype)
+
+
+def load_smpl_tables(gender="neutral", model_dir=None):
+    """Reads SMPL_{GENDER}.pkl from `model_dir`, $MULTIPLY_SMPL_DIR or ./lib/smpl/smpl_model (the reference's location,
+    smpl.py:13); falls back to the seeded synthetic tables only when MULTIPLY_SYNTHETIC_SMPL=1 is set explicitly."""
+    dirs = [model_dir, os.environ.get("MULTIPLY_SMPL_DIR"), os.path.join(os.getcwd(), "lib/smpl/smpl_model")]
+    for d in dirs:
+        if d and os.path.exists(os.path.join(d, f"SMPL_{str(gender).upper()}.pkl")):
+            with open(os.path.join(d, f"SMPL_{str(gender).upper()}.pkl"), "rb") as f:
+                return pickle.load(f, encoding="latin1")
+    if os.environ.get("MULTIPLY_SYNTHETIC_SMPL") == "1":
+        from .synthetic import make_smpl_tables
+        return make_smpl_tables(0)
+    raise FileNotFoundError("SMPL model file not found (set MULTIPLY_SMPL_DIR, or MULTIPLY_SYNTHETIC_SMPL=1 for the "
+                            "synthetic body used by the benchmarks)")
+
+
+class SMPLDeviceTables:
+    """fp32 device copies of the model tables in the layouts the kernels read."""
+
+    def __init__(self, tables, device):
+        f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        self.v_template = f(_to_np(tables["v_template"]))                                   # (V,3)
+        self.shapedirs = f(_to_np(np.asarray(tables["shapedirs"])[:, :, :10]))               # (V,3,10)
+        pd = _to_np(tables["posedirs"])
+        self.posedirs = f(np.ascontiguousarray(pd.reshape(-1, pd.shape[-1]).T))              # (207, 3V)
+        self.j_regressor = f(_to_np(tables["J_regressor"]))                                  # (24,V)
+        self.lbs_weights = f(_to_np(tables["weights"]))                                      # (V,24)
+        parents = _to_np(tables["kintree_table"], np.float64)[0].astype(np.int64)
+        parents[0] = -1
+        self.parents_np = parents
+        self.parents = f(parents.astype(np.int32))
+        self.faces = np.asarray(tables["f"]).astype(np.int64)
+        assert self.v_template.shape == (NUM_VERTS, 3) and self.lbs_weights.shape == (NUM_VERTS, NUM_JOINTS)
+
+
+def knn_cluster_perm(verts_np):
+    """Static clustering for the exact nearest-vertex search: vertices are split kd-tree style into leaves of exactly 64
+    (the last one partial) so that clusters stay spatially compact under posing. Returns int32 [108*64], -1 = padding."""
+    leaves = []
+
+    def split(idx):
+        if len(idx) <= hip.KNN_CLUSTER:
+            leaves.append(idx)
+            return
+        pts = verts_np[idx]
+        axis = int(np.argmax(pts.max(0) - pts.min(0)))
+        order = idx[np.argsort(pts[:, axis], kind="stable")]
+        nleaf = -(-len(idx) // hip.KNN_CLUSTER)
+        nl = (nleaf // 2) * hip.KNN_CLUSTER
+        split(order[:nl])
+        split(order[nl:])
+
+    split(np.arange(verts_np.shape[0]))
+    assert len(leaves) <= hip.KNN_NC
+    perm = -np.ones(hip.KNN_NC * hip.KNN_CLUSTER, dtype=np.int32)
+    for c, l in enumerate(leaves):
+        perm[c * hip.KNN_CLUSTER:c * hip.KNN_CLUSTER + len(l)] = l
+    return perm
+
+
+class _SMPLHandle:
+    """stands in for `smpl_server.smpl` (only `.faces` / `.bone_parents` are read by callers)"""
+
+    def __init__(self, tables):
+        self.faces = tables.faces
+        self.bone_parents = tables.parents_np.copy()
+
+
+class SMPLServer(nn.Module):
+    def __init__(self, gender="neutral", betas=None, v_template=None, smpl_tables=None, device=None):
+        super().__init__()
+        if v_template is not None:
+            raise NotImplementedError("custom v_template is not used by the shipped configs")
+        hip.require_device()
+        device = torch.device(device or "cuda")
+        raw = smpl_tables if smpl_tables is not None else load_smpl_tables(gender)
+        self.tables = raw if isinstance(raw, SMPLDeviceTables) else SMPLDeviceTables(raw, device)
+        self.smpl = _SMPLHandle(self.tables)
+        self.faces = self.tables.faces
+        self.bone_parents = self.tables.parents_np.astype(int)
+        self.bone_ids = [[int(self.bone_parents[i]), i] for i in range(NUM_JOINTS)]
+        self.v_template = None
+        self.betas = None if betas is None else torch.tensor(np.asarray(betas), dtype=torch.float32, device=device)
+        pc = torch.zeros(1, 86, dtype=torch.float32, device=device)
+        pc[0, 0] = 1
+        pc[0, 9] = np.pi / 6
+        pc[0, 12] = -np.pi / 6
+        if self.betas is not None:
+            pc[0, -10:] = self.betas
+        self.param_canonical = pc
+        self._work = torch.empty(3 * NUM_VERTS + 1024, dtype=torch.float32, device=device)
+        self.tfs_c_inv = None
+        out = self.forward(*torch.split(pc, [1, 3, 72, 10], dim=1), absolute=True)
+        self.verts_c = out["smpl_verts"]
+        self.joints_c = out["smpl_jnts"]
+        self.tfs_c_inv = torch.linalg.inv(out["smpl_tfs"].squeeze(0)).contiguous()   # init-time only (smpl.py:47)
+
+    def pose_into(self, params86, verts, tfs, joints, absolute=False):
+        """raw launch: params86 (86,) device -> preallocated verts (V,3), tfs (24,4,4), joints (24,3)"""
+        t = self.tables
+        hip.check(hip.lib().mp_smpl_pose(hip.ptr(t.v_template), hip.ptr(t.shapedirs), hip.ptr(t.posedirs),
+                                         hip.ptr(t.j_regressor), hip.ptr(t.lbs_weights), hip.ptr(t.parents),
+                                         hip.ptr(params86), None if absolute else hip.ptr(self.tfs_c_inv), hip.ptr(verts),
+                                         hip.ptr(tfs), hip.ptr(joints), hip.ptr(self._work), hip.stream()),
+                  "mp_smpl_pose")
+
+    def forward(self, scale, transl, thetas, betas, absolute=False):
+        dev = self.param_canonical.device
+        p = torch.cat([scale.reshape(1, 1), transl.reshape(1, 3), thetas.reshape(1, 72), betas.reshape(1, 10)], 1)
+        p = p.detach().float().reshape(86).contiguous()
+        verts = torch.empty(NUM_VERTS, 3, dtype=torch.float32, device=dev)
+        tfs = torch.empty(NUM_JOINTS, 4, 4, dtype=torch.float32, device=dev)
+        jnts = torch.empty(NUM_JOINTS, 3, dtype=torch.float32, device=dev)
+        self.pose_into(p, verts, tfs, jnts, absolute=absolute)
+        return {"smpl_verts": verts[None], "smpl_jnts": jnts[None], "smpl_tfs": tfs[None],
+                "smpl_weights": self.tables.lbs_weights[None]}

@@ -1,0 +1,76 @@
+"""GPU parity of the geometry kernels (SMPL posing, exact nearest-vertex warp, rays) against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import multiply_oracle as O
+from tests.util import t32
+
+pytestmark = pytest.mark.gpu
+
+
+def err(name, got, want):
+    e = (torch.as_tensor(got).double().cpu() - torch.as_tensor(want).double()).abs().max().item()
+    print(f"[parity] {name}: max abs err {e:.3e}")
+    return e
+
+
+@pytest.fixture(scope="module")
+def server(smpl_tables):
+    from multiply_amd.smpl import SMPLServer
+    from multiply_amd.synthetic import make_scene
+    sc = make_scene(2, seed=0, H=16, W=16)
+    sp = t32(sc["smpl_params"])
+    return SMPLServer(gender="male", betas=sp[0, 0, 76:].numpy(), smpl_tables=smpl_tables), sp
+
+
+def test_smpl_server(server, smpl_tables):
+    sv, sp = server
+    ref = O.SMPLServerOracle(smpl_tables, sp[0, 0, 76:].numpy())
+    assert err("verts_c", sv.verts_c[0], ref.verts_c) < 2e-6
+    assert err("tfs_c_inv", sv.tfs_c_inv, ref.tfs_c_inv) < 2e-5
+    rng = np.random.RandomState(0)
+    for i in range(3):
+        th = t32(rng.normal(0, 0.3 * i, 72))
+        scale, tr = t32(1.0 + 0.1 * i), sp[0, 0, 1:4]
+        want = ref.forward(scale, tr, th, sp[0, 0, 76:])
+        got = sv(scale.cuda(), tr.cuda(), th.cuda(), sp[0, 0, 76:].cuda())
+        assert err(f"smpl_verts[{i}]", got["smpl_verts"][0], want["smpl_verts"]) < 5e-6
+        assert err(f"smpl_tfs[{i}]", got["smpl_tfs"][0], want["smpl_tfs"]) < 2e-5
+        assert err(f"smpl_jnts[{i}]", got["smpl_jnts"][0], want["smpl_jnts"]) < 5e-6
+
+
+def test_deformer_inverse_and_jacobian(server, smpl_tables):
+    from multiply_amd.deformer import SMPLDeformer
+    sv, sp = server
+    ref = O.SMPLServerOracle(smpl_tables, sp[0, 0, 76:].numpy())
+    want_pose = ref.forward(sp[0, 0, 0], sp[0, 0, 1:4], sp[0, 0, 4:76], sp[0, 0, 76:])
+    got_pose = sv(sp[0, 0, 0].cuda(), sp[0, 0, 1:4].cuda(), sp[0, 0, 4:76].cuda(), sp[0, 0, 76:].cuda())
+    d = SMPLDeformer(betas=sp[0, 0, 76:].numpy(), gender="male", server=sv)
+    rng = np.random.RandomState(2)
+    pick = rng.randint(0, 6890, 5000)
+    x = want_pose["smpl_verts"][pick] + t32(rng.normal(0, 0.08, (5000, 3)))
+    x[:200] += 1.5      # far-away points: exact search must still find the true nearest vertex
+    xc_w, out_w = O.deform_inverse(x, want_pose["smpl_tfs"], want_pose["smpl_verts"], ref.weights)
+    xc_g, out_g = d.forward(x.cuda(), got_pose["smpl_tfs"], return_weights=False, inverse=True,
+                            smpl_verts=got_pose["smpl_verts"])
+    assert (out_g.cpu() == out_w).all()
+    assert err("x_c", xc_g, xc_w) < 2e-5
+    w_c, _, _ = O.query_weights(xc_w, ref.verts_c, ref.weights)
+    J = torch.einsum("pn,nij->pij", w_c, want_pose["smpl_tfs"])[:, :3, :3]
+    jinv = d.forward_skinning_jacobian_inverse(xc_w.cuda(), got_pose["smpl_tfs"])
+    assert err("J^-1", jinv, J.inverse()) < 5e-5
+
+
+def test_rays(golden):
+    import ctypes as C
+    from multiply_amd import hip
+    uv, pose, K = t32(golden["g1_uv"])[0], t32(golden["g1_pose"])[0], t32(golden["g1_K"])[0]
+    R = uv.shape[0]
+    dirs = torch.empty(R, 3, device="cuda"); far = torch.empty(R, device="cuda")
+    uv_d, K_d, pose_d = uv.cuda().contiguous(), K.cuda().reshape(16).contiguous(), pose.cuda().reshape(16).contiguous()
+    hip.check(hip.lib().mp_ray_setup(hip.ptr(uv_d), hip.ptr(K_d), hip.ptr(pose_d), R, C.c_float(3.0), hip.ptr(dirs),
+                                     hip.ptr(far), hip.stream()), "mp_ray_setup")
+    assert err("ray dirs vs reference golden", dirs, golden["g1_dirs"][0]) < 5e-7
+    d, c = O.get_camera_rays(uv, pose, K)
+    assert err("far", far, O.sphere_far(c[None].expand(R, -1), d, 3.0)[:, 0]) < 5e-6

@@ -1,0 +1,82 @@
+"""End-to-end parity: Multiply.forward (eval) on the GPU vs the CPU oracle on the same seeded scene.
+
+Tolerances: the MLPs run with bf16 MFMA operands and fp32 accumulation, everything else is fp32.
+Against the fp32 oracle that gives ~5e-3 on sdf; pixels are compared with the tolerances asserted below."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import multiply_oracle as O
+from tests.util import t32
+
+pytestmark = pytest.mark.gpu
+
+
+def build(P=2, H=20, W=20, seed=0):
+    import warnings
+    warnings.filterwarnings("ignore")
+    from multiply_amd.config import load_config
+    from multiply_amd.multiply import Multiply
+    from multiply_amd.synthetic import make_scene, make_smpl_tables
+    tables = make_smpl_tables(0)
+    sc = make_scene(P, seed=seed, H=H, W=W)
+    opt = load_config()
+    torch.manual_seed(0)
+    model = Multiply(opt, sc["smpl_params"][0, :, 76:], smpl_tables=tables).eval()
+    sp = t32(sc["smpl_params"])
+    inp = dict(uv=t32(sc["uv"]), intrinsics=t32(sc["intrinsics"]), pose=t32(sc["pose"]), smpl_params=sp,
+               smpl_pose=sp[:, :, 4:76], smpl_shape=sp[:, :, 76:], smpl_trans=sp[:, :, 1:4], idx=torch.tensor([3]))
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    oracle = O.MultiplyOracle(sd, tables, sc["smpl_params"][0, :, 76:])
+    return model, oracle, inp
+
+
+def report(name, got, want):
+    got, want = torch.as_tensor(got).double().cpu(), torch.as_tensor(want).double()
+    # a ray through the sphere centre makes the reference's depth2pts_outside divide 0/0 (multiply.py:712-713):
+    # NaNs must appear at the same places (the reference filters them in the loss, loss.py:120)
+    assert (got.isnan() == want.isnan()).all(), f"{name}: NaN pattern differs"
+    e = (got - want).abs()
+    e = e[~e.isnan()]
+    print(f"[parity] {name}: max {e.max().item():.3e} mean {e.mean().item():.3e}")
+    return e.max().item(), e.mean().item()
+
+
+def within(stats, max_tol, mean_tol):
+    return stats[0] < max_tol and stats[1] < mean_tol
+
+
+def test_forward_eval_all_rays_hit():
+    model, oracle, inp = build()
+    R = inp["uv"].shape[1]
+    hit = [torch.arange(R), torch.arange(R)]
+    want = oracle.forward_eval(inp, hit)
+    got = model({**{k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inp.items()}, "hit_index": hit})
+    torch.cuda.synchronize()
+    print("[info] oracle sampler iterations", want["iters"], "gpu", [i.tolist() for i in model.last_stats["iters"]])
+    for p in range(2):
+        report(f"z_vals person {p}", model._last["per"][p]["zfinal"], torch.cat([want["z_vals"][p], want["z_max"][p][:, None]], 1))
+    # bf16-MLP tolerances: (max over pixels, mean over pixels); isolated grazing rays dominate the max
+    assert within(report("bg_rgb", model._last["bg_rgb"], want["bg_rgb"]), 2e-3, 3e-4)
+    assert within(report("bg_transmittance", model._last["bg_T"], want["bg_transmittance"]), 0.15, 3e-3)
+    assert within(report("acc_map", got["acc_map"], want["acc_map"]), 0.15, 3e-3)
+    assert within(report("acc_person_list", got["acc_person_list"], want["acc_person_list"]), 0.15, 3e-3)
+    assert within(report("rgb_values", got["rgb_values"], want["rgb_values"]), 0.1, 2e-3)
+    assert within(report("fg_rgb_values", got["fg_rgb_values"], want["fg_rgb_values"]), 0.1, 2e-3)
+    assert within(report("normal_values", got["normal_values"], want["normal_values"]), 0.15, 3e-3)
+
+
+def test_forward_eval_box_cull_is_conservative():
+    """With the library's own (PCA) box the result must equal the all-rays-hit render: rays outside the box only carry
+    outlier samples whose weights are exactly zero in eval mode (multiply.py:142-143)."""
+    model, oracle, inp = build(H=24, W=24)
+    R = inp["uv"].shape[1]
+    gin = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inp.items()}
+    full = model({**gin, "hit_index": [torch.arange(R), torch.arange(R)]})
+    n_all = model.last_stats["n_hit"]
+    cull = model(gin)
+    n_cull = model.last_stats["n_hit"]
+    print("[info] hit rays all/culled", n_all, n_cull)
+    assert all(c < a for c, a in zip(n_cull, n_all))
+    for k in ["rgb_values", "acc_map", "normal_values", "acc_person_list"]:
+        assert report("cull vs all: " + k, cull[k], full[k].cpu())[0] < 1e-5
