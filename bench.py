@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""Headline benchmark: rays/sec rendering full synthetic 512x512 frames of a 2-person scene on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one pass of the hot path (Multiply.forward, eval mode, all persons, with background) over one batch of
+synthetic input = one full 512x512 frame = 262,144 rays (BASELINE.json configs[1]: 2 persons, 128 importance
+samples/ray, bf16 MLPs).  Inputs (rays' uv, camera, SMPL parameters, weights) are resident in HBM before the timed
+region.  N > 1: one process per GPU (torchrun), every rank renders its own frames of the sequence (rays/frames shard
+without any data-path collective -> weak scaling); time = max over ranks between barriers.
+
+The JSON line also carries
+  roofline     : the dominant kernel's algorithmic FLOP/s (HIP events inside the timed region) vs the bf16 MFMA peak
+  cpu_baseline : the CPU oracle (fp32 torch restatement of the reference path) timed on this host on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+M_IMP, M_REN, M_BGIMP, M_BGREN = 542208, 266496, 532736, 40704      # MACs / point
+PEAK_BF16_TFLOPS = 2500.0                                           # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def build_model(n_samples, seed=0, H=512, W=512, P=2):
+    import warnings
+    warnings.filterwarnings("ignore")
+    from multiply_amd.config import load_config
+    from multiply_amd.multiply import Multiply
+    from multiply_amd.synthetic import make_scene, make_smpl_tables
+    tables = make_smpl_tables(0)
+    sc = make_scene(P, seed=seed, H=H, W=W)
+    opt = load_config()
+    opt.ray_sampler.N_samples = n_samples
+    opt.ray_sampler.N_samples_eval = max(128, n_samples)
+    torch.manual_seed(0)
+    model = Multiply(opt, sc["smpl_params"][0, :, 76:], smpl_tables=tables).eval()
+    t = lambda a: torch.tensor(a, dtype=torch.float32)
+    sp = t(sc["smpl_params"])
+    inp = dict(uv=t(sc["uv"]), intrinsics=t(sc["intrinsics"]), pose=t(sc["pose"]), smpl_params=sp,
+               smpl_pose=sp[:, :, 4:76], smpl_shape=sp[:, :, 76:], smpl_trans=sp[:, :, 1:4], idx=torch.tensor([3]))
+    return model, inp, tables, sc
+
+
+def to_dev(inp):
+    return {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inp.items()}
+
+
+def cpu_baseline(model, inp, tables, sc, n_samples, rows=1, stride=4):
+    """Times the CPU oracle on a bounded sample of the same frame: every `stride`-th pixel of the middle image row
+    (which crosses both bodies).  Also returns the GPU-vs-oracle pixel error on that sample."""
+    from oracle import multiply_oracle as O
+    H = W = int(round(np.sqrt(inp["uv"].shape[1])))
+    sel = (H // 2) * W + torch.arange(0, W, stride)
+    sub = dict(inp)
+    sub["uv"] = inp["uv"][:, sel]
+    got = model(to_dev(sub))
+    torch.cuda.synchronize()
+    hit = [model._last["per"][p]["hit_index"][:n].long().cpu() for p, n in zip(model._last["persons"], model.last_stats["n_hit"])]
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cfg = O.SamplerCfg(N_samples=n_samples, N_samples_eval=max(128, n_samples))
+    oracle = O.MultiplyOracle(sd, tables, sc["smpl_params"][0, :, 76:], cfg)
+    t0 = time.time()
+    want = oracle.forward_eval(sub, hit)
+    dt = time.time() - t0
+    err = (got["rgb_values"].cpu() - want["rgb_values"]).abs()
+    err = err[~err.isnan()]
+    return dict(value=len(sel) / dt, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{len(sel)} rays (every {stride}th pixel of image row {H // 2}) of the same frame, fp32 torch "
+                       f"oracle, {dt:.1f} s", parity_rgb_max_abs=float(err.max()), parity_rgb_mean_abs=float(err.mean()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--samples", type=int, default=128, help="importance samples per ray (N_samples)")
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print per-phase GPU times to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = world > 1
+    torch.cuda.set_device(local)
+    if dist:
+        import torch.distributed as td
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    # every rank renders its own frame of the synthetic sequence (seed = rank)
+    model, inp, tables, sc = build_model(args.samples, seed=rank, H=args.res, W=args.res)
+    model.convergence_group = 512            # the reference renders frames in chunks of pixel_per_batch = 512 rays
+    gin = to_dev(inp)
+    R = gin["uv"].shape[1]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model(gin)
+    model.profile = True
+    model.phase_events = {}
+    shaded, sdf_evals = [], []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model(gin)
+        shaded.append(model.last_stats["n_shaded"])
+        sdf_evals.append(model.last_stats["n_sdf_evals"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    model.profile = False
+    if dist:
+        tt = torch.tensor([elapsed], device="cuda")
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    phases = model.phase_times_ms()
+    n_shaded = float(sum(int(w.sum()) for s in shaded for w in s)) / args.steps          # per frame
+    n_sdf = float(sum(int(w[:-1].sum()) for s in sdf_evals for w in s)) / args.steps
+    flops = {"mlp_shade": n_shaded * 4 * M_IMP, "sampler_mlp_sdf": n_sdf * 2 * M_IMP, "mlp_color": n_shaded * 2 * M_REN,
+             "background": R * 32 * 2 * (M_BGIMP + M_BGREN)}
+    dom = max(flops, key=lambda k: phases.get(k, (0, 0.0))[1])
+    n_launch, ms = phases[dom]
+    per_launch_s = ms / 1e3 / max(n_launch, 1)
+    launches_per_frame = n_launch / args.steps
+    achieved = flops[dom] / launches_per_frame / per_launch_s / 1e12
+    if args.breakdown and rank == 0:
+        tot = sum(v[1] for v in phases.values())
+        for k, (n, m) in sorted(phases.items(), key=lambda kv: -kv[1][1]):
+            print(f"  {k:18s} {n:5d} launches {m / args.steps:9.2f} ms/frame {100 * m / tot:5.1f}%", file=sys.stderr)
+        print(f"  shaded points/frame {n_shaded:.0f}  sdf evals/frame {n_sdf:.0f}  hit rays {model.last_stats['n_hit']}",
+              file=sys.stderr)
+
+    if rank == 0:
+        out = {
+            "metric": "rays/sec rendering full 512x512 frames (eval forward, all persons, with background)",
+            "value": R * args.steps * world / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"2-person synthetic SMPL scene, {args.res}x{args.res} rays/frame, N_samples="
+                                   f"{args.samples} (+32 extra +2 bounds = {args.samples + 33} composited samples/ray/"
+                                   f"person), N_samples_eval={max(128, args.samples)}, 32 background samples, "
+                                   f"convergence groups of 512 rays (reference pixel_per_batch), geometric-init weights",
+                       "rays_per_step": R, "frames_per_rank": args.steps, "parallelism": f"frame-sharded dp{world}"},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "avg_launch_ms": 1e3 * per_launch_s, "launches_per_step": launches_per_frame,
+                         "algorithmic_flop_per_launch": flops[dom] / launches_per_frame},
+            "phases_ms_per_step": {k: v[1] / args.steps for k, v in phases.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, inp, tables, sc, args.samples)
+        print(json.dumps(out))
+    if dist:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -98,9 +98,36 @@ class Multiply(nn.Module):
         self.convergence_group = None
         self.obb_inflate = 1.2
         self.last_stats = {}
+        self.profile = False
+        self.phase_events = {}
         self.to(device)
 
     # ------------------------------------------------------------------ helpers
+    class _Phase:
+        """HIP-event bracket around a group of launches on the current stream (enabled by `model.profile = True`)."""
+
+        def __init__(self, owner, name):
+            self.o, self.name = owner, name
+
+        def __enter__(self):
+            if self.o.profile:
+                self.e0 = torch.cuda.Event(enable_timing=True)
+                self.e1 = torch.cuda.Event(enable_timing=True)
+                self.e0.record()
+
+        def __exit__(self, *a):
+            if self.o.profile:
+                self.e1.record()
+                self.o.phase_events.setdefault(self.name, []).append((self.e0, self.e1))
+
+    def _ph(self, name):
+        return Multiply._Phase(self, name)
+
+    def phase_times_ms(self):
+        """{phase: (n_brackets, total ms)} of the events recorded since the last reset (synchronises)."""
+        torch.cuda.synchronize()
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.phase_events.items()}
+
     def _sampler_cfg(self):
         rs = self.ray_sampler
         return hip.MpSamplerCfg(rs.N_samples, rs.N_samples_eval, rs.N_samples_extra, rs.beta_iters, rs.max_total_iters,
@@ -209,19 +236,23 @@ class Multiply(nn.Module):
             work = torch.empty(Rp * NE, **i32)
             wcount = torch.zeros(rs.max_total_iters + 1, **i32)
             for it in range(rs.max_total_iters):
-                hip.check(L.mp_warp_inverse(None, hip.ptr(dirs), hip.ptr(pose), hip.ptr(pp["hit_index"]),
-                                            hip.ptr(pp["count"]), hip.ptr(znew), NE, NE, Rp, hip.ptr(pp["vsorted"]),
-                                            hip.ptr(pp["cbound"]), hip.ptr(skin_w), hip.ptr(pp["tfs"]), 1,
-                                            hip.ptr(active), hip.ptr(xc_new), None, hip.ptr(sdfnew), hip.ptr(work),
-                                            hip.ptr(wcount[it:it + 1]), st), "mp_warp_inverse")
-                hip.check(L.mp_mlp_sdf(C.byref(pk_sdf.net), hip.ptr(pk_sdf.wpack), hip.ptr(pk_sdf.bias), hip.ptr(xc_new),
-                                       hip.ptr(work), hip.ptr(wcount[it:it + 1]), Rp * NE, hip.ptr(sdfnew), st),
-                          "mp_mlp_sdf")
-                hip.check(L.mp_sampler_bound(C.byref(cfg), C.byref(state), hip.ptr(beta), hip.ptr(pp["hit_index"]),
-                                             hip.ptr(pp["count"]), Rp, group, R, it, st), "mp_sampler_bound")
-                hip.check(L.mp_sampler_resample(C.byref(cfg), C.byref(state), hip.ptr(beta), hip.ptr(far),
-                                                hip.ptr(pp["hit_index"]), hip.ptr(pp["count"]), Rp, group, R, it, None,
-                                                None, st), "mp_sampler_resample")
+                with self._ph("sampler_warp"):
+                    hip.check(L.mp_warp_inverse(None, hip.ptr(dirs), hip.ptr(pose), hip.ptr(pp["hit_index"]),
+                                                hip.ptr(pp["count"]), hip.ptr(znew), NE, NE, Rp, hip.ptr(pp["vsorted"]),
+                                                hip.ptr(pp["cbound"]), hip.ptr(skin_w), hip.ptr(pp["tfs"]), 1,
+                                                hip.ptr(active), hip.ptr(xc_new), None, hip.ptr(sdfnew), hip.ptr(work),
+                                                hip.ptr(wcount[it:it + 1]), st), "mp_warp_inverse")
+                with self._ph("sampler_mlp_sdf"):
+                    hip.check(L.mp_mlp_sdf(C.byref(pk_sdf.net), hip.ptr(pk_sdf.wpack), hip.ptr(pk_sdf.bias),
+                                           hip.ptr(xc_new), hip.ptr(work), hip.ptr(wcount[it:it + 1]), Rp * NE,
+                                           hip.ptr(sdfnew), st), "mp_mlp_sdf")
+                with self._ph("sampler_bound"):
+                    hip.check(L.mp_sampler_bound(C.byref(cfg), C.byref(state), hip.ptr(beta), hip.ptr(pp["hit_index"]),
+                                                 hip.ptr(pp["count"]), Rp, group, R, it, st), "mp_sampler_bound")
+                with self._ph("sampler_resample"):
+                    hip.check(L.mp_sampler_resample(C.byref(cfg), C.byref(state), hip.ptr(beta), hip.ptr(far),
+                                                    hip.ptr(pp["hit_index"]), hip.ptr(pp["count"]), Rp, group, R, it,
+                                                    None, None, st), "mp_sampler_resample")
             # ---- shading of the final samples (multiply.py:294-308, 403-405)
             npts = Rp * S
             xc = torch.empty(npts, 3, **f32)
@@ -230,14 +261,18 @@ class Multiply(nn.Module):
             rgb = torch.zeros(npts, 3, **f32)
             work2 = torch.empty(npts, **i32)
             wc2 = wcount[rs.max_total_iters:]
+            ph = self._ph("shade_warp"); ph.__enter__()
             hip.check(L.mp_warp_inverse_shade(hip.ptr(dirs), hip.ptr(pose), hip.ptr(pp["hit_index"]), hip.ptr(pp["count"]),
                                               hip.ptr(zfinal), NZ, S, Rp, hip.ptr(pp["vsorted"]), hip.ptr(pp["cbound"]),
                                               hip.ptr(skin_w), hip.ptr(pp["tfs"]), 1, hip.ptr(beta), hip.ptr(xc), None,
                                               hip.ptr(sdf), hip.ptr(work2), hip.ptr(wc2), st), "mp_warp_inverse_shade")
+            ph.__exit__()
             jinv = torch.empty(npts, 9, **f32)
+            ph = self._ph("shade_jacobian"); ph.__enter__()
             hip.check(L.mp_warp_jacobian(hip.ptr(xc), hip.ptr(work2), hip.ptr(wc2), npts, hip.ptr(dfm.vsorted_c),
                                          hip.ptr(dfm.cbound_c), hip.ptr(skin_w), hip.ptr(pp["tfs"]), hip.ptr(jinv), st),
                       "mp_warp_jacobian")
+            ph.__exit__()
             pk_full = hip.packed(imp, "full", 2)
             pk_full.refresh(pp["cond"])
             pk_col = hip.packed(ren, "color", 2)
@@ -245,15 +280,17 @@ class Multiply(nn.Module):
             ren.__dict__["_mp_pose_embed"] = pe
             pk_col.refresh(pe(pp["cond"]))
             feat = torch.empty(((npts + 255) // 256) * 4 * 8 * 4 * 1024, dtype=torch.uint8, device=dev)
-            hip.check(L.mp_mlp_shade(C.byref(pk_full.net), hip.ptr(pk_full.wpack), hip.ptr(pk_full.bias), hip.ptr(xc),
-                                     hip.ptr(jinv), hip.ptr(work2), hip.ptr(wc2), npts, hip.ptr(sdf), hip.ptr(nrm),
-                                     hip.ptr(feat), st), "mp_mlp_shade")
-            hip.check(L.mp_mlp_color(C.byref(pk_col.net), hip.ptr(pk_col.wpack), hip.ptr(pk_col.bias), hip.ptr(xc),
-                                     hip.ptr(nrm), hip.ptr(feat), hip.ptr(work2), hip.ptr(wc2), npts, hip.ptr(rgb), st),
-                      "mp_mlp_color")
+            with self._ph("mlp_shade"):
+                hip.check(L.mp_mlp_shade(C.byref(pk_full.net), hip.ptr(pk_full.wpack), hip.ptr(pk_full.bias), hip.ptr(xc),
+                                         hip.ptr(jinv), hip.ptr(work2), hip.ptr(wc2), npts, hip.ptr(sdf), hip.ptr(nrm),
+                                         hip.ptr(feat), st), "mp_mlp_shade")
+            with self._ph("mlp_color"):
+                hip.check(L.mp_mlp_color(C.byref(pk_col.net), hip.ptr(pk_col.wpack), hip.ptr(pk_col.bias), hip.ptr(xc),
+                                         hip.ptr(nrm), hip.ptr(feat), hip.ptr(work2), hip.ptr(wc2), npts, hip.ptr(rgb),
+                                         st), "mp_mlp_color")
             z_l.append(zfinal); sdf_l.append(sdf); rgb_l.append(rgb); nrm_l.append(nrm); inv_l.append(pp["inv_index"])
             stats["iters"].append(iters); stats["n_sdf_evals"].append(wcount)
-            per[p].update(zfinal=zfinal, sdf=sdf, rgb=rgb, nrm=nrm, xc=xc, work2=work2)
+            per[p].update(zfinal=zfinal, sdf=sdf, rgb=rgb, nrm=nrm, xc=xc, work2=work2, wc2=wc2)
 
         # ---- background (multiply.py:482-484, 514-539)
         bg_rgb = None
@@ -262,8 +299,10 @@ class Multiply(nn.Module):
             code = self.frame_latent_encoder.weight.detach()[int(torch.as_tensor(input[key]).reshape(-1)[0])]
             t = torch.linspace(0.0, 1.0, rs.N_samples_inverse_sphere, device=dev)
             z_bg = torch.flip(t * (1.0 / rs.scene_bounding_sphere), dims=[0]).contiguous()
-            bg_rgb = hip.background(self.bg_implicit_network, self.bg_rendering_network, dirs, pose.reshape(4, 4)[:3, 3],
-                                    z_bg, code, radius=self.sdf_bounding_sphere)
+            with self._ph("background"):
+                bg_rgb = hip.background(self.bg_implicit_network, self.bg_rendering_network, dirs,
+                                        pose.reshape(4, 4)[:3, 3].contiguous(), z_bg, code,
+                                        radius=self.sdf_bounding_sphere)
 
         # ---- compositing (multiply.py:425-480, 544-545)
         def table(ts):
@@ -272,10 +311,13 @@ class Multiply(nn.Module):
         rgb_values = torch.empty(R, 3, **f32); fg_rgb_values = torch.empty(R, 3, **f32)
         normal_values = torch.empty(R, 3, **f32); acc_map = torch.empty(R, **f32)
         acc_person = torch.empty(R, len(persons), **f32); bg_T = torch.empty(R, **f32)
+        ph = self._ph("composite"); ph.__enter__()
         hip.check(L.mp_composite(R, len(persons), NZ, hip.ptr(t_inv), hip.ptr(t_z), hip.ptr(t_sdf), hip.ptr(t_rgb),
                                  hip.ptr(t_nrm), hip.ptr(beta), hip.ptr(bg_rgb) if bg_rgb is not None else None,
                                  hip.ptr(rgb_values), hip.ptr(fg_rgb_values), hip.ptr(normal_values), hip.ptr(acc_map),
                                  hip.ptr(acc_person), hip.ptr(bg_T), st), "mp_composite")
+        ph.__exit__()
+        stats["n_shaded"] = [per[p]["wc2"] for p in persons]
         self.last_stats = stats
         self._last = dict(per=per, dirs=dirs, far=far, bg_T=bg_T, bg_rgb=bg_rgb, persons=persons, keep=(t_inv, t_z, t_sdf,
                                                                                                         t_rgb, t_nrm))
