@@ -132,11 +132,11 @@ int mp_ray_hits_from_index(const int* hit_index, int n_hit, int n_rays, int* hit
  * point id = k*n_s + s, x = cam + z[k*z_stride + s] * dirs[hit_index[k]], cam = pose[:3,3].
  *   mode 0 (training): every point is written to xc and appended to worklist.
  *   mode 1 (eval): outliers get sdf_out = 4 (multiply.py:142-143) and are NOT appended.
- *   active [ceil(n_hit/group)] per-group flag or NULL.  Outputs: xc [n][3], worklist, *work_count (atomic, must be 0). */
+ *   ray_active [max_rays] per-ray flag or NULL; launch_active: device int, 0 = nothing to do (kernel exits), or NULL.  Outputs: xc [n][3], worklist, *work_count (atomic, must be 0). */
 int mp_warp_inverse(const float* pts, const float* dirs, const float* pose, const int* hit_index, const int* hit_count,
                     const float* z, int z_stride, int n_s, int max_rays, const float* vsorted, const float* cbound,
-                    const float* skin_w, const float* tfs, int mode, const int* ray_active, float* xc,
-                    unsigned char* outlier, float* sdf_out, int* worklist, int* work_count, void* stream);
+                    const float* skin_w, const float* tfs, int mode, const int* ray_active, const int* launch_active,
+                    float* xc, unsigned char* outlier, float* sdf_out, int* worklist, int* work_count, void* stream);
 /* The same for the final samples of the shading pass (z rows hold n_s+1 depths).  eval_mode: outliers get sdf 4 and are
  * dropped from the worklist only when their compositing alpha 1-exp(-sigma(4) dt) is exactly 0 in fp32. */
 int mp_warp_inverse_shade(const float* dirs, const float* pose, const int* hit_index, const int* hit_count,
@@ -164,6 +164,7 @@ typedef struct {
     int* group_flag;   /* [max_total_iters+1][n_groups] */
     float* zfinal;     /* [max_rays][n_samples + n_samples_extra + 2] */
     int* iters;        /* [n_groups] iterations run (diagnostics) */
+    int* any_active;   /* [max_total_iters+1] any_active[i] != 0: some ray still needs SDF queries in iteration i */
 } MpSamplerState;
 /* uniform start (ray_sampler.py:21-42, 70-76); t_rand [max_rays][n_eval] or NULL (eval: no jitter) */
 int mp_sampler_init(const MpSamplerCfg* cfg, const MpSamplerState* st, const float* far, const int* hit_index,

@@ -210,14 +210,17 @@ __global__ __launch_bounds__(64) void k_knn_build(const float* __restrict__ vert
 // Ties -> lowest vertex id, like an argmin over the original order (pytorch3d knn_points / deformer.py:39).
 __device__ __forceinline__ void knn_query(const float4* vs, const float4* cb, float px, float py, float pz, float cap2,
                                           float& best, int& bi) {
-    float ub2 = FLT_MAX;
-    for (int c = 0; c < NC; ++c) {
-        const float4 b = cb[c];
-        const float dx = px - b.x, dy = py - b.y, dz = pz - b.z;
-        const float u = sqrtf(dx * dx + dy * dy + dz * dz) + b.w;
-        ub2 = fminf(ub2, u * u);
+    best = cap2;
+    if (__any(cap2 == FLT_MAX)) {  // unbounded search: start from the tightest "some vertex is at most this far" bound
+        float ub2 = FLT_MAX;
+        for (int c = 0; c < NC; ++c) {
+            const float4 b = cb[c];
+            const float dx = px - b.x, dy = py - b.y, dz = pz - b.z;
+            const float u = sqrtf(dx * dx + dy * dy + dz * dz) + b.w;
+            ub2 = fminf(ub2, u * u);
+        }
+        best = fminf(ub2 * 1.0001f + 1e-12f, cap2);
     }
-    best = fminf(ub2 * 1.0001f + 1e-12f, cap2);
     bi = INT_MAX;
     for (int c = 0; c < NC; ++c) {
         const float4 b = cb[c];
@@ -272,7 +275,7 @@ __device__ __forceinline__ void inv3(const float (&T)[12], float (&I)[9]) {
 }
 
 constexpr int WARP_THREADS = 512;
-constexpr int WARP_LDS = NC * CL * 16 + NC * 16 + NJ * 16 * 4;
+constexpr int WARP_LDS = NC * CL * 16 + NC * 16 + NJ * 16 * 4 + 32;
 
 // mode 0: all points -> xc + worklist; mode 1: eval, outliers get sdf 4 and are skipped;
 // mode 2: eval shading, outliers get sdf 4 and are skipped only when their alpha is exactly 0 in fp32
@@ -281,14 +284,28 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
     const int* __restrict__ hit_index, const int* __restrict__ hit_count, const float* __restrict__ z, int z_stride,
     int n_s, int max_rays, int n_pts, const float* __restrict__ vsorted, const float* __restrict__ cbound,
     const float* __restrict__ skin_w, const float* __restrict__ tfs, int mode, const int* __restrict__ ray_active,
-    const float* __restrict__ beta_p, float* __restrict__ xc, unsigned char* __restrict__ outlier,
-    float* __restrict__ sdf_out, int* __restrict__ worklist, int* __restrict__ work_count) {
+    const float* __restrict__ beta_p, const int* __restrict__ launch_active, float* __restrict__ xc,
+    unsigned char* __restrict__ outlier, float* __restrict__ sdf_out, int* __restrict__ worklist,
+    int* __restrict__ work_count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (launch_active && *launch_active == 0) return;  // no ray of this launch is still being sampled
     float4* vs = (float4*)smem;
     float4* cb = vs + NC * CL;
     float* tl = (float*)(cb + NC);
+    float* box = tl + NJ * 16;  // [6] conservative bounds of the vertex set (from the cluster spheres)
     load_knn_lds(vs, cb, vsorted, cbound);
     for (int i = threadIdx.x; i < NJ * 16; i += blockDim.x) tl[i] = tfs[i];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (int c = threadIdx.x; c < NC; c += 64) {
+            const float4 b = cb[c];
+            lo[0] = fminf(lo[0], b.x - b.w); lo[1] = fminf(lo[1], b.y - b.w); lo[2] = fminf(lo[2], b.z - b.w);
+            hi[0] = fmaxf(hi[0], b.x + b.w); hi[1] = fmaxf(hi[1], b.y + b.w); hi[2] = fmaxf(hi[2], b.z + b.w);
+        }
+        for (int a = 0; a < 3; ++a) { lo[a] = wave_min(lo[a]); hi[a] = wave_max(hi[a]); }
+        if (threadIdx.x == 0) for (int a = 0; a < 3; ++a) { box[a] = lo[a] - 0.1005f; box[3 + a] = hi[a] + 0.1005f; }
+    }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const bool rays = pts == nullptr;
@@ -313,8 +330,13 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
             const int i = slab * 64 + lane;
             if (i < n_pts) { x = pts[3 * i]; y = pts[3 * i + 1]; zz = pts[3 * i + 2]; pid = i; }
         }
-        float best; int bi;
-        knn_query(vs, cb, x, y, zz, pid >= 0 ? cap2 : -1.0f, best, bi);  // idle lanes never open a cluster
+        // eval: a point farther than 0.1 from the box of all vertices is an outlier without any search
+        const bool near_box = mode == 0 || (x >= box[0] && y >= box[1] && zz >= box[2] && x <= box[3] && y <= box[4] &&
+                                            zz <= box[5]);
+        float best = -1.0f;
+        int bi = INT_MAX;
+        if (__any(pid >= 0 && near_box))
+            knn_query(vs, cb, x, y, zz, (pid >= 0 && near_box) ? cap2 : -1.0f, best, bi);  // idle lanes open no cluster
         bool append = false;
         if (pid >= 0) {
             // outlier = sqrt(min(d2, 4)) > 0.1 (deformer.py:41-49)
@@ -648,8 +670,8 @@ extern "C" int mp_ray_hits_from_index(const int* hit_index, int n_hit, int n_ray
 extern "C" int mp_warp_inverse(const float* pts, const float* dirs, const float* pose, const int* hit_index,
                                const int* hit_count, const float* z, int z_stride, int n_s, int max_rays,
                                const float* vsorted, const float* cbound, const float* skin_w, const float* tfs,
-                               int mode, const int* ray_active, float* xc, unsigned char* outlier, float* sdf_out,
-                               int* worklist, int* work_count, void* stream) {
+                               int mode, const int* ray_active, const int* launch_active, float* xc,
+                               unsigned char* outlier, float* sdf_out, int* worklist, int* work_count, void* stream) {
     // when pts != NULL, max_rays carries the number of explicit points and sdf_out may carry beta for mode 2 (unused)
     if (max_rays <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
@@ -660,7 +682,8 @@ extern "C" int mp_warp_inverse(const float* pts, const float* dirs, const float*
     const int n_slab = pts ? (max_rays + 63) / 64 : ((max_rays + 63) / 64) * n_s;
     hipLaunchKernelGGL(k_warp_inverse, dim3(warp_grid(n_slab, nw)), dim3(WARP_THREADS), WARP_LDS, st, pts, dirs, pose,
                        hit_index, hit_count, z, z_stride, n_s, max_rays, pts ? max_rays : 0, vsorted, cbound, skin_w, tfs,
-                       mode & 3, ray_active, (const float*)nullptr, xc, outlier, sdf_out, worklist, work_count);
+                       mode & 3, ray_active, (const float*)nullptr, launch_active, xc, outlier, sdf_out, worklist,
+                       work_count);
     return (int)hipGetLastError();
 }
 
@@ -679,8 +702,8 @@ extern "C" int mp_warp_inverse_shade(const float* dirs, const float* pose, const
     const int n_slab = ((max_rays + 63) / 64) * n_s;
     hipLaunchKernelGGL(k_warp_inverse, dim3(warp_grid(n_slab, nw)), dim3(WARP_THREADS), WARP_LDS, st,
                        (const float*)nullptr, dirs, pose, hit_index, hit_count, z, z_stride, n_s, max_rays, 0, vsorted,
-                       cbound, skin_w, tfs, eval_mode ? 2 : 0, (const int*)nullptr, beta, xc, outlier, sdf_out, worklist,
-                       work_count);
+                       cbound, skin_w, tfs, eval_mode ? 2 : 0, (const int*)nullptr, beta, (const int*)nullptr, xc, outlier,
+                       sdf_out, worklist, work_count);
     return (int)hipGetLastError();
 }
 

@@ -111,13 +111,12 @@ __global__ __launch_bounds__(256) void k_mlp_sdf(const NetDesc net, const char* 
         float x[3] = {0.f, 0.f, 0.f};
         if (id >= 0) { x[0] = xc[3 * (size_t)id]; x[1] = xc[3 * (size_t)id + 1]; x[2] = xc[3 * (size_t)id + 2]; }
         stage_pe<3, 6, KS_IN>(stage + lane * in_stride(KS_IN), x);
-        bf16x8 Bcur[KS_REG][NB], Bin[KS_IN][NB];
+        bf16x8 Bcur[KS_REG][NB];
         f32x4 out[NB];
         zero_b<NB>(Bcur);
         __syncthreads();  // staging rows are written by other lanes
-        read_bin<NB, KS_IN>(stage, Bin, lane);
         prologue<KS_IN>(net, wpack, smem + L::ring, wave, lane);
-        run_net<NB, false, KS_IN>(net, wpack, bias_lds, smem + L::ring, Bcur, Bin, out, wave, lane);
+        run_net<NB, false, KS_IN, HID_SOFTPLUS>(net, wpack, bias_lds, smem + L::ring, Bcur, stage, out, wave, lane);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int pid = __shfl(id, nb * 16 + (lane & 15));
@@ -145,13 +144,12 @@ __global__ __launch_bounds__(256) void k_mlp_full(const NetDesc net, const char*
 #pragma unroll
         for (int a = 0; a < D_IN; ++a) xi[a] = id >= 0 ? x[(size_t)id * D_IN + a] : 0.f;
         stage_pe<D_IN, LFREQ, KS_IN>(stage + lane * in_stride(KS_IN), xi);
-        bf16x8 Bcur[KS_REG][NB], Bin[KS_IN][NB];
+        bf16x8 Bcur[KS_REG][NB];
         f32x4 out[NB];
         zero_b<NB>(Bcur);
         __syncthreads();  // staging rows are written by other lanes
-        read_bin<NB, KS_IN>(stage, Bin, lane);
         prologue<KS_IN>(net, wpack, smem + L::ring, wave, lane);
-        run_net<NB, false, KS_IN>(net, wpack, bias_lds, smem + L::ring, Bcur, Bin, out, wave, lane);
+        run_net<NB, false, KS_IN, HID_SOFTPLUS>(net, wpack, bias_lds, smem + L::ring, Bcur, stage, out, wave, lane);
         const int j = lane & 15, g = lane >> 4;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -193,13 +191,12 @@ __global__ __launch_bounds__(256) void k_mlp_shade(const NetDesc net, const char
         __bf16* row = stage + (role * 16 + j) * in_stride(KS_IN);
         if (role == 0) stage_pe<3, 6, KS_IN>(row, x);
         else stage_pe_tangent<6, KS_IN>(row, x, role - 1);
-        bf16x8 Bcur[KS_REG][NB], Bin[KS_IN][NB];
+        bf16x8 Bcur[KS_REG][NB];
         f32x4 out[NB];
         zero_b<NB>(Bcur);
         __syncthreads();  // staging rows are written by other lanes
-        read_bin<NB, KS_IN>(stage, Bin, lane);
         prologue<KS_IN>(net, wpack, smem + L::ring, wave, lane);
-        run_net<NB, true, KS_IN>(net, wpack, bias_lds, smem + L::ring, Bcur, Bin, out, wave, lane);
+        run_net<NB, true, KS_IN, HID_SOFTPLUS>(net, wpack, bias_lds, smem + L::ring, Bcur, stage, out, wave, lane);
         // features of block 0 -> B fragments of the colour kernel's tile t, column block `wave`
 #pragma unroll
         for (int ks = 0; ks < KS_REG; ++ks)
@@ -250,7 +247,7 @@ __global__ __launch_bounds__(256) void k_mlp_color(const NetDesc net, const char
                 row[3 + a] = (__bf16)normal[3 * (size_t)id + a];
             }
         }
-        bf16x8 Bcur[KS_REG][NB], Bin[KS_IN][NB];
+        bf16x8 Bcur[KS_REG][NB];
         f32x4 out[NB];
         const bool live = tile * 64 < count;
 #pragma unroll
@@ -260,9 +257,8 @@ __global__ __launch_bounds__(256) void k_mlp_color(const NetDesc net, const char
                 Bcur[ks][nb] = live ? *(const bf16x8*)(feat_frag + (((size_t)tile * KS_REG + ks) * 4 + nb) * 1024 + lane * 16)
                                     : (bf16x8)(__bf16)0.0f;
         __syncthreads();
-        read_bin<NB, KS_IN>(stage, Bin, lane);
         prologue<KS_IN>(net, wpack, smem + L::ring, wave, lane);
-        run_net<NB, false, KS_IN>(net, wpack, bias_lds, smem + L::ring, Bcur, Bin, out, wave, lane);
+        run_net<NB, false, KS_IN, HID_RELU>(net, wpack, bias_lds, smem + L::ring, Bcur, stage, out, wave, lane);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int pid = __shfl(id, nb * 16 + (lane & 15));
@@ -325,13 +321,12 @@ __global__ __launch_bounds__(256) void k_background(const NetDesc net_imp, const
         const float pnn = sqrtf(pn[0] * pn[0] + pn[1] * pn[1] + pn[2] * pn[2]);
         const float x4[4] = {pn[0] / pnn, pn[1] / pnn, pn[2] / pnn, depth};
         stage_pe<4, 10, KS_IN>(stage + lane * in_stride(KS_IN), x4);
-        bf16x8 Bcur[KS_REG][NB], Bin[KS_IN][NB];
+        bf16x8 Bcur[KS_REG][NB];
         f32x4 out[NB];
         zero_b<NB>(Bcur);
         __syncthreads();  // staging rows are written by other lanes
-        read_bin<NB, KS_IN>(stage, Bin, lane);
         prologue<KS_IN>(net_imp, wp_imp, smem + L::ring, wave, lane);
-        run_net<NB, false, KS_IN>(net_imp, wp_imp, bias_lds0, smem + L::ring, Bcur, Bin, out, wave, lane);
+        run_net<NB, false, KS_IN, HID_SOFTPLUS>(net_imp, wp_imp, bias_lds0, smem + L::ring, Bcur, stage, out, wave, lane);
         if (lane < 16) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) scr[(nb * 16 + lane) * 4 + 3] = fabsf(out[nb][0]);  // AbsDensity (density.py:32-34)
@@ -339,9 +334,8 @@ __global__ __launch_bounds__(256) void k_background(const NetDesc net_imp, const
         // colour net: [PE_4(view dir) (27), frame code (hoisted), features (registers)]
         stage_pe<3, 4, KS_IN>(stage + lane * in_stride(KS_IN), d);
         __syncthreads();
-        read_bin<NB, KS_IN>(stage, Bin, lane);
         prologue<KS_IN>(net_ren, wp_ren, smem + L::ring, wave, lane);
-        run_net<NB, false, KS_IN>(net_ren, wp_ren, bias_lds1, smem + L::ring, Bcur, Bin, out, wave, lane);
+        run_net<NB, false, KS_IN, HID_RELU>(net_ren, wp_ren, bias_lds1, smem + L::ring, Bcur, stage, out, wave, lane);
         if (lane < 16) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)

@@ -58,21 +58,34 @@ struct NetDesc {
     LayerDesc layer[MAX_LAYERS];
 };
 
-// softplus(beta=100, threshold=20) exactly as torch.nn.Softplus (networks.py:85)
-__device__ __forceinline__ float softplus100(float z) {
-    float t = 100.0f * z;
-    // log1p(exp(t))/100 = max(z,0) + log1p(exp(-|t|))/100
-    float u = __expf(-fabsf(t));
-    float sp = fmaxf(z, 0.0f) + 0.01f * __logf(1.0f + u);
-    return t > 20.0f ? z : sp;
+// max as ONE v_max_f32 (fmaxf on an MFMA result makes hipcc add a canonicalising v_max in front)
+__device__ __forceinline__ float relu_f(float x) {
+    float r;
+    asm("v_max_f32 %0, %1, 0" : "=v"(r) : "v"(x));
+    return r;
 }
-// d softplus / dz = sigmoid(100 z)
-__device__ __forceinline__ float softplus100_grad(float z) {
-    float t = 100.0f * z;
-    float u = __expf(-fabsf(t));
-    float r = __frcp_rn(1.0f + u);
-    float s = t >= 0.0f ? r : u * r;
-    return t > 20.0f ? 1.0f : s;
+__device__ __forceinline__ float max_f(float x, float y) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+// softplus(beta=100, threshold=20) of torch.nn.Softplus (networks.py:85):  log1p(exp(100 z))/100
+//   = max(z,0) + (ln2/100) * log2(1 + 2^(-100*log2(e)*|z|)).  The threshold branch (100 z > 20 -> z) is dropped: there the
+//   correction term is < 2.1e-11, below half an ulp of z >= 0.2, so the fp32 result is identical.
+// Raw v_exp_f32 / v_log_f32 (no denormal fix-up code: the log argument lies in [1,2], the exp result in [0,1]).
+constexpr float SP_K = 144.26950408889634f;      // 100 * log2(e)
+constexpr float SP_C = 0.0069314718055994531f;   // ln(2) / 100
+__device__ __forceinline__ float softplus100(float z) {
+    const float u = __builtin_amdgcn_exp2f(-SP_K * fabsf(z));
+    return fmaf(SP_C, __builtin_amdgcn_logf(1.0f + u), relu_f(z));
+}
+// softplus and its derivative sigmoid(100 z) sharing one exponential
+__device__ __forceinline__ void softplus100_vg(float z, float& h, float& s) {
+    const float u = __builtin_amdgcn_exp2f(-SP_K * fabsf(z));
+    const float w = 1.0f + u;
+    h = fmaf(SP_C, __builtin_amdgcn_logf(w), relu_f(z));
+    const float r = __builtin_amdgcn_rcpf(w);
+    s = z >= 0.0f ? r : u * r;
 }
 
 template <int KS_IN>
@@ -91,36 +104,140 @@ __device__ __forceinline__ void issue_chunk(const char* __restrict__ wpack, char
     }
 }
 
-template <int NB>
-__device__ __forceinline__ void store_bhalf(bf16x8& b, int half, const f32x4& v) {
-    if (half == 0) {
-        b[0] = (__bf16)v[0]; b[1] = (__bf16)v[1]; b[2] = (__bf16)v[2]; b[3] = (__bf16)v[3];
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    const bf16x2 p = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, p);
+}
+
+// Next-layer K operand under construction.  With NB = 4 the live state (Bcur 128 + Bnext 128 + input 32 + accumulators)
+// exceeds the 256 architectural VGPRs; left to itself hipcc parks arbitrary pieces in AGPRs and pays a
+// v_accvgpr_read for every MFMA operand.  Bnext is written once and read once per layer, so it is pinned in the
+// accumulator file explicitly (one write and one read per register per layer) and everything hot stays in VGPRs.
+template <int NB, bool IN_AGPR>
+struct NextB {
+    unsigned r[KS_REG][NB][4];
+    __device__ __forceinline__ void put(int c, int nb, int half, const f32x4& v) {
+        const unsigned lo = pack_bf16(v[0], v[1]), hi = pack_bf16(v[2], v[3]);
+        if constexpr (IN_AGPR) {
+            asm("v_accvgpr_write_b32 %0, %1" : "=a"(r[c][nb][2 * half]) : "v"(lo));
+            asm("v_accvgpr_write_b32 %0, %1" : "=a"(r[c][nb][2 * half + 1]) : "v"(hi));
+        } else {
+            r[c][nb][2 * half] = lo;
+            r[c][nb][2 * half + 1] = hi;
+        }
+    }
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int c = 0; c < KS_REG; ++c)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if constexpr (IN_AGPR) asm("v_accvgpr_write_b32 %0, 0" : "=a"(r[c][nb][i]));
+                    else r[c][nb][i] = 0u;
+                }
+    }
+    __device__ __forceinline__ bf16x8 get(int c, int nb) const {
+        u32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (IN_AGPR) {
+                unsigned t;
+                asm("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(r[c][nb][i]));
+                v[i] = t;
+            } else {
+                v[i] = r[c][nb][i];
+            }
+        }
+        return __builtin_bit_cast(bf16x8, v);
+    }
+};
+
+enum Hidden : int { HID_SOFTPLUS = 0, HID_RELU = 1 };
+
+// Activation of one finished 16-row block, cut into KS_REG pieces so that piece `ks` can be issued between the MFMAs
+// of K step `ks` of the NEXT block (software pipeline, see run_net).  Branch-free; m = 1: hidden layer, m = 0: linear
+// (last) layer, k = 1 - m:
+//   softplus: max(z, k z) + (m ln2/100) log2(1 + 2^(-K|z|))   (k = 0 -> softplus, k = 1 -> z)
+//   relu    : max(z, k z)
+// Forward mode (column block 0 = values, 1..3 = tangents): t' = sigmoid(100 z) * t.
+template <int NB, bool FWD, int HID>
+__device__ __forceinline__ float act_value(float z, float m, float k, float cm) {
+    const float base = max_f(z, k * z);
+    if constexpr (HID == HID_SOFTPLUS) {
+        const float u = __builtin_amdgcn_exp2f(-SP_K * fabsf(z));
+        return fmaf(cm, __builtin_amdgcn_logf(1.0f + u), base);
     } else {
-        b[4] = (__bf16)v[0]; b[5] = (__bf16)v[1]; b[6] = (__bf16)v[2]; b[7] = (__bf16)v[3];
+        return base;
     }
 }
 
+template <int NB, bool FWD, int HID, int PIECE, typename NB_T>
+__device__ __forceinline__ void act_piece(f32x4 (&p)[NB], float m, NB_T& Bn, int pc, int ph) {
+    const float k = 1.0f - m, cm = SP_C * m;
+    if constexpr (FWD) {
+        static_assert(NB == 4, "forward mode uses 4 column blocks");
+        if constexpr (PIECE < 4) {               // row PIECE: value + its three tangents
+            constexpr int r = PIECE;
+            const float z = p[0][r];
+            const float u = __builtin_amdgcn_exp2f(-SP_K * fabsf(z));
+            const float w = 1.0f + u;
+            p[0][r] = fmaf(cm, __builtin_amdgcn_logf(w), max_f(z, k * z));
+            const float rr = __builtin_amdgcn_rcpf(w);
+            const float sg = z >= 0.0f ? rr : u * rr;   // sigmoid(100 z)
+            const float s = fmaf(m, sg, k);             // m = 0 -> 1
+            p[1][r] *= s; p[2][r] *= s; p[3][r] *= s;
+        } else {                                  // pack column block PIECE-4 into the next layer's K operand
+            if (pc < KS_REG) Bn.put(pc, PIECE - 4, ph, p[PIECE - 4]);
+        }
+    } else if constexpr (NB == 4) {               // 16 values: two per piece, block nb = PIECE/2 packed when complete
+        constexpr int nb = PIECE / 2, r0 = 2 * (PIECE % 2);
+        p[nb][r0] = act_value<NB, FWD, HID>(p[nb][r0], m, k, cm);
+        p[nb][r0 + 1] = act_value<NB, FWD, HID>(p[nb][r0 + 1], m, k, cm);
+        if constexpr (PIECE % 2 == 1) { if (pc < KS_REG) Bn.put(pc, nb, ph, p[nb]); }
+    } else {                                      // NB == 2: 8 values, one per piece
+        static_assert(NB == 2, "NB must be 2 or 4");
+        constexpr int nb = PIECE / 4, r = PIECE % 4;
+        p[nb][r] = act_value<NB, FWD, HID>(p[nb][r], m, k, cm);
+        if constexpr (PIECE % 4 == 3) { if (pc < KS_REG) Bn.put(pc, nb, ph, p[nb]); }
+    }
+}
+
+template <int NB, bool FWD, int HID, typename NB_T>
+__device__ __forceinline__ void act_all(f32x4 (&p)[NB], float m, NB_T& Bn, int pc, int ph) {
+    act_piece<NB, FWD, HID, 0>(p, m, Bn, pc, ph); act_piece<NB, FWD, HID, 1>(p, m, Bn, pc, ph);
+    act_piece<NB, FWD, HID, 2>(p, m, Bn, pc, ph); act_piece<NB, FWD, HID, 3>(p, m, Bn, pc, ph);
+    act_piece<NB, FWD, HID, 4>(p, m, Bn, pc, ph); act_piece<NB, FWD, HID, 5>(p, m, Bn, pc, ph);
+    act_piece<NB, FWD, HID, 6>(p, m, Bn, pc, ph); act_piece<NB, FWD, HID, 7>(p, m, Bn, pc, ph);
+}
+
 // Runs the whole network for this wave's NB column blocks.
-//   Bcur : register K operand of the first layer that has use_reg (undefined content is fine
-//          if layer 0 has use_reg = 0); on return holds the last layer's (bf16) output blocks.
-//   Bin  : encoded-input K operand (K steps 8,9 of every layer with use_in).
-//   out  : fp32 rows 0..15 of the `out_chunk` of the layer that declares one.
-// The caller must have issued chunk 0 into ring slot 0 and synchronised (see prologue()).
-template <int NB, bool FWD, int KS_IN>
+//   Bcur : register K operand of layer 0 (zeros when the network input only enters through Bin); on return it holds
+//          the last layer's (bf16) output blocks (e.g. the 256 features).
+//   stage_wave : this wave's input staging tile in LDS ([16*NB rows][in_stride] bf16, rows = columns): the encoded
+//          network input, read on demand as the K operand of K steps 8.. of every layer with use_in.
+//   out  : fp32 rows 0..15 of the `out_chunk` (0 or 8) of the layer that declares one, before activation.
+// Software pipeline: the activation of a finished 16-row block is issued inside the MFMA stream of the next block
+// (same basic block, independent registers), so the matrix pipe keeps running while the VALU does softplus / bf16
+// packing.  The caller must have issued chunk 0 into ring slot 0 and synchronised (see prologue()).
+template <int NB, bool FWD, int KS_IN, int HID>
 __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restrict__ wpack, const float* bias_lds,
-                                        char* wring, bf16x8 (&Bcur)[KS_REG][NB], const bf16x8 (&Bin)[KS_IN][NB],
+                                        char* wring, bf16x8 (&Bcur)[KS_REG][NB], const __bf16* stage_wave,
                                         f32x4 (&out)[NB], int wave, int lane) {
     const int g = lane >> 4;
     int ci = 0;
-    bf16x8 Bnext[KS_REG][NB];
-#pragma unroll
-    for (int k = 0; k < KS_REG; ++k)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) Bnext[k][nb] = (bf16x8)(__bf16)0.0f;
-
+    NextB<NB, (NB > 2)> Bn;
+    Bn.zero();
     for (int l = 0; l < net.n_layers; ++l) {
         const LayerDesc L = net.layer[l];
         const float* bl = bias_lds + l * BIAS_STRIDE;
+        const float m = L.act != ACT_NONE ? 1.0f : 0.0f;
+        f32x4 pend[NB];  // finished block whose activation is still pending
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) pend[nb] = (f32x4){0, 0, 0, 0};
 #pragma unroll
         for (int c = 0; c < MAX_CHUNKS; ++c) {
             if (c < L.n_chunk) {
@@ -133,57 +250,48 @@ __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restri
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) acc[nb] = (FWD && nb > 0) ? (f32x4){0, 0, 0, 0} : bv;
                     const char* tile = slot + mbl * mb_bytes(KS_IN) + lane * 16;
-                    if (L.use_reg) {
+                    // pending block = (c, 0) when mbl == 1, (c-1, 1) when mbl == 0: its activation rides in this MFMA stream
+                    const bool has_pend = mbl == 1 || c > 0;
+                    const int pc = mbl == 1 ? c : c - 1, ph = mbl == 1 ? 0 : 1;
+                    if (has_pend && (pc == 0 || pc == MAX_CHUNKS - 1) && ph == 0) {
+                        if (pc == L.out_chunk) {
 #pragma unroll
-                        for (int ks = 0; ks < KS_REG; ++ks) {
-                            const bf16x8 a = *(const bf16x8*)(tile + ks * TILE_BYTES);
-#pragma unroll
-                            for (int nb = 0; nb < NB; ++nb)
-                                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, Bcur[ks][nb], acc[nb], 0, 0, 0);
+                            for (int nb = 0; nb < NB; ++nb) out[nb] = pend[nb];
                         }
                     }
+                    bf16x8 a_nxt = *(const bf16x8*)(tile);
+#define MP_KSTEP(KS)                                                                                              \
+                    {                                                                                             \
+                        const bf16x8 a = a_nxt;                                                                   \
+                        if (KS + 1 < KS_REG) a_nxt = *(const bf16x8*)(tile + (KS + 1) * TILE_BYTES);              \
+                        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                         \
+                            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, Bcur[KS][nb], acc[nb], 0, 0, 0); \
+                        if (has_pend) act_piece<NB, FWD, HID, KS>(pend, m, Bn, pc, ph);                           \
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                        \
+                        _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                          \
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+                            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                    \
+                        }                                                                                         \
+                        __builtin_amdgcn_sched_barrier(0);                                                        \
+                    }
+                    MP_KSTEP(0) MP_KSTEP(1) MP_KSTEP(2) MP_KSTEP(3) MP_KSTEP(4) MP_KSTEP(5) MP_KSTEP(6) MP_KSTEP(7)
+#undef MP_KSTEP
                     if (L.use_in) {
 #pragma unroll
                         for (int ks = 0; ks < KS_IN; ++ks) {
                             const bf16x8 a = *(const bf16x8*)(tile + (KS_REG + ks) * TILE_BYTES);
 #pragma unroll
-                            for (int nb = 0; nb < NB; ++nb)
-                                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, Bin[ks][nb], acc[nb], 0, 0, 0);
-                        }
-                    }
-                    // activation (fp32), then either fp32 out or bf16 K operand of the next layer
-                    if (L.act == ACT_SOFTPLUS) {
-                        if (FWD) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float z = acc[0][r];
-                                const float s = softplus100_grad(z);
-                                acc[0][r] = softplus100(z);
-#pragma unroll
-                                for (int nb = 1; nb < NB; ++nb) acc[nb][r] *= s;
+                            for (int nb = 0; nb < NB; ++nb) {
+                                const bf16x8 bi = *(const bf16x8*)(stage_wave + (nb * 16 + (lane & 15)) * in_stride(KS_IN) +
+                                                                   ks * 32 + g * 8);
+                                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bi, acc[nb], 0, 0, 0);
                             }
-                        } else {
-#pragma unroll
-                            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) acc[nb][r] = softplus100(acc[nb][r]);
                         }
-                    } else if (L.act == ACT_RELU) {
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) acc[nb][r] = fmaxf(acc[nb][r], 0.0f);
                     }
-                    if (c == L.out_chunk) {
-                        if (mbl == 0) {
 #pragma unroll
-                            for (int nb = 0; nb < NB; ++nb) out[nb] = acc[nb];
-                        }
-                    } else if (c < KS_REG) {
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) store_bhalf<NB>(Bnext[c < KS_REG ? c : 0][nb], mbl, acc[nb]);
-                    }
+                    for (int nb = 0; nb < NB; ++nb) pend[nb] = acc[nb];
                 }
+                if (c == L.n_chunk - 1) act_all<NB, FWD, HID>(pend, m, Bn, c, 1);  // layer ends: drain block (c, 1)
                 __syncthreads();  // every wave is done with chunk ci; chunk ci+1 has landed (vmcnt drained)
                 ++ci;
             }
@@ -191,7 +299,7 @@ __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restri
 #pragma unroll
         for (int k = 0; k < KS_REG; ++k)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) Bcur[k][nb] = Bnext[k][nb];
+            for (int nb = 0; nb < NB; ++nb) Bcur[k][nb] = Bn.get(k, nb);
     }
 }
 

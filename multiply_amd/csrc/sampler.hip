@@ -101,8 +101,10 @@ __global__ __launch_bounds__(256) void k_sampler_init(MpSamplerCfg cfg, MpSample
     const int lane = threadIdx.x & 63;
     const int n_rays = min(*hit_count, max_rays);
     const int NE = cfg.n_samples_eval;
-    if (blockIdx.x == 0)
+    if (blockIdx.x == 0) {
         for (int i = threadIdx.x; i < (cfg.max_total_iters + 1) * n_groups; i += 256) st.group_flag[i] = 0;
+        for (int i = threadIdx.x; i <= cfg.max_total_iters; i += 256) st.any_active[i] = i == 0 ? 1 : 0;
+    }
     float* zl = (float*)smem + (threadIdx.x >> 6) * NE;   // wave-private
     for (int k = blockIdx.x * WAVES + (threadIdx.x >> 6); k < n_rays; k += gridDim.x * WAVES) {
         const float fr = far[hit_index[k]], nr = cfg.near_;
@@ -269,6 +271,7 @@ __global__ __launch_bounds__(256) void k_sampler_resample(MpSamplerCfg cfg, MpSa
     wave_sync();
     if (more) {
         for (int j = lane; j < NE; j += 64) st.znew[(size_t)k * NE + j] = outv[j];
+        if (lane == 0) st.any_active[iter + 1] = 1;
         return;
     }
     // final set: samples + near + far + N_extra of the current depths, sorted (ray_sampler.py:194-209)

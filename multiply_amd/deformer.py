@@ -51,7 +51,7 @@ class SMPLDeformer(nn.Module):
         outl = torch.empty(n, dtype=torch.uint8, device=dev)
         tfs = smpl_tfs.detach().float().reshape(24, 16).contiguous()
         hip.check(L.mp_warp_inverse(hip.ptr(x), None, None, None, None, None, 0, 1, n, hip.ptr(vs), hip.ptr(cb),
-                                    hip.ptr(self.smpl_weights[0].contiguous()), hip.ptr(tfs), 0, None, hip.ptr(xc),
+                                    hip.ptr(self.smpl_weights[0].contiguous()), hip.ptr(tfs), 0, None, None, hip.ptr(xc),
                                     hip.ptr(outl), None, None, None, hip.stream()), "mp_warp_inverse")
         return xc, outl.bool()
 

@@ -37,7 +37,7 @@ class MpSamplerCfg(C.Structure):
 class MpSamplerState(C.Structure):
     _fields_ = [("zs", C.c_void_p), ("sdfs", C.c_void_p), ("nz", C.c_void_p), ("znew", C.c_void_p),
                 ("sdfnew", C.c_void_p), ("beta", C.c_void_p), ("ray_active", C.c_void_p), ("group_flag", C.c_void_p),
-                ("zfinal", C.c_void_p), ("iters", C.c_void_p)]
+                ("zfinal", C.c_void_p), ("iters", C.c_void_p), ("any_active", C.c_void_p)]
 
 
 _lib = None

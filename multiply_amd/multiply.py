@@ -227,9 +227,10 @@ class Multiply(nn.Module):
             betar = torch.empty(Rp, **f32); active = torch.empty(Rp, **i32)
             gflag = torch.empty((rs.max_total_iters + 1) * n_groups, **i32)
             zfinal = torch.empty(Rp, NZ, **f32); iters = torch.zeros(n_groups, **i32)
+            any_active = torch.zeros(rs.max_total_iters + 1, **i32)
             state = hip.MpSamplerState(zs.data_ptr(), sdfs.data_ptr(), nz.data_ptr(), znew.data_ptr(),
                                        sdfnew.data_ptr(), betar.data_ptr(), active.data_ptr(), gflag.data_ptr(),
-                                       zfinal.data_ptr(), iters.data_ptr())
+                                       zfinal.data_ptr(), iters.data_ptr(), any_active.data_ptr())
             hip.check(L.mp_sampler_init(C.byref(cfg), C.byref(state), hip.ptr(far), hip.ptr(pp["hit_index"]),
                                         hip.ptr(pp["count"]), Rp, group, R, None, st), "mp_sampler_init")
             xc_new = torch.empty(Rp * NE, 3, **f32)
@@ -240,7 +241,8 @@ class Multiply(nn.Module):
                     hip.check(L.mp_warp_inverse(None, hip.ptr(dirs), hip.ptr(pose), hip.ptr(pp["hit_index"]),
                                                 hip.ptr(pp["count"]), hip.ptr(znew), NE, NE, Rp, hip.ptr(pp["vsorted"]),
                                                 hip.ptr(pp["cbound"]), hip.ptr(skin_w), hip.ptr(pp["tfs"]), 1,
-                                                hip.ptr(active), hip.ptr(xc_new), None, hip.ptr(sdfnew), hip.ptr(work),
+                                                hip.ptr(active), hip.ptr(any_active[it:it + 1]), hip.ptr(xc_new), None,
+                                                hip.ptr(sdfnew), hip.ptr(work),
                                                 hip.ptr(wcount[it:it + 1]), st), "mp_warp_inverse")
                 with self._ph("sampler_mlp_sdf"):
                     hip.check(L.mp_mlp_sdf(C.byref(pk_sdf.net), hip.ptr(pk_sdf.wpack), hip.ptr(pk_sdf.bias),

@@ -1,0 +1,95 @@
+"""CPU-side checks: the C-ABI library exports every declared symbol, host-side packing logic, config surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    from multiply_amd.build import build
+    return build(verbose=False)        # hipcc cross-compiles gfx950 without a GPU
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    lib = ctypes.CDLL(lib_path)
+    hdr = open(os.path.join(REPO, "include", "multiply_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(mp_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(names) >= 20
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    lib.mp_arch.restype = ctypes.c_char_p
+    assert lib.mp_arch() == b"gfx950"
+
+
+def test_struct_layouts_match_header():
+    from multiply_amd import hip
+    assert ctypes.sizeof(hip.MpLayer) == 20 and ctypes.sizeof(hip.MpNet) == 8 + 20 * hip.MAX_LAYERS
+    assert ctypes.sizeof(hip.MpSamplerCfg) == 32
+    assert ctypes.sizeof(hip.MpSamplerState) == 11 * ctypes.sizeof(ctypes.c_void_p)
+
+
+def test_k_slot_permutation_is_a_bijection():
+    from multiply_amd import hip
+    f = [hip.reg_slot_feature(s) for s in range(256)]
+    assert sorted(f) == list(range(256))
+    # lane group g of K step ks owns output rows 4g..4g+3 of blocks 2ks and 2ks+1 (mlp_core.hpp)
+    for s in range(256):
+        ks, sl = divmod(s, 32); g, e = divmod(sl, 8)
+        row = f[s] - 32 * ks
+        assert row // 16 == (0 if e < 4 else 1) and (row % 16) // 4 == g
+
+
+def test_layer_plans_cover_every_weight_exactly_once():
+    from multiply_amd import hip
+    from tests.util import seeded_networks
+    m, _ = seeded_networks(1, 0)
+    for net, role, ks_in in [(m.foreground_implicit_network_list[0], "full", 2), (m.bg_implicit_network, "full", 3),
+                             (m.foreground_rendering_network_list[0], "color", 2), (m.bg_rendering_network, "color", 3)]:
+        from multiply_amd.networks import ImplicitNet
+        plans = hip.implicit_plans(net, role) if isinstance(net, ImplicitNet) else hip.rendering_plans(net)
+        for p in plans:
+            w = p.lin.weight_v if hasattr(p.lin, "weight_v") else p.lin.weight
+            out_dim, in_dim = w.shape
+            cm = p.colmap(ks_in)
+            used = sorted(c for c in cm if c >= 0)
+            hoisted = list(range(p.hoist[0], p.hoist[0] + p.hoist[1])) if p.hoist else []
+            assert sorted(used + hoisted) == list(range(in_dim)), "every input column is packed or hoisted exactly once"
+            rows = sorted(r for r in p.rowmap if r >= 0)
+            assert rows == list(range(out_dim))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from multiply_amd import hip
+    monkeypatch.setattr(hip, "_lib", None)
+    monkeypatch.setattr(hip, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no fallback"):
+        hip.lib()
+
+
+def test_no_device_fails_loudly():
+    from multiply_amd import hip
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        hip.require_device()
+
+
+def test_cluster_perm_partitions_all_vertices(smpl_tables):
+    from multiply_amd.smpl import knn_cluster_perm
+    perm = knn_cluster_perm(np.asarray(smpl_tables["v_template"], dtype=np.float32))
+    assert perm.shape == (108 * 64,)
+    assert sorted(perm[perm >= 0].tolist()) == list(range(6890))
+    v = np.asarray(smpl_tables["v_template"])
+    # clusters are spatially compact: mean cluster radius far below the body size
+    rad = []
+    for c in range(108):
+        ids = perm[c * 64:(c + 1) * 64]
+        ids = ids[ids >= 0]
+        rad.append(np.linalg.norm(v[ids] - v[ids].mean(0), axis=1).max())
+    assert np.mean(rad) < 0.15
