@@ -17,8 +17,8 @@ def test_shard_bounds_partition_and_alignment():
             assert e0 == s1
         for s, e in b:
             assert s % group == 0 or s == n
-        sizes = [e - s for s, e in b]
-        assert max(sizes) - min(sizes) <= group
+        ngroups = [-(-(e - s) // group) for s, e in b]      # balanced to within one group
+        assert max(ngroups) - min(ngroups) <= 1
 
 
 def _worker(rank, world, port, n, group, q):
