@@ -53,10 +53,12 @@ typedef struct {
  *   rowmap [n_rows] : source row of packed row r, -1 = zero row   (n_rows multiple of 32)
  *   colmap [(8+ks_in)*32], colscale [...] : source column of K slot s (-1 = zero) and a factor
  *   wpack_layer : destination (n_rows/32 chunks of (8+ks_in)*2 KiB) or NULL to only write the bias
- *   bias_layer  : destination, MP_BIAS_STRIDE floats (rows >= n_rows are zeroed) */
+ *   bias_layer  : destination, MP_BIAS_STRIDE floats (rows >= n_rows are zeroed); bias_scale multiplies (b + hoist).
+ * Softplus networks run in scaled units (csrc/mlp_core.hpp): the host passes colscale = K for input-fed slots and
+ * bias_scale = K = 100 log2(e) on hidden layers, and colscale = 1/K on the last (linear) layer. */
 int mp_pack_layer(const float* v, const float* g, const float* b, int out_dim, int in_dim, const int* rowmap,
                   int n_rows, const int* colmap, const float* colscale, int ks_in, int hoist_col0, int hoist_n,
-                  const float* hoist_vec, void* wpack_layer, float* bias_layer, void* stream);
+                  const float* hoist_vec, float bias_scale, void* wpack_layer, float* bias_layer, void* stream);
 
 /* ---- fused MLP evaluation -------------------------------------------------------------------
  * mp_mlp_sdf: ImplicitNet.forward restricted to the sdf column (networks.py:126-181; caller:
@@ -138,15 +140,20 @@ int mp_warp_inverse(const float* pts, const float* dirs, const float* pose, cons
                     const float* skin_w, const float* tfs, int mode, const int* ray_active, const int* launch_active,
                     float* xc, unsigned char* outlier, float* sdf_out, int* worklist, int* work_count, void* stream);
 /* The same for the final samples of the shading pass (z rows hold n_s+1 depths).  eval_mode: outliers get sdf 4 and are
- * dropped from the worklist only when their compositing alpha 1-exp(-sigma(4) dt) is exactly 0 in fp32. */
+ * dropped from the worklist only when their compositing alpha 1-exp(-sigma(4) dt) is exactly 0 in fp32.
+ * need_flag [id] (optional) = 1 for every point that was appended. */
 int mp_warp_inverse_shade(const float* dirs, const float* pose, const int* hit_index, const int* hit_count,
                           const float* z, int z_stride, int n_s, int max_rays, const float* vsorted, const float* cbound,
                           const float* skin_w, const float* tfs, int eval_mode, const float* beta, float* xc,
-                          unsigned char* outlier, float* sdf_out, int* worklist, int* work_count, void* stream);
+                          unsigned char* outlier, unsigned char* need_flag, float* sdf_out, int* worklist,
+                          int* work_count, void* stream);
 /* Jacobian of forward skinning at canonical points (deformer.py:31-35 + multiply.py:625-641): nearest CANONICAL
- * vertex -> weights -> J = (sum_j w_j T_j)[:3,:3] -> jinv [id][9].  Only ids in worklist. */
-int mp_warp_jacobian(const float* xc, const int* worklist, const int* count, int max_count, const float* vsorted_c,
-                     const float* cbound_c, const float* skin_w, const float* tfs, float* jinv, void* stream);
+ * vertex -> weights -> J = (sum_j w_j T_j)[:3,:3] -> jinv [id][9].
+ * n_s > 0: points are the samples of the hit rays (id = k*n_s + s, as in mp_warp_inverse_shade) and only ids with
+ * need[id] != 0 are processed; n_s == 0: explicit list of n_pts points (need, hit_count ignored). */
+int mp_warp_jacobian(const float* xc, const unsigned char* need, const int* hit_count, int max_rays, int n_s, int n_pts,
+                     const float* vsorted_c, const float* cbound_c, const float* skin_w, const float* tfs, float* jinv,
+                     void* stream);
 
 /* ---- VolSDF error-bound sampler (ray_sampler.py:66-220), split at the SDF queries ---------------
  * State per hit ray k (row stride zmax = 640): zs/sdfs sorted samples and their sdf, nz count, znew/sdfnew [128]

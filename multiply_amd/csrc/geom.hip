@@ -205,40 +205,74 @@ __global__ __launch_bounds__(64) void k_knn_build(const float* __restrict__ vert
     if (l == 0) cbound[c] = make_float4(cx, cy, cz, r * 1.00001f + 1e-7f);
 }
 
-// Exact nearest vertex among the clustered set held in LDS (vs, cb).  cap2: search radius^2 (FLT_MAX = unbounded).
-// Returns the original vertex id (INT_MAX when nothing lies within the cap) and the squared distance.
-// Ties -> lowest vertex id, like an argmin over the original order (pytorch3d knn_points / deformer.py:39).
-__device__ __forceinline__ void knn_query(const float4* vs, const float4* cb, float px, float py, float pz, float cap2,
-                                          float& best, int& bi) {
-    best = cap2;
-    if (__any(cap2 == FLT_MAX)) {  // unbounded search: start from the tightest "some vertex is at most this far" bound
-        float ub2 = FLT_MAX;
-        for (int c = 0; c < NC; ++c) {
+// Exact nearest vertex among the clustered set held in LDS (vs, cb), for the 64 points of one wave at once.
+// The wave's points are spatially coherent (neighbouring rays at the same sample index), so clusters are culled ONCE per
+// wave against the bounding box of its points: lane c tests clusters c and c+64 in parallel (two LDS reads instead of a
+// latency-bound loop over all 108 spheres), and only the surviving clusters are scanned vertex by vertex.
+//   cap2 (per lane): squared search radius; < 0 = idle lane.  A vertex within the cap, if any, is the exact nearest one
+//   (ties -> lowest vertex id, like an argmin over the original order: pytorch3d knn_points / deformer.py:39).
+//   Returns bi = INT_MAX when no vertex lies within the cap.
+__device__ __forceinline__ void knn_capped(const float4* vs, const float4* cb, float px, float py, float pz, float cap2,
+                                           float& best, int& bi) {
+    const int lane = threadIdx.x & 63;
+    const bool on = cap2 >= 0.0f;
+    const float lx = wave_min(on ? px : FLT_MAX), ly = wave_min(on ? py : FLT_MAX), lz = wave_min(on ? pz : FLT_MAX);
+    const float hx = wave_max(on ? px : -FLT_MAX), hy = wave_max(on ? py : -FLT_MAX), hz = wave_max(on ? pz : -FLT_MAX);
+    const float capr = sqrtf(wave_max(on ? cap2 : 0.0f));
+    unsigned long long cand[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int c = lane + 64 * h;
+        bool hit = false;
+        if (c < NC) {
             const float4 b = cb[c];
-            const float dx = px - b.x, dy = py - b.y, dz = pz - b.z;
-            const float u = sqrtf(dx * dx + dy * dy + dz * dz) + b.w;
-            ub2 = fminf(ub2, u * u);
+            const float dx = b.x - fminf(fmaxf(b.x, lx), hx), dy = b.y - fminf(fmaxf(b.y, ly), hy),
+                        dz = b.z - fminf(fmaxf(b.z, lz), hz);
+            const float reach = (b.w + capr) * 1.0001f;
+            hit = dx * dx + dy * dy + dz * dz <= reach * reach;
         }
-        best = fminf(ub2 * 1.0001f + 1e-12f, cap2);
+        cand[h] = __ballot(hit);
     }
+    best = cap2;
     bi = INT_MAX;
-    for (int c = 0; c < NC; ++c) {
-        const float4 b = cb[c];
-        const float dx = px - b.x, dy = py - b.y, dz = pz - b.z;
-        const float lb = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz) - b.w, 0.0f);
-        if (__any(lb * lb * 0.9999f <= best)) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        unsigned long long m = cand[h];
+        while (m) {
+            const int c = __builtin_ctzll(m) + 64 * h;
+            m &= m - 1;
+            const float4 b = cb[c];
+            const float ex = px - b.x, ey = py - b.y, ez = pz - b.z;
+            const float lb = fmaxf(sqrtf(ex * ex + ey * ey + ez * ez) - b.w, 0.0f);
+            if (!__any(lb * lb * 0.9999f <= best)) continue;   // no lane can improve inside this sphere
             const float4* cv = vs + c * CL;
 #pragma unroll 8
             for (int k = 0; k < CL; ++k) {
                 const float4 v = cv[k];
-                const float ex = px - v.x, ey = py - v.y, ez = pz - v.z;
-                const float d2 = ex * ex + ey * ey + ez * ez;
+                const float fx = px - v.x, fy = py - v.y, fz = pz - v.z;
+                const float d2 = fx * fx + fy * fy + fz * fz;
                 const int id = __float_as_int(v.w);
                 const bool upd = d2 < best || (d2 == best && id < bi);
                 best = upd ? d2 : best;
                 bi = upd ? id : bi;
             }
         }
+    }
+}
+
+// Unbounded exact search: grow the cap geometrically for the lanes that found nothing (far points need few rounds; every
+// round re-culls the clusters in parallel).  want: lane participates.
+__device__ __forceinline__ void knn_unbounded(const float4* vs, const float4* cb, float px, float py, float pz, bool want,
+                                              float& best, int& bi) {
+    float cap = 0.0064f;  // (0.08)^2
+    best = -1.0f;
+    bi = INT_MAX;
+    bool todo = want;
+    while (__any(todo)) {
+        float b2; int i2;
+        knn_capped(vs, cb, px, py, pz, todo ? cap : -1.0f, b2, i2);
+        if (todo && i2 != INT_MAX) { best = b2; bi = i2; todo = false; }
+        cap *= 4.0f;
     }
 }
 
@@ -285,8 +319,8 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
     int n_s, int max_rays, int n_pts, const float* __restrict__ vsorted, const float* __restrict__ cbound,
     const float* __restrict__ skin_w, const float* __restrict__ tfs, int mode, const int* __restrict__ ray_active,
     const float* __restrict__ beta_p, const int* __restrict__ launch_active, float* __restrict__ xc,
-    unsigned char* __restrict__ outlier, float* __restrict__ sdf_out, int* __restrict__ worklist,
-    int* __restrict__ work_count) {
+    unsigned char* __restrict__ outlier, unsigned char* __restrict__ need_flag, float* __restrict__ sdf_out,
+    int* __restrict__ worklist, int* __restrict__ work_count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (launch_active && *launch_active == 0) return;  // no ray of this launch is still being sampled
     float4* vs = (float4*)smem;
@@ -313,7 +347,7 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
     const int n_slab = rays ? ((n_rays + 63) / 64) * n_s : (n_pts + 63) / 64;
     float cam[3] = {0.f, 0.f, 0.f};
     if (rays) { cam[0] = pose[3]; cam[1] = pose[7]; cam[2] = pose[11]; }
-    const float cap2 = mode == 0 ? FLT_MAX : 0.0101f;  // eval only needs neighbours within the 0.1 outlier radius
+    const float cap2 = 0.0101f;  // eval only needs neighbours within the 0.1 outlier radius
     for (int slab = blockIdx.x * nw + wave; slab < n_slab; slab += gridDim.x * nw) {
         int pid = -1;
         float x = 0.f, y = 0.f, zz = 0.f, dt = 0.f;
@@ -335,14 +369,15 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
                                             zz <= box[5]);
         float best = -1.0f;
         int bi = INT_MAX;
-        if (__any(pid >= 0 && near_box))
-            knn_query(vs, cb, x, y, zz, (pid >= 0 && near_box) ? cap2 : -1.0f, best, bi);  // idle lanes open no cluster
-        bool append = false;
+        if (mode == 0) knn_unbounded(vs, cb, x, y, zz, pid >= 0, best, bi);
+        else if (__any(pid >= 0 && near_box))
+            knn_capped(vs, cb, x, y, zz, (pid >= 0 && near_box) ? cap2 : -1.0f, best, bi);  // idle lanes open no cluster
+        bool append = false, need_far = false, need = false, is_out = false;
         if (pid >= 0) {
             // outlier = sqrt(min(d2, 4)) > 0.1 (deformer.py:41-49)
-            const bool is_out = bi == INT_MAX || sqrtf(fminf(best, 4.0f)) > 0.1f;
+            is_out = bi == INT_MAX || sqrtf(fminf(best, 4.0f)) > 0.1f;
             if (outlier) outlier[pid] = is_out ? 1 : 0;
-            bool need = true;
+            need = true;
             if (mode != 0 && is_out) {
                 sdf_out[pid] = 4.0f;  // multiply.py:142-143
                 need = false;
@@ -350,9 +385,15 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
                     need = mp::alpha_of(4.0f, *beta_p, dt) != 0.0f;
                 }
             }
-            if (need && bi == INT_MAX) {  // rare: outlier that still has weight -> exact unbounded search
-                knn_query(vs, cb, x, y, zz, FLT_MAX, best, bi);
-            }
+            need_far = need && bi == INT_MAX;   // rare: outlier that still has weight -> exact unbounded search below
+        }
+        if (__any(need_far)) {
+            float b2; int i2;
+            knn_unbounded(vs, cb, x, y, zz, need_far, b2, i2);
+            if (need_far) { best = b2; bi = i2; }
+        }
+        if (pid >= 0) {
+            if (need_flag) need_flag[pid] = need ? 1 : 0;
             if (need) {
                 float T[12], s33, I[9];
                 blend_tf(skin_w, tl, bi, T, s33);
@@ -376,10 +417,13 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
     }
 }
 
+// Points are addressed like in k_warp_inverse (slab = 64 neighbouring hit rays x one sample index, so the 64 canonical
+// points of a wave are spatially coherent); only points whose `need` flag is set are processed.
+// Explicit-list variant (n_s == 0): point id = index, all `count` points processed.
 __global__ __launch_bounds__(WARP_THREADS) void k_warp_jacobian(const float* __restrict__ xc,
-                                                                const int* __restrict__ worklist,
-                                                                const int* __restrict__ count_p, int max_count,
-                                                                const float* __restrict__ vsorted_c,
+                                                                const unsigned char* __restrict__ need,
+                                                                const int* __restrict__ hit_count, int max_rays, int n_s,
+                                                                int n_pts, const float* __restrict__ vsorted_c,
                                                                 const float* __restrict__ cbound_c,
                                                                 const float* __restrict__ skin_w,
                                                                 const float* __restrict__ tfs, float* __restrict__ jinv) {
@@ -391,14 +435,23 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_jacobian(const float* __r
     for (int i = threadIdx.x; i < NJ * 16; i += blockDim.x) tl[i] = tfs[i];
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-    const int count = count_p ? min(*count_p, max_count) : max_count;
-    for (int slab = blockIdx.x * nw + wave; slab * 64 < count; slab += gridDim.x * nw) {
-        const int w = slab * 64 + lane;
-        const int id = w < count ? (worklist ? worklist[w] : w) : -1;
+    const bool rays = n_s > 0;
+    const int n_rays = rays ? min(*hit_count, max_rays) : 0;
+    const int n_slab = rays ? ((n_rays + 63) / 64) * n_s : (n_pts + 63) / 64;
+    for (int slab = blockIdx.x * nw + wave; slab < n_slab; slab += gridDim.x * nw) {
+        int id = -1;
+        if (rays) {
+            const int k = (slab / n_s) * 64 + lane, s = slab % n_s;
+            if (k < n_rays && need[(size_t)k * n_s + s]) id = k * n_s + s;
+        } else {
+            const int i = slab * 64 + lane;
+            if (i < n_pts) id = i;
+        }
+        if (!__any(id >= 0)) continue;
         float x = 0.f, y = 0.f, z = 0.f;
         if (id >= 0) { x = xc[3 * (size_t)id]; y = xc[3 * (size_t)id + 1]; z = xc[3 * (size_t)id + 2]; }
         float best; int bi;
-        knn_query(vs, cb, x, y, z, id >= 0 ? FLT_MAX : -1.0f, best, bi);
+        knn_unbounded(vs, cb, x, y, z, id >= 0, best, bi);
         if (id >= 0) {
             float T[12], s33, I[9];
             blend_tf(skin_w, tl, bi, T, s33);
@@ -682,8 +735,8 @@ extern "C" int mp_warp_inverse(const float* pts, const float* dirs, const float*
     const int n_slab = pts ? (max_rays + 63) / 64 : ((max_rays + 63) / 64) * n_s;
     hipLaunchKernelGGL(k_warp_inverse, dim3(warp_grid(n_slab, nw)), dim3(WARP_THREADS), WARP_LDS, st, pts, dirs, pose,
                        hit_index, hit_count, z, z_stride, n_s, max_rays, pts ? max_rays : 0, vsorted, cbound, skin_w, tfs,
-                       mode & 3, ray_active, (const float*)nullptr, launch_active, xc, outlier, sdf_out, worklist,
-                       work_count);
+                       mode & 3, ray_active, (const float*)nullptr, launch_active, xc, outlier, (unsigned char*)nullptr, sdf_out,
+                       worklist, work_count);
     return (int)hipGetLastError();
 }
 
@@ -691,8 +744,8 @@ extern "C" int mp_warp_inverse(const float* pts, const float* dirs, const float*
 extern "C" int mp_warp_inverse_shade(const float* dirs, const float* pose, const int* hit_index, const int* hit_count,
                                      const float* z, int z_stride, int n_s, int max_rays, const float* vsorted,
                                      const float* cbound, const float* skin_w, const float* tfs, int eval_mode,
-                                     const float* beta, float* xc, unsigned char* outlier, float* sdf_out,
-                                     int* worklist, int* work_count, void* stream) {
+                                     const float* beta, float* xc, unsigned char* outlier, unsigned char* need_flag,
+                                     float* sdf_out, int* worklist, int* work_count, void* stream) {
     if (max_rays <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     static int once = (int)hipFuncSetAttribute((const void*)k_warp_inverse, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -703,20 +756,21 @@ extern "C" int mp_warp_inverse_shade(const float* dirs, const float* pose, const
     hipLaunchKernelGGL(k_warp_inverse, dim3(warp_grid(n_slab, nw)), dim3(WARP_THREADS), WARP_LDS, st,
                        (const float*)nullptr, dirs, pose, hit_index, hit_count, z, z_stride, n_s, max_rays, 0, vsorted,
                        cbound, skin_w, tfs, eval_mode ? 2 : 0, (const int*)nullptr, beta, (const int*)nullptr, xc, outlier,
-                       sdf_out, worklist, work_count);
+                       need_flag, sdf_out, worklist, work_count);
     return (int)hipGetLastError();
 }
 
-extern "C" int mp_warp_jacobian(const float* xc, const int* worklist, const int* count, int max_count,
-                                const float* vsorted_c, const float* cbound_c, const float* skin_w, const float* tfs,
-                                float* jinv, void* stream) {
-    if (max_count <= 0) return 0;
+extern "C" int mp_warp_jacobian(const float* xc, const unsigned char* need, const int* hit_count, int max_rays, int n_s,
+                                int n_pts, const float* vsorted_c, const float* cbound_c, const float* skin_w,
+                                const float* tfs, float* jinv, void* stream) {
+    if ((n_s > 0 ? max_rays : n_pts) <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     static int once = (int)hipFuncSetAttribute((const void*)k_warp_jacobian, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                WARP_LDS);
     (void)once;
     const int nw = WARP_THREADS / 64;
-    hipLaunchKernelGGL(k_warp_jacobian, dim3(warp_grid((max_count + 63) / 64, nw)), dim3(WARP_THREADS), WARP_LDS, st, xc,
-                       worklist, count, max_count, vsorted_c, cbound_c, skin_w, tfs, jinv);
+    const int n_slab = n_s > 0 ? ((max_rays + 63) / 64) * n_s : (n_pts + 63) / 64;
+    hipLaunchKernelGGL(k_warp_jacobian, dim3(warp_grid(n_slab, nw)), dim3(WARP_THREADS), WARP_LDS, st, xc, need, hit_count,
+                       max_rays, n_s, n_pts, vsorted_c, cbound_c, skin_w, tfs, jinv);
     return (int)hipGetLastError();
 }

@@ -4,6 +4,8 @@
 //   mp_mlp_shade  foreground ImplicitNet in forward mode: sdf, d sdf/d x_c, features (multiply.py:643-661)
 //   mp_mlp_color  foreground RenderingNet 'pose_no_view' (networks.py:277-281)
 //   mp_background NeRF++ background branch (multiply.py:514-539, 682-726)
+// Geometry: plain kernels run 8 waves x (2 column blocks of 16 points) = 2 waves per SIMD; the forward-mode kernel needs
+// value and its three tangents in one wave: 8 waves x 8 points in a half-block layout, also 2 waves per SIMD.
 #include <hip/hip_runtime.h>
 #include "../../include/multiply_hip.h"
 #include "mlp_core.hpp"
@@ -17,14 +19,16 @@ static_assert(MP_BIAS_STRIDE == BIAS_STRIDE && MP_MAX_LAYERS == MAX_LAYERS && MP
 
 constexpr int BIAS_BYTES = MAX_LAYERS * BIAS_STRIDE * 4;
 
-template <int KS_IN>
+template <int KS_IN, int NB, int WAVES>
 struct Lds {
+    static constexpr int PTS = 16 * NB;          // staging rows (= columns) per wave
+    static constexpr int TILE = PTS * WAVES;     // columns per workgroup pass
     static constexpr int ring = 0;
-    static constexpr int bias0 = 2 * chunk_bytes(KS_IN);
+    static constexpr int bias0 = RING_SLOTS * chunk_bytes(KS_IN);
     static constexpr int bias1 = bias0 + BIAS_BYTES;
     static constexpr int stage = bias1 + BIAS_BYTES;
-    static constexpr int scratch = stage + 4 * 64 * in_stride(KS_IN) * 2;
-    static constexpr int total = scratch + 4 * 64 * 16;  // 4 floats per point per wave
+    static constexpr int scratch = stage + WAVES * PTS * in_stride(KS_IN) * 2;
+    static constexpr int total = scratch + WAVES * PTS * 16;  // 4 floats per column
 };
 
 // Fourier features of a D-vector into one staging row (bf16): [x, sin(2^0 x), cos(2^0 x), ...]  (embedders.py)
@@ -54,7 +58,7 @@ __device__ __forceinline__ void stage_pe(__bf16* row, const float (&x)[D]) {
 // d/dx_axis of the 3-D, L-octave Fourier features (tangent row for forward mode)
 template <int L, int KS_IN>
 __device__ __forceinline__ void stage_pe_tangent(__bf16* row, const float (&x)[3], int axis) {
-    constexpr int D = 3, NF = D + 2 * D * L;
+    constexpr int D = 3;
 #pragma unroll
     for (int f = 0; f < KS_IN * 32; ++f) row[f] = (__bf16)0.0f;
     float s, c;
@@ -71,17 +75,6 @@ __device__ __forceinline__ void stage_pe_tangent(__bf16* row, const float (&x)[3
         c = c2;
         f *= 2.0f;
     }
-    (void)NF;
-}
-
-template <int NB, int KS_IN>
-__device__ __forceinline__ void read_bin(const __bf16* stage_wave, bf16x8 (&Bin)[KS_IN][NB], int lane) {
-    const int j = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int ks = 0; ks < KS_IN; ++ks)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-            Bin[ks][nb] = *(const bf16x8*)(stage_wave + (nb * 16 + j) * in_stride(KS_IN) + ks * 32 + g * 8);
 }
 
 template <int NB>
@@ -93,30 +86,33 @@ __device__ __forceinline__ void zero_b(bf16x8 (&B)[KS_REG][NB]) {
 }
 
 // ------------------------------------------------------------------------------------------------ sdf only
-__global__ __launch_bounds__(256) void k_mlp_sdf(const NetDesc net, const char* __restrict__ wpack,
-                                                 const float* __restrict__ bias, const float* __restrict__ xc,
-                                                 const int* __restrict__ worklist, const int* __restrict__ count_p,
-                                                 int max_count, float* __restrict__ sdf_out) {
-    constexpr int KS_IN = 2, NB = 4;
-    using L = Lds<KS_IN>;
+template <int NB, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_mlp_sdf(const NetDesc net, const char* __restrict__ wpack,
+                                                        const float* __restrict__ bias, const float* __restrict__ xc,
+                                                        const int* __restrict__ worklist,
+                                                        const int* __restrict__ count_p, int max_count,
+                                                        float* __restrict__ sdf_out) {
+    constexpr int KS_IN = 2;
+    using L = Lds<KS_IN, NB, WAVES>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int count = count_p ? min(*count_p, max_count) : max_count;
     float* bias_lds = (float*)(smem + L::bias0);
-    __bf16* stage = (__bf16*)(smem + L::stage) + wave * 64 * in_stride(KS_IN);
+    __bf16* stage = (__bf16*)(smem + L::stage) + wave * L::PTS * in_stride(KS_IN);
     load_bias(net, bias, bias_lds);
-    for (int t = blockIdx.x; t * 256 < count; t += gridDim.x) {
-        const int w = t * 256 + wave * 64 + lane;
-        const int id = w < count ? (worklist ? worklist[w] : w) : -1;
-        float x[3] = {0.f, 0.f, 0.f};
-        if (id >= 0) { x[0] = xc[3 * (size_t)id]; x[1] = xc[3 * (size_t)id + 1]; x[2] = xc[3 * (size_t)id + 2]; }
-        stage_pe<3, 6, KS_IN>(stage + lane * in_stride(KS_IN), x);
+    for (int t = blockIdx.x; t * L::TILE < count; t += gridDim.x) {
+        const int w = t * L::TILE + wave * L::PTS + lane;
+        const int id = (lane < L::PTS && w < count) ? (worklist ? worklist[w] : w) : -1;
+        if (lane < L::PTS) {
+            float x[3] = {0.f, 0.f, 0.f};
+            if (id >= 0) { x[0] = xc[3 * (size_t)id]; x[1] = xc[3 * (size_t)id + 1]; x[2] = xc[3 * (size_t)id + 2]; }
+            stage_pe<3, 6, KS_IN>(stage + lane * in_stride(KS_IN), x);
+        }
         bf16x8 Bcur[KS_REG][NB];
         f32x4 out[NB];
         zero_b<NB>(Bcur);
-        __syncthreads();  // staging rows are written by other lanes
-        prologue<KS_IN>(net, wpack, smem + L::ring, wave, lane);
-        run_net<NB, false, KS_IN, HID_SOFTPLUS>(net, wpack, bias_lds, smem + L::ring, Bcur, stage, out, wave, lane);
+        prologue<KS_IN, WAVES>(net, wpack, smem + L::ring, wave, lane);  // barrier inside: staging rows visible
+        run_net<NB, false, KS_IN, HID_SOFTPLUS, WAVES>(net, wpack, bias_lds, smem + L::ring, Bcur, stage, out, wave, lane);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int pid = __shfl(id, nb * 16 + (lane & 15));
@@ -126,30 +122,30 @@ __global__ __launch_bounds__(256) void k_mlp_sdf(const NetDesc net, const char* 
 }
 
 // ------------------------------------------------------------------------------------------------ all outputs
-template <int D_IN, int LFREQ, int KS_IN>
-__global__ __launch_bounds__(256) void k_mlp_full(const NetDesc net, const char* __restrict__ wpack,
-                                                  const float* __restrict__ bias, const float* __restrict__ x, int n,
-                                                  float* __restrict__ outp) {
-    constexpr int NB = 4;
-    using L = Lds<KS_IN>;
+template <int D_IN, int LFREQ, int KS_IN, int NB, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_mlp_full(const NetDesc net, const char* __restrict__ wpack,
+                                                         const float* __restrict__ bias, const float* __restrict__ x,
+                                                         int n, float* __restrict__ outp) {
+    using L = Lds<KS_IN, NB, WAVES>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* bias_lds = (float*)(smem + L::bias0);
-    __bf16* stage = (__bf16*)(smem + L::stage) + wave * 64 * in_stride(KS_IN);
+    __bf16* stage = (__bf16*)(smem + L::stage) + wave * L::PTS * in_stride(KS_IN);
     load_bias(net, bias, bias_lds);
-    for (int t = blockIdx.x; t * 256 < n; t += gridDim.x) {
-        const int id0 = t * 256 + wave * 64;
-        const int id = id0 + lane < n ? id0 + lane : -1;
-        float xi[D_IN];
+    for (int t = blockIdx.x; t * L::TILE < n; t += gridDim.x) {
+        const int id0 = t * L::TILE + wave * L::PTS;
+        if (lane < L::PTS) {
+            const int id = id0 + lane < n ? id0 + lane : -1;
+            float xi[D_IN];
 #pragma unroll
-        for (int a = 0; a < D_IN; ++a) xi[a] = id >= 0 ? x[(size_t)id * D_IN + a] : 0.f;
-        stage_pe<D_IN, LFREQ, KS_IN>(stage + lane * in_stride(KS_IN), xi);
+            for (int a = 0; a < D_IN; ++a) xi[a] = id >= 0 ? x[(size_t)id * D_IN + a] : 0.f;
+            stage_pe<D_IN, LFREQ, KS_IN>(stage + lane * in_stride(KS_IN), xi);
+        }
         bf16x8 Bcur[KS_REG][NB];
         f32x4 out[NB];
         zero_b<NB>(Bcur);
-        __syncthreads();  // staging rows are written by other lanes
-        prologue<KS_IN>(net, wpack, smem + L::ring, wave, lane);
-        run_net<NB, false, KS_IN, HID_SOFTPLUS>(net, wpack, bias_lds, smem + L::ring, Bcur, stage, out, wave, lane);
+        prologue<KS_IN, WAVES>(net, wpack, smem + L::ring, wave, lane);
+        run_net<NB, false, KS_IN, HID_SOFTPLUS, WAVES>(net, wpack, bias_lds, smem + L::ring, Bcur, stage, out, wave, lane);
         const int j = lane & 15, g = lane >> 4;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -168,41 +164,51 @@ __global__ __launch_bounds__(256) void k_mlp_full(const NetDesc net, const char*
 }
 
 // ------------------------------------------------------------------------------------------------ shading: fwd mode
-__global__ __launch_bounds__(256) void k_mlp_shade(const NetDesc net, const char* __restrict__ wpack,
+// 8 waves (2 per SIMD), each 8 points in the half-block tangent layout of mlp_core.hpp:
+//   block 0 = [values of points 0..7 | d/dx], block 1 = [d/dy | d/dz].
+// Feature fragments are written for tiles of 64 work items in the colour kernel's 16-column block layout:
+//   feat_frag[tile][ks][block = wave/2][lane' = (col + 8*(wave&1)) + 16 g][8 bf16]
+__global__ __launch_bounds__(512) void k_mlp_shade(const NetDesc net, const char* __restrict__ wpack,
                                                    const float* __restrict__ bias, const float* __restrict__ xc,
                                                    const float* __restrict__ jinv, const int* __restrict__ worklist,
                                                    const int* __restrict__ count_p, int max_count,
                                                    float* __restrict__ sdf_out, float* __restrict__ normal_out,
                                                    char* __restrict__ feat_frag) {
-    constexpr int KS_IN = 2, NB = 4;
-    using L = Lds<KS_IN>;
+    constexpr int KS_IN = 2, NB = 2, WAVES = 8;
+    using L = Lds<KS_IN, NB, WAVES>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int j = lane & 15, role = lane >> 4;
     const int count = count_p ? min(*count_p, max_count) : max_count;
     float* bias_lds = (float*)(smem + L::bias0);
-    __bf16* stage = (__bf16*)(smem + L::stage) + wave * 64 * in_stride(KS_IN);
+    __bf16* stage = (__bf16*)(smem + L::stage) + wave * L::PTS * in_stride(KS_IN);
     load_bias(net, bias, bias_lds);
     for (int t = blockIdx.x; t * 64 < count; t += gridDim.x) {
-        const int w = t * 64 + wave * 16 + j;
-        const int id = w < count ? (worklist ? worklist[w] : w) : -1;
-        float x[3] = {0.f, 0.f, 0.f};
-        if (id >= 0) { x[0] = xc[3 * (size_t)id]; x[1] = xc[3 * (size_t)id + 1]; x[2] = xc[3 * (size_t)id + 2]; }
-        __bf16* row = stage + (role * 16 + j) * in_stride(KS_IN);
-        if (role == 0) stage_pe<3, 6, KS_IN>(row, x);
-        else stage_pe_tangent<6, KS_IN>(row, x, role - 1);
+        // staging: lane l < 32 builds column l: block l>>4, column l&15 -> point (l&7), role 2*(l>>4) + ((l>>3)&1)
+        const int pt = lane & 7, role = 2 * ((lane >> 4) & 1) + ((lane >> 3) & 1);
+        const int w = t * 64 + wave * 8 + pt;
+        const int id = w < count ? (worklist ? worklist[w] : w) : -1;   // every lane knows the id of point lane&7
+        if (lane < 32) {
+            float x[3] = {0.f, 0.f, 0.f};
+            if (id >= 0) { x[0] = xc[3 * (size_t)id]; x[1] = xc[3 * (size_t)id + 1]; x[2] = xc[3 * (size_t)id + 2]; }
+            __bf16* row = stage + lane * in_stride(KS_IN);
+            if (role == 0) stage_pe<3, 6, KS_IN>(row, x);
+            else stage_pe_tangent<6, KS_IN>(row, x, role - 1);
+        }
         bf16x8 Bcur[KS_REG][NB];
         f32x4 out[NB];
         zero_b<NB>(Bcur);
-        __syncthreads();  // staging rows are written by other lanes
-        prologue<KS_IN>(net, wpack, smem + L::ring, wave, lane);
-        run_net<NB, true, KS_IN, HID_SOFTPLUS>(net, wpack, bias_lds, smem + L::ring, Bcur, stage, out, wave, lane);
-        // features of block 0 -> B fragments of the colour kernel's tile t, column block `wave`
+        prologue<KS_IN, WAVES>(net, wpack, smem + L::ring, wave, lane);
+        run_net<NB, true, KS_IN, HID_SOFTPLUS, WAVES>(net, wpack, bias_lds, smem + L::ring, Bcur, stage, out, wave, lane);
+        if ((lane & 8) == 0) {   // value columns: features of point lane&7
+            const int lp = ((lane & 15) + 8 * (wave & 1)) + 16 * (lane >> 4);
 #pragma unroll
-        for (int ks = 0; ks < KS_REG; ++ks)
-            *(bf16x8*)(feat_frag + (((size_t)t * KS_REG + ks) * 4 + wave) * 1024 + lane * 16) = Bcur[ks][0];
-        if (role == 0 && id >= 0) {
-            const float gx = out[1][0], gy = out[2][0], gz = out[3][0];
+            for (int ks = 0; ks < KS_REG; ++ks)
+                *(bf16x8*)(feat_frag + (((size_t)t * KS_REG + ks) * 4 + (wave >> 1)) * 1024 + lp * 16) = Bcur[ks][0];
+        }
+        // row 0 of the last layer: lanes 0..7 hold sdf (block 0) and d/dy (block 1), lanes 8..15 d/dx and d/dz
+        const float gx = __shfl(out[0][0], (lane & 7) + 8), gz = __shfl(out[1][0], (lane & 7) + 8);
+        if (lane < 8 && id >= 0) {
+            const float gy = out[1][0];
             const float* Ji = jinv + 9 * (size_t)id;
             float n0 = gx * Ji[0] + gy * Ji[3] + gz * Ji[6];
             float n1 = gx * Ji[1] + gy * Ji[4] + gz * Ji[7];
@@ -219,46 +225,51 @@ __global__ __launch_bounds__(256) void k_mlp_shade(const NetDesc net, const char
 }
 
 // ------------------------------------------------------------------------------------------------ colour
-__global__ __launch_bounds__(256) void k_mlp_color(const NetDesc net, const char* __restrict__ wpack,
-                                                   const float* __restrict__ bias, const float* __restrict__ xc,
-                                                   const float* __restrict__ normal, const char* __restrict__ feat_frag,
-                                                   const int* __restrict__ worklist, const int* __restrict__ count_p,
-                                                   int max_count, float* __restrict__ rgb_out) {
-    constexpr int KS_IN = 2, NB = 4;
-    using L = Lds<KS_IN>;
+template <int NB, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_mlp_color(const NetDesc net, const char* __restrict__ wpack,
+                                                          const float* __restrict__ bias, const float* __restrict__ xc,
+                                                          const float* __restrict__ normal,
+                                                          const char* __restrict__ feat_frag,
+                                                          const int* __restrict__ worklist,
+                                                          const int* __restrict__ count_p, int max_count,
+                                                          float* __restrict__ rgb_out) {
+    constexpr int KS_IN = 2;
+    using L = Lds<KS_IN, NB, WAVES>;
+    static_assert(64 % L::PTS == 0, "a wave consumes a whole number of column blocks of one 64-item shade tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int count = count_p ? min(*count_p, max_count) : max_count;
     float* bias_lds = (float*)(smem + L::bias0);
-    __bf16* stage = (__bf16*)(smem + L::stage) + wave * 64 * in_stride(KS_IN);
+    __bf16* stage = (__bf16*)(smem + L::stage) + wave * L::PTS * in_stride(KS_IN);
     load_bias(net, bias, bias_lds);
-    // shade tiles hold 64 work items; this kernel's wave `wave` of block-tile T consumes shade tile 4T+wave
-    for (int t = blockIdx.x; t * 256 < count; t += gridDim.x) {
-        const int tile = t * 4 + wave;
-        const int w = tile * 64 + lane;
-        const int id = w < count ? (worklist ? worklist[w] : w) : -1;
-        __bf16* row = stage + lane * in_stride(KS_IN);
+    for (int t = blockIdx.x; t * L::TILE < count; t += gridDim.x) {
+        const int w0 = t * L::TILE + wave * L::PTS;   // first work item of this wave
+        const int tile = w0 / 64, nb0 = (w0 % 64) / 16;
+        const int w = w0 + lane;
+        const int id = (lane < L::PTS && w < count) ? (worklist ? worklist[w] : w) : -1;
+        if (lane < L::PTS) {
+            __bf16* row = stage + lane * in_stride(KS_IN);
 #pragma unroll
-        for (int f = 0; f < KS_IN * 32; ++f) row[f] = (__bf16)0.0f;
-        if (id >= 0) {
+            for (int f = 0; f < KS_IN * 32; ++f) row[f] = (__bf16)0.0f;
+            if (id >= 0) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                row[a] = (__bf16)xc[3 * (size_t)id + a];
-                row[3 + a] = (__bf16)normal[3 * (size_t)id + a];
+                for (int a = 0; a < 3; ++a) {
+                    row[a] = (__bf16)xc[3 * (size_t)id + a];
+                    row[3 + a] = (__bf16)normal[3 * (size_t)id + a];
+                }
             }
         }
         bf16x8 Bcur[KS_REG][NB];
         f32x4 out[NB];
-        const bool live = tile * 64 < count;
+        const bool live = w0 < count;
 #pragma unroll
         for (int ks = 0; ks < KS_REG; ++ks)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
-                Bcur[ks][nb] = live ? *(const bf16x8*)(feat_frag + (((size_t)tile * KS_REG + ks) * 4 + nb) * 1024 + lane * 16)
+                Bcur[ks][nb] = live ? *(const bf16x8*)(feat_frag + (((size_t)tile * KS_REG + ks) * 4 + nb0 + nb) * 1024 + lane * 16)
                                     : (bf16x8)(__bf16)0.0f;
-        __syncthreads();
-        prologue<KS_IN>(net, wpack, smem + L::ring, wave, lane);
-        run_net<NB, false, KS_IN, HID_RELU>(net, wpack, bias_lds, smem + L::ring, Bcur, stage, out, wave, lane);
+        prologue<KS_IN, WAVES>(net, wpack, smem + L::ring, wave, lane);
+        run_net<NB, false, KS_IN, HID_RELU, WAVES>(net, wpack, bias_lds, smem + L::ring, Bcur, stage, out, wave, lane);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int pid = __shfl(id, nb * 16 + (lane & 15));
@@ -271,71 +282,75 @@ __global__ __launch_bounds__(256) void k_mlp_color(const NetDesc net, const char
 }
 
 // ------------------------------------------------------------------------------------------------ background
-// One wave = 64 samples = 64/n_bg rays (n_bg = 32: two rays).  multiply.py:698-726 for the points.
-__global__ __launch_bounds__(256) void k_background(const NetDesc net_imp, const char* __restrict__ wp_imp,
-                                                    const float* __restrict__ bias_imp,
-                                                    const NetDesc net_ren, const char* __restrict__ wp_ren,
-                                                    const float* __restrict__ bias_ren, const float* __restrict__ dirs,
-                                                    const float* __restrict__ cam, const float* __restrict__ z_bg,
-                                                    int z_per_ray, int n_rays, float radius, float* __restrict__ bg_rgb) {
-    constexpr int KS_IN = 3, NB = 4, NBG = 32;
-    using L = Lds<KS_IN>;
+// A wave owns 16*NB consecutive samples; with NB = 2 and 32 samples per ray that is exactly one ray.
+template <int NB, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_background(const NetDesc net_imp, const char* __restrict__ wp_imp,
+                                                           const float* __restrict__ bias_imp, const NetDesc net_ren,
+                                                           const char* __restrict__ wp_ren,
+                                                           const float* __restrict__ bias_ren,
+                                                           const float* __restrict__ dirs, const float* __restrict__ cam,
+                                                           const float* __restrict__ z_bg, int z_per_ray, int n_rays,
+                                                           float radius, float* __restrict__ bg_rgb) {
+    constexpr int KS_IN = 3, NBG = 32;
+    using L = Lds<KS_IN, NB, WAVES>;
+    static_assert(L::PTS % NBG == 0, "whole rays per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* bias_lds0 = (float*)(smem + L::bias0);
     float* bias_lds1 = (float*)(smem + L::bias1);
-    __bf16* stage = (__bf16*)(smem + L::stage) + wave * 64 * in_stride(KS_IN);
-    float* scr = (float*)(smem + L::scratch) + wave * 64 * 4;
+    __bf16* stage = (__bf16*)(smem + L::stage) + wave * L::PTS * in_stride(KS_IN);
+    float* scr = (float*)(smem + L::scratch) + wave * L::PTS * 4;
     load_bias(net_imp, bias_imp, bias_lds0);
     load_bias(net_ren, bias_ren, bias_lds1);
     const int n_pts = n_rays * NBG;
     const float ox = cam[0], oy = cam[1], oz = cam[2];
-    for (int t = blockIdx.x; t * 256 < n_pts; t += gridDim.x) {
-        const int q = t * 256 + wave * 64 + lane;
+    for (int t = blockIdx.x; t * L::TILE < n_pts; t += gridDim.x) {
+        const int q = t * L::TILE + wave * L::PTS + lane;
         const int ray = q / NBG, s = q % NBG;
-        const bool ok = ray < n_rays;
         float d[3] = {0.f, 0.f, 1.f};
-        float depth = 0.1f;
-        if (ok) {
-            d[0] = dirs[3 * ray]; d[1] = dirs[3 * ray + 1]; d[2] = dirs[3 * ray + 2];
-            depth = z_per_ray ? z_bg[(size_t)ray * NBG + s] : z_bg[s];
-        }
-        // depth2pts_outside
-        const float o_dot_d = d[0] * ox + d[1] * oy + d[2] * oz;
-        const float under = o_dot_d * o_dot_d - ((ox * ox + oy * oy + oz * oz) - radius * radius);
-        const float d_sphere = sqrtf(under) - o_dot_d;
-        const float ps[3] = {ox + d_sphere * d[0], oy + d_sphere * d[1], oz + d_sphere * d[2]};
-        const float pm[3] = {ox - o_dot_d * d[0], oy - o_dot_d * d[1], oz - o_dot_d * d[2]};
-        const float pm_n = sqrtf(pm[0] * pm[0] + pm[1] * pm[1] + pm[2] * pm[2]);
-        float ax[3] = {oy * ps[2] - oz * ps[1], oz * ps[0] - ox * ps[2], ox * ps[1] - oy * ps[0]};
-        const float an = sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
-        ax[0] /= an; ax[1] /= an; ax[2] /= an;
-        const float phi = asinf(pm_n / radius), theta = asinf(pm_n * depth);
-        float sa, ca;
-        sincosf(phi - theta, &sa, &ca);
-        const float cr[3] = {ax[1] * ps[2] - ax[2] * ps[1], ax[2] * ps[0] - ax[0] * ps[2], ax[0] * ps[1] - ax[1] * ps[0]};
-        const float adp = ax[0] * ps[0] + ax[1] * ps[1] + ax[2] * ps[2];
-        float pn[3];
+        if (lane < L::PTS) {
+            const bool ok = ray < n_rays;
+            float depth = 0.1f;
+            if (ok) {
+                d[0] = dirs[3 * ray]; d[1] = dirs[3 * ray + 1]; d[2] = dirs[3 * ray + 2];
+                depth = z_per_ray ? z_bg[(size_t)ray * NBG + s] : z_bg[s];
+            }
+            // depth2pts_outside (multiply.py:698-726)
+            const float o_dot_d = d[0] * ox + d[1] * oy + d[2] * oz;
+            const float under = o_dot_d * o_dot_d - ((ox * ox + oy * oy + oz * oz) - radius * radius);
+            const float d_sphere = sqrtf(under) - o_dot_d;
+            const float ps[3] = {ox + d_sphere * d[0], oy + d_sphere * d[1], oz + d_sphere * d[2]};
+            const float pm[3] = {ox - o_dot_d * d[0], oy - o_dot_d * d[1], oz - o_dot_d * d[2]};
+            const float pm_n = sqrtf(pm[0] * pm[0] + pm[1] * pm[1] + pm[2] * pm[2]);
+            float ax[3] = {oy * ps[2] - oz * ps[1], oz * ps[0] - ox * ps[2], ox * ps[1] - oy * ps[0]};
+            const float an = sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+            ax[0] /= an; ax[1] /= an; ax[2] /= an;
+            const float phi = asinf(pm_n / radius), theta = asinf(pm_n * depth);
+            float sa, ca;
+            sincosf(phi - theta, &sa, &ca);
+            const float cr[3] = {ax[1] * ps[2] - ax[2] * ps[1], ax[2] * ps[0] - ax[0] * ps[2], ax[0] * ps[1] - ax[1] * ps[0]};
+            const float adp = ax[0] * ps[0] + ax[1] * ps[1] + ax[2] * ps[2];
+            float pn[3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) pn[a] = ps[a] * ca + cr[a] * sa + ax[a] * adp * (1.0f - ca);
-        const float pnn = sqrtf(pn[0] * pn[0] + pn[1] * pn[1] + pn[2] * pn[2]);
-        const float x4[4] = {pn[0] / pnn, pn[1] / pnn, pn[2] / pnn, depth};
-        stage_pe<4, 10, KS_IN>(stage + lane * in_stride(KS_IN), x4);
+            for (int a = 0; a < 3; ++a) pn[a] = ps[a] * ca + cr[a] * sa + ax[a] * adp * (1.0f - ca);
+            const float pnn = sqrtf(pn[0] * pn[0] + pn[1] * pn[1] + pn[2] * pn[2]);
+            const float x4[4] = {pn[0] / pnn, pn[1] / pnn, pn[2] / pnn, depth};
+            stage_pe<4, 10, KS_IN>(stage + lane * in_stride(KS_IN), x4);
+        }
         bf16x8 Bcur[KS_REG][NB];
         f32x4 out[NB];
         zero_b<NB>(Bcur);
-        __syncthreads();  // staging rows are written by other lanes
-        prologue<KS_IN>(net_imp, wp_imp, smem + L::ring, wave, lane);
-        run_net<NB, false, KS_IN, HID_SOFTPLUS>(net_imp, wp_imp, bias_lds0, smem + L::ring, Bcur, stage, out, wave, lane);
+        prologue<KS_IN, WAVES>(net_imp, wp_imp, smem + L::ring, wave, lane);
+        run_net<NB, false, KS_IN, HID_SOFTPLUS, WAVES>(net_imp, wp_imp, bias_lds0, smem + L::ring, Bcur, stage, out, wave,
+                                                       lane);
         if (lane < 16) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) scr[(nb * 16 + lane) * 4 + 3] = fabsf(out[nb][0]);  // AbsDensity (density.py:32-34)
         }
         // colour net: [PE_4(view dir) (27), frame code (hoisted), features (registers)]
-        stage_pe<3, 4, KS_IN>(stage + lane * in_stride(KS_IN), d);
-        __syncthreads();
-        prologue<KS_IN>(net_ren, wp_ren, smem + L::ring, wave, lane);
-        run_net<NB, false, KS_IN, HID_RELU>(net_ren, wp_ren, bias_lds1, smem + L::ring, Bcur, stage, out, wave, lane);
+        if (lane < L::PTS) stage_pe<3, 4, KS_IN>(stage + lane * in_stride(KS_IN), d);
+        prologue<KS_IN, WAVES>(net_ren, wp_ren, smem + L::ring, wave, lane);
+        run_net<NB, false, KS_IN, HID_RELU, WAVES>(net_ren, wp_ren, bias_lds1, smem + L::ring, Bcur, stage, out, wave, lane);
         if (lane < 16) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
@@ -343,11 +358,11 @@ __global__ __launch_bounds__(256) void k_background(const NetDesc net_imp, const
                 for (int c = 0; c < 3; ++c) scr[(nb * 16 + lane) * 4 + c] = 1.0f / (1.0f + __expf(-out[nb][c]));
         }
         __syncthreads();
-        // bg_volume_rendering (multiply.py:682-696): lanes 0..(64/NBG-1) composite one ray each
-        if (lane < 64 / NBG) {
-            const int r = (t * 256 + wave * 64) / NBG + lane;
+        // bg_volume_rendering (multiply.py:682-696): the first lanes composite one ray each
+        if (lane < L::PTS / NBG) {
+            const int r = (t * L::TILE + wave * L::PTS) / NBG + lane;
             if (r < n_rays) {
-                float T = 1.0f, acc[3] = {0.f, 0.f, 0.f}, csum = 0.0f;
+                float acc[3] = {0.f, 0.f, 0.f}, csum = 0.0f;
                 for (int i = 0; i < NBG; ++i) {
                     const float zi = z_per_ray ? z_bg[(size_t)r * NBG + i] : z_bg[i];
                     const float zn = i + 1 < NBG ? (z_per_ray ? z_bg[(size_t)r * NBG + i + 1] : z_bg[i + 1]) : 0.f;
@@ -355,8 +370,7 @@ __global__ __launch_bounds__(256) void k_background(const NetDesc net_imp, const
                     const float* sp = scr + (lane * NBG + i) * 4;
                     const float fe = dist * sp[3];
                     const float alpha = 1.0f - expf(-fe);
-                    T = expf(-csum);
-                    const float wgt = alpha * T;
+                    const float wgt = alpha * expf(-csum);
                     acc[0] += wgt * sp[0]; acc[1] += wgt * sp[1]; acc[2] += wgt * sp[2];
                     csum += fe;
                 }
@@ -371,10 +385,10 @@ int set_lds(K kernel, int bytes) {
     return (int)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-int grid_for(int work_blocks) {
-    // persistent grid: one 256-thread block per CU (register budget allows exactly one), grid-stride over tiles
-    const int cus = 256;
-    return work_blocks < cus ? (work_blocks > 0 ? work_blocks : 1) : cus;
+// persistent grid: `per_cu` workgroups per CU, grid-stride over tiles
+int grid_for(int work_blocks, int per_cu) {
+    const int cap = 256 * per_cu;
+    return work_blocks < cap ? (work_blocks > 0 ? work_blocks : 1) : cap;
 }
 
 NetDesc as_desc(const MpNet* net) {
@@ -383,17 +397,21 @@ NetDesc as_desc(const MpNet* net) {
     return d;
 }
 
+constexpr int PNB = 2, PWAVES = 8;   // plain-mode geometry
+
 }  // namespace
 
 extern "C" int mp_mlp_sdf(const MpNet* net, const void* wpack, const float* bias, const float* xc,
                           const int* worklist, const int* count, int max_count, float* sdf_out, void* stream) {
     if (max_count <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    static int once = set_lds(k_mlp_sdf, Lds<2>::total);
+    using L = Lds<2, PNB, PWAVES>;
+    static int once = set_lds(k_mlp_sdf<PNB, PWAVES>, L::total);
     (void)once;
     const NetDesc d = as_desc(net);
-    hipLaunchKernelGGL(k_mlp_sdf, dim3(grid_for((max_count + 255) / 256)), dim3(256), Lds<2>::total, st, d,
-                       (const char*)wpack, bias, xc, worklist, count, max_count, sdf_out);
+    hipLaunchKernelGGL((k_mlp_sdf<PNB, PWAVES>), dim3(grid_for((max_count + L::TILE - 1) / L::TILE, 1)),
+                       dim3(PWAVES * 64), L::total, st, d, (const char*)wpack, bias, xc, worklist, count, max_count,
+                       sdf_out);
     return (int)hipGetLastError();
 }
 
@@ -402,17 +420,18 @@ extern "C" int mp_mlp_full(const MpNet* net, const void* wpack, const float* bia
     if (n <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const NetDesc d = as_desc(net);
-    const int grid = grid_for((n + 255) / 256);
     if (d_in == 3) {
-        static int once = set_lds(k_mlp_full<3, 6, 2>, Lds<2>::total);
+        using L = Lds<2, PNB, PWAVES>;
+        static int once = set_lds(k_mlp_full<3, 6, 2, PNB, PWAVES>, L::total);
         (void)once;
-        hipLaunchKernelGGL((k_mlp_full<3, 6, 2>), dim3(grid), dim3(256), Lds<2>::total, st, d, (const char*)wpack, bias, x,
-                           n, out);
+        hipLaunchKernelGGL((k_mlp_full<3, 6, 2, PNB, PWAVES>), dim3(grid_for((n + L::TILE - 1) / L::TILE, 1)),
+                           dim3(PWAVES * 64), L::total, st, d, (const char*)wpack, bias, x, n, out);
     } else if (d_in == 4) {
-        static int once = set_lds(k_mlp_full<4, 10, 3>, Lds<3>::total);
+        using L = Lds<3, PNB, PWAVES>;
+        static int once = set_lds(k_mlp_full<4, 10, 3, PNB, PWAVES>, L::total);
         (void)once;
-        hipLaunchKernelGGL((k_mlp_full<4, 10, 3>), dim3(grid), dim3(256), Lds<3>::total, st, d, (const char*)wpack, bias,
-                           x, n, out);
+        hipLaunchKernelGGL((k_mlp_full<4, 10, 3, PNB, PWAVES>), dim3(grid_for((n + L::TILE - 1) / L::TILE, 1)),
+                           dim3(PWAVES * 64), L::total, st, d, (const char*)wpack, bias, x, n, out);
     } else {
         return -1;
     }
@@ -424,10 +443,11 @@ extern "C" int mp_mlp_shade(const MpNet* net, const void* wpack, const float* bi
                             float* normal_out, void* feat_frag, void* stream) {
     if (max_count <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    static int once = set_lds(k_mlp_shade, Lds<2>::total);
+    using L = Lds<2, 2, 8>;
+    static int once = set_lds(k_mlp_shade, L::total);
     (void)once;
     const NetDesc d = as_desc(net);
-    hipLaunchKernelGGL(k_mlp_shade, dim3(grid_for((max_count + 63) / 64)), dim3(256), Lds<2>::total, st, d,
+    hipLaunchKernelGGL(k_mlp_shade, dim3(grid_for((max_count + 63) / 64, 1)), dim3(512), L::total, st, d,
                        (const char*)wpack, bias, xc, jinv, worklist, count, max_count, sdf_out, normal_out,
                        (char*)feat_frag);
     return (int)hipGetLastError();
@@ -438,11 +458,13 @@ extern "C" int mp_mlp_color(const MpNet* net, const void* wpack, const float* bi
                             int max_count, float* rgb_out, void* stream) {
     if (max_count <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    static int once = set_lds(k_mlp_color, Lds<2>::total);
+    using L = Lds<2, PNB, PWAVES>;
+    static int once = set_lds(k_mlp_color<PNB, PWAVES>, L::total);
     (void)once;
     const NetDesc d = as_desc(net);
-    hipLaunchKernelGGL(k_mlp_color, dim3(grid_for((max_count + 255) / 256)), dim3(256), Lds<2>::total, st, d,
-                       (const char*)wpack, bias, xc, normal, (const char*)feat_frag, worklist, count, max_count, rgb_out);
+    hipLaunchKernelGGL((k_mlp_color<PNB, PWAVES>), dim3(grid_for((max_count + L::TILE - 1) / L::TILE, 1)),
+                       dim3(PWAVES * 64), L::total, st, d, (const char*)wpack, bias, xc, normal, (const char*)feat_frag,
+                       worklist, count, max_count, rgb_out);
     return (int)hipGetLastError();
 }
 
@@ -451,11 +473,12 @@ extern "C" int mp_background(const MpNet* net_imp, const void* wpack_imp, const 
                              const float* z_bg, int z_per_ray, int n_rays, float radius, float* bg_rgb, void* stream) {
     if (n_rays <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    static int once = set_lds(k_background, Lds<3>::total);
+    using L = Lds<3, PNB, PWAVES>;
+    static int once = set_lds(k_background<PNB, PWAVES>, L::total);
     (void)once;
     const NetDesc d0 = as_desc(net_imp), d1 = as_desc(net_ren);
-    hipLaunchKernelGGL(k_background, dim3(grid_for((n_rays * 32 + 255) / 256)), dim3(256), Lds<3>::total, st, d0,
-                       (const char*)wpack_imp, bias_imp, d1, (const char*)wpack_ren, bias_ren, dirs, cam, z_bg, z_per_ray,
-                       n_rays, radius, bg_rgb);
+    hipLaunchKernelGGL((k_background<PNB, PWAVES>), dim3(grid_for((n_rays * 32 + L::TILE - 1) / L::TILE, 1)),
+                       dim3(PWAVES * 64), L::total, st, d0, (const char*)wpack_imp, bias_imp, d1, (const char*)wpack_ren,
+                       bias_ren, dirs, cam, z_bg, z_per_ray, n_rays, radius, bg_rgb);
     return (int)hipGetLastError();
 }

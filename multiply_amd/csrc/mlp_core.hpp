@@ -18,7 +18,8 @@
 // (see pack_weights.py / mp_pack_weights), so that bf16(act(D)) of output blocks
 // (2ks, 2ks+1) IS the B fragment of K step ks: no LDS round trip, no cross-lane moves.
 //
-// A wave owns NB column blocks of 16 columns.  Plain mode: 16*NB different points.
+// A wave owns NB column blocks of 16 columns.  Plain mode: 16*NB different points (NB = 2 with 8 waves per workgroup
+// = 2 waves per SIMD, so that one wave's activation VALU work overlaps the other wave's MFMAs).
 // Forward-mode (FWD, NB=4): block 0 = values of 16 points, blocks 1..3 = d/dx, d/dy,
 // d/dz tangents of the same 16 points, so sdf and its spatial gradient (the normals of
 // multiply.py:620-661) come out of one pass: t' = softplus'(z) * (W t).
@@ -40,6 +41,7 @@ constexpr int MAX_LAYERS = 10;
 constexpr int BIAS_STRIDE = MAX_CHUNKS * 32;      // 288 floats per layer
 __host__ __device__ constexpr int mb_bytes(int ks_in) { return (KS_REG + ks_in) * TILE_BYTES; }  // all K steps of 16 rows
 __host__ __device__ constexpr int chunk_bytes(int ks_in) { return CHUNK_MB * mb_bytes(ks_in); }  // 20 / 22 KiB
+constexpr int RING_SLOTS = 3;   // weight chunks are loaded two chunks ahead of their use
 __host__ __device__ constexpr int in_stride(int ks_in) { return ks_in * 32 + 8; }  // bf16 per staging row (+pad)
 
 enum Act : int { ACT_NONE = 0, ACT_SOFTPLUS = 1, ACT_RELU = 2 };
@@ -88,15 +90,15 @@ __device__ __forceinline__ void softplus100_vg(float z, float& h, float& s) {
     s = z >= 0.0f ? r : u * r;
 }
 
-template <int KS_IN>
+template <int KS_IN, int WAVES>
 __device__ __forceinline__ void issue_chunk(const char* __restrict__ wpack, char* wring, int ci, int wave, int lane) {
     constexpr int CB = chunk_bytes(KS_IN);
-    constexpr int NP = CB / TILE_BYTES;   // 1 KiB pieces, dealt round-robin to the 4 waves
+    constexpr int NP = CB / TILE_BYTES;   // 1 KiB pieces, dealt round-robin to the workgroup's waves
     const char* src = wpack + (size_t)ci * CB;
-    char* dst = wring + (ci & 1) * CB;
+    char* dst = wring + (ci % RING_SLOTS) * CB;
 #pragma unroll
-    for (int i = 0; i < (NP + 3) / 4; ++i) {
-        const int piece = wave + 4 * i;
+    for (int i = 0; i < (NP + WAVES - 1) / WAVES; ++i) {
+        const int piece = wave + WAVES * i;
         if (piece < NP)
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(src + piece * TILE_BYTES + lane * 16),
@@ -158,124 +160,152 @@ struct NextB {
 
 enum Hidden : int { HID_SOFTPLUS = 0, HID_RELU = 1 };
 
-// Activation of one finished 16-row block, cut into KS_REG pieces so that piece `ks` can be issued between the MFMAs
-// of K step `ks` of the NEXT block (software pipeline, see run_net).  Branch-free; m = 1: hidden layer, m = 0: linear
-// (last) layer, k = 1 - m:
-//   softplus: max(z, k z) + (m ln2/100) log2(1 + 2^(-K|z|))   (k = 0 -> softplus, k = 1 -> z)
-//   relu    : max(z, k z)
-// Forward mode (column block 0 = values, 1..3 = tangents): t' = sigmoid(100 z) * t.
-template <int NB, bool FWD, int HID>
-__device__ __forceinline__ float act_value(float z, float m, float k, float cm) {
-    const float base = max_f(z, k * z);
-    if constexpr (HID == HID_SOFTPLUS) {
-        const float u = __builtin_amdgcn_exp2f(-SP_K * fabsf(z));
-        return fmaf(cm, __builtin_amdgcn_logf(1.0f + u), base);
-    } else {
-        return base;
-    }
+// Softplus networks are evaluated in SCALED UNITS: every hidden pre-activation / activation carries the factor
+// K = 100 log2(e) (the host scales biases and input-fed weights by K and the last, linear layer's weights by 1/K, see
+// hip.py), because  K * softplus_100(z) = max(z',0) + log2(1 + 2^-|z'|)  with z' = K z:  base-2 softplus needs no
+// multiplications around the two transcendentals, and d softplus/dz = sigmoid(100 z) = 1/(1+2^-z') is unit-free.
+// (torch's threshold branch, 100 z > 20 -> z, is dropped: there the correction is below half an ulp of z.)
+__device__ __forceinline__ float softplus2(float z) {
+#ifdef MP_EXP_NOTRANS
+    return relu_f(z) + 0.001f * z;
+#else
+    const float u = __builtin_amdgcn_exp2f(-fabsf(z));
+    return relu_f(z) + __builtin_amdgcn_logf(1.0f + u);
+#endif
 }
 
-template <int NB, bool FWD, int HID, int PIECE, typename NB_T>
-__device__ __forceinline__ void act_piece(f32x4 (&p)[NB], float m, NB_T& Bn, int pc, int ph) {
-    const float k = 1.0f - m, cm = SP_C * m;
+// Piece q (0..7) of the activation of a finished block of 16 rows x NB column blocks; one piece rides in every K step
+// of the next block's MFMA stream.  `hidden` (wave-uniform): apply the nonlinearity, else pass through.
+//   plain  : value q -> column block q/4, row q%4; a column block is packed when its 4 rows are done
+//   forward: half-block tangent layout (8 points per wave): block 0 = [values | d/dx], block 1 = [d/dy | d/dz]; lanes
+//            with (lane & 8) == 0 hold the value / d/dy columns of point lane&7, the others d/dx / d/dz.
+//            q < 4: row q (softplus + sigmoid, tangents scaled), q = 4,5: pack column block q-4
+template <int NB, bool FWD, int HID, int q, typename NB_T>
+__device__ __forceinline__ void act_piece(f32x4 (&p)[NB], bool hidden, NB_T& Bn, int pc, int ph) {
+    static_assert(NB == 2, "the MLP core is specialised for 2 column blocks per wave (2 waves per SIMD)");
     if constexpr (FWD) {
-        static_assert(NB == 4, "forward mode uses 4 column blocks");
-        if constexpr (PIECE < 4) {               // row PIECE: value + its three tangents
-            constexpr int r = PIECE;
-            const float z = p[0][r];
-            const float u = __builtin_amdgcn_exp2f(-SP_K * fabsf(z));
-            const float w = 1.0f + u;
-            p[0][r] = fmaf(cm, __builtin_amdgcn_logf(w), max_f(z, k * z));
-            const float rr = __builtin_amdgcn_rcpf(w);
-            const float sg = z >= 0.0f ? rr : u * rr;   // sigmoid(100 z)
-            const float s = fmaf(m, sg, k);             // m = 0 -> 1
-            p[1][r] *= s; p[2][r] *= s; p[3][r] *= s;
-        } else {                                  // pack column block PIECE-4 into the next layer's K operand
-            if (pc < KS_REG) Bn.put(pc, PIECE - 4, ph, p[PIECE - 4]);
+        if constexpr (q < 4) {
+            if (hidden) {
+                const bool vl = (threadIdx.x & 8) == 0;
+                const float z = p[0][q];
+#ifdef MP_EXP_NOTRANS
+                const float u = 0.5f * z, w = 1.0f + u, h = relu_f(z) + w, rr = w * 0.3f;
+#else
+                const float u = __builtin_amdgcn_exp2f(-fabsf(z));
+                const float w = 1.0f + u;
+                const float h = relu_f(z) + __builtin_amdgcn_logf(w);
+                const float rr = __builtin_amdgcn_rcpf(w);
+#endif
+                const float s = z >= 0.0f ? rr : u * rr;   // sigmoid(100 z_unscaled); meaningful in the value lanes
+                // lanes 8..15 of every 16-lane row take s from lane-8 (row_shr:8); value lanes keep their own
+                const float sf = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, s),
+                                                                                        __builtin_bit_cast(int, s),
+                                                                                        0x118, 0xF, 0xF, false));
+                p[0][q] = vl ? h : z * sf;
+                p[1][q] *= sf;
+            }
+        } else if constexpr (q < 6) {
+            if (pc < KS_REG) Bn.put(pc, q - 4, ph, p[q - 4]);
         }
-    } else if constexpr (NB == 4) {               // 16 values: two per piece, block nb = PIECE/2 packed when complete
-        constexpr int nb = PIECE / 2, r0 = 2 * (PIECE % 2);
-        p[nb][r0] = act_value<NB, FWD, HID>(p[nb][r0], m, k, cm);
-        p[nb][r0 + 1] = act_value<NB, FWD, HID>(p[nb][r0 + 1], m, k, cm);
-        if constexpr (PIECE % 2 == 1) { if (pc < KS_REG) Bn.put(pc, nb, ph, p[nb]); }
-    } else {                                      // NB == 2: 8 values, one per piece
-        static_assert(NB == 2, "NB must be 2 or 4");
-        constexpr int nb = PIECE / 4, r = PIECE % 4;
-        p[nb][r] = act_value<NB, FWD, HID>(p[nb][r], m, k, cm);
-        if constexpr (PIECE % 4 == 3) { if (pc < KS_REG) Bn.put(pc, nb, ph, p[nb]); }
+    } else {
+        constexpr int nb = q / 4, r = q % 4;
+        if (hidden) p[nb][r] = HID == HID_SOFTPLUS ? softplus2(p[nb][r]) : relu_f(p[nb][r]);
+        if constexpr (r == 3) { if (pc < KS_REG) Bn.put(pc, nb, ph, p[nb]); }
     }
 }
 
-template <int NB, bool FWD, int HID, typename NB_T>
-__device__ __forceinline__ void act_all(f32x4 (&p)[NB], float m, NB_T& Bn, int pc, int ph) {
-    act_piece<NB, FWD, HID, 0>(p, m, Bn, pc, ph); act_piece<NB, FWD, HID, 1>(p, m, Bn, pc, ph);
-    act_piece<NB, FWD, HID, 2>(p, m, Bn, pc, ph); act_piece<NB, FWD, HID, 3>(p, m, Bn, pc, ph);
-    act_piece<NB, FWD, HID, 4>(p, m, Bn, pc, ph); act_piece<NB, FWD, HID, 5>(p, m, Bn, pc, ph);
-    act_piece<NB, FWD, HID, 6>(p, m, Bn, pc, ph); act_piece<NB, FWD, HID, 7>(p, m, Bn, pc, ph);
+template <int NB, bool FWD, int HID, int q, typename NB_T>
+__device__ __forceinline__ void act_from(f32x4 (&p)[NB], bool hidden, NB_T& Bn, int pc, int ph) {
+    act_piece<NB, FWD, HID, q>(p, hidden, Bn, pc, ph);
+    if constexpr (q + 1 < 8) act_from<NB, FWD, HID, q + 1>(p, hidden, Bn, pc, ph);
 }
 
 // Runs the whole network for this wave's NB column blocks.
-//   Bcur : register K operand of layer 0 (zeros when the network input only enters through Bin); on return it holds
-//          the last layer's (bf16) output blocks (e.g. the 256 features).
+//   Bcur : register K operand of layer 0 (zeros when the network input only enters through the staging tile); on
+//          return it holds the last layer's (bf16) output blocks (e.g. the 256 features).
 //   stage_wave : this wave's input staging tile in LDS ([16*NB rows][in_stride] bf16, rows = columns): the encoded
 //          network input, read on demand as the K operand of K steps 8.. of every layer with use_in.
-//   out  : fp32 rows 0..15 of the `out_chunk` (0 or 8) of the layer that declares one, before activation.
-// Software pipeline: the activation of a finished 16-row block is issued inside the MFMA stream of the next block
-// (same basic block, independent registers), so the matrix pipe keeps running while the VALU does softplus / bf16
-// packing.  The caller must have issued chunk 0 into ring slot 0 and synchronised (see prologue()).
-template <int NB, bool FWD, int KS_IN, int HID>
+//   out  : fp32 rows 0..15 of the `out_chunk` (must be the last chunk of its layer).
+// Software pipeline: the activation of a finished 16-row block is issued, one piece per K step, inside the MFMA stream
+// of the next block; A tiles run PF tiles ahead in a rotating register queue across block and chunk boundaries;
+// weight chunks are loaded two chunks ahead into a 3-slot LDS ring (one barrier per chunk).
+// The caller must have run prologue() (chunks 0 and 1 in ring slots 0 and 1, barrier).
+template <int NB, bool FWD, int KS_IN, int HID, int WAVES>
 __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restrict__ wpack, const float* bias_lds,
                                         char* wring, bf16x8 (&Bcur)[KS_REG][NB], const __bf16* stage_wave,
                                         f32x4 (&out)[NB], int wave, int lane) {
     const int g = lane >> 4;
     int ci = 0;
-    NextB<NB, (NB > 2)> Bn;
+    NextB<NB, false> Bn;
     Bn.zero();
+    constexpr int PF = 3, QN = 4;   // prefetch distance / queue length in A tiles
+    bf16x8 aq[QN];
+#pragma unroll
+    for (int t = 0; t < PF; ++t) aq[t] = *(const bf16x8*)(wring + t * TILE_BYTES + lane * 16);  // chunk 0, block 0
     for (int l = 0; l < net.n_layers; ++l) {
         const LayerDesc L = net.layer[l];
         const float* bl = bias_lds + l * BIAS_STRIDE;
-        const float m = L.act != ACT_NONE ? 1.0f : 0.0f;
+        const bool hidden = L.act != ACT_NONE;
         f32x4 pend[NB];  // finished block whose activation is still pending
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) pend[nb] = (f32x4){0, 0, 0, 0};
 #pragma unroll
         for (int c = 0; c < MAX_CHUNKS; ++c) {
             if (c < L.n_chunk) {
-                if (ci + 1 < net.total_chunks) issue_chunk<KS_IN>(wpack, wring, ci + 1, wave, lane);
-                const char* slot = wring + (ci & 1) * chunk_bytes(KS_IN);
+#ifndef MP_EXP_NOLOAD
+                if (ci + 2 < net.total_chunks) issue_chunk<KS_IN, WAVES>(wpack, wring, ci + 2, wave, lane);
+#endif
+                const char* slot = wring + (ci % RING_SLOTS) * chunk_bytes(KS_IN) + lane * 16;
+                // chunk ci+1 landed before the previous barrier: its first A tiles are prefetched from this chunk
+                const char* slot_next = wring + ((ci + 1) % RING_SLOTS) * chunk_bytes(KS_IN) + lane * 16;
+                const bool has_next = ci + 1 < net.total_chunks;
 #pragma unroll
                 for (int mbl = 0; mbl < CHUNK_MB; ++mbl) {
                     f32x4 acc[NB];
                     const f32x4 bv = *(const f32x4*)(bl + c * 32 + mbl * 16 + g * 4);
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) acc[nb] = (FWD && nb > 0) ? (f32x4){0, 0, 0, 0} : bv;
-                    const char* tile = slot + mbl * mb_bytes(KS_IN) + lane * 16;
-                    // pending block = (c, 0) when mbl == 1, (c-1, 1) when mbl == 0: its activation rides in this MFMA stream
+                    if constexpr (FWD) {  // only the value half of block 0 carries the bias
+                        if (threadIdx.x & 8) acc[0] = (f32x4){0, 0, 0, 0};
+                    }
+                    const char* tile = slot + mbl * mb_bytes(KS_IN);
+                    // pending block = (c, 0) when mbl == 1, (c-1, 1) when mbl == 0
                     const bool has_pend = mbl == 1 || c > 0;
                     const int pc = mbl == 1 ? c : c - 1, ph = mbl == 1 ? 0 : 1;
-                    if (has_pend && (pc == 0 || pc == MAX_CHUNKS - 1) && ph == 0) {
-                        if (pc == L.out_chunk) {
-#pragma unroll
-                            for (int nb = 0; nb < NB; ++nb) out[nb] = pend[nb];
-                        }
-                    }
-                    bf16x8 a_nxt = *(const bf16x8*)(tile);
-#define MP_KSTEP(KS)                                                                                              \
-                    {                                                                                             \
-                        const bf16x8 a = a_nxt;                                                                   \
-                        if (KS + 1 < KS_REG) a_nxt = *(const bf16x8*)(tile + (KS + 1) * TILE_BYTES);              \
-                        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                         \
-                            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, Bcur[KS][nb], acc[nb], 0, 0, 0); \
-                        if (has_pend) act_piece<NB, FWD, HID, KS>(pend, m, Bn, pc, ph);                           \
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                        \
-                        _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                          \
-                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
-                            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                    \
-                        }                                                                                         \
-                        __builtin_amdgcn_sched_barrier(0);                                                        \
-                    }
+#ifdef MP_EXP_NOACT
+#define MP_ACT_STMT(KS)
+#else
+#define MP_ACT_STMT(KS) if (has_pend) act_piece<NB, FWD, HID, KS>(pend, hidden, Bn, pc, ph);
+#endif
+#ifdef MP_EXP_NOLDS
+#define MP_LDS_STMT (void)src;
+#else
+#define MP_LDS_STMT if (nk < KS_REG || mbl + 1 < CHUNK_MB || has_next) aq[nk % QN] = *(const bf16x8*)src;
+#endif
+#define MP_KSTEP(KS)                                                                                                  \
+    {                                                                                                                 \
+        const bf16x8 a = aq[KS % QN];                                                                                 \
+        {                                                                                                             \
+            constexpr int nk = KS + PF;                                                                               \
+            const char* src = nk < KS_REG ? tile + nk * TILE_BYTES                                                    \
+                              : (mbl + 1 < CHUNK_MB ? tile + mb_bytes(KS_IN) + (nk - KS_REG) * TILE_BYTES             \
+                                                    : slot_next + (nk - KS_REG) * TILE_BYTES);                        \
+            MP_LDS_STMT                                                                                               \
+        }                                                                                                             \
+        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                             \
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, Bcur[KS][nb], acc[nb], 0, 0, 0);                     \
+        MP_ACT_STMT(KS)                                                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                            \
+        _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                                              \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                        \
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);                                                        \
+        }                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+    }
                     MP_KSTEP(0) MP_KSTEP(1) MP_KSTEP(2) MP_KSTEP(3) MP_KSTEP(4) MP_KSTEP(5) MP_KSTEP(6) MP_KSTEP(7)
 #undef MP_KSTEP
+#undef MP_ACT_STMT
+#undef MP_LDS_STMT
                     if (L.use_in) {
 #pragma unroll
                         for (int ks = 0; ks < KS_IN; ++ks) {
@@ -290,9 +320,19 @@ __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restri
                     }
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) pend[nb] = acc[nb];
+                    if ((c == 0 || c == MAX_CHUNKS - 1) && mbl == 0) {
+                        if (c == L.out_chunk) {  // fp32 rows 0..15 of the out chunk (its layer is linear)
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb) out[nb] = acc[nb];
+                        }
+                    }
                 }
-                if (c == L.n_chunk - 1) act_all<NB, FWD, HID>(pend, m, Bn, c, 1);  // layer ends: drain block (c, 1)
-                __syncthreads();  // every wave is done with chunk ci; chunk ci+1 has landed (vmcnt drained)
+                if (c == L.n_chunk - 1) {  // layer ends: drain the pipeline (block (c, 1))
+                    act_from<NB, FWD, HID, 0>(pend, hidden, Bn, c, 1);
+                }
+#ifndef MP_EXP_NOBARRIER
+                __syncthreads();  // every wave is done with chunk ci; chunk ci+2's loads have had a whole chunk to land
+#endif
                 ++ci;
             }
         }
@@ -303,11 +343,12 @@ __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restri
     }
 }
 
-// Loads the per-layer biases into LDS and the first weight chunk into ring slot 0.
-template <int KS_IN>
+// Issues the first two weight chunks into ring slots 0 and 1 and synchronises (also publishes the staging rows).
+template <int KS_IN, int WAVES>
 __device__ __forceinline__ void prologue(const NetDesc& net, const char* __restrict__ wpack, char* wring, int wave,
                                          int lane) {
-    issue_chunk<KS_IN>(wpack, wring, 0, wave, lane);
+    issue_chunk<KS_IN, WAVES>(wpack, wring, 0, wave, lane);
+    if (net.total_chunks > 1) issue_chunk<KS_IN, WAVES>(wpack, wring, 1, wave, lane);
     __syncthreads();
 }
 __device__ __forceinline__ void load_bias(const NetDesc& net, const float* __restrict__ bias, float* bias_lds) {

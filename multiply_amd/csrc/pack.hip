@@ -18,7 +18,7 @@ __global__ __launch_bounds__(64) void k_pack_layer(const float* __restrict__ v, 
                                                    const float* __restrict__ b, int out_dim, int in_dim,
                                                    const int* __restrict__ rowmap, const int* __restrict__ colmap,
                                                    const float* __restrict__ colscale, int ks_in, int hoist_col0,
-                                                   int hoist_n, const float* __restrict__ hoist_vec,
+                                                   int hoist_n, const float* __restrict__ hoist_vec, float bias_scale,
                                                    __bf16* __restrict__ wpack, float* __restrict__ bias_out) {
     const int r = blockIdx.x, lane = threadIdx.x;
     const int src = rowmap[r];
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(64) void k_pack_layer(const float* __restrict__ v, 
             for (int c = lane; c < hoist_n; c += 64) h += (row[hoist_col0 + c] * scale) * hoist_vec[c];
             h = wave_sum(h);
         }
-        if (lane == 0) bias_out[r] = src >= 0 ? b[src] + h : 0.0f;
+        if (lane == 0) bias_out[r] = src >= 0 ? (b[src] + h) * bias_scale : 0.0f;
     }
 }
 
@@ -66,14 +66,14 @@ __global__ void k_zero_f(float* p, int n) {
 
 extern "C" int mp_pack_layer(const float* v, const float* g, const float* b, int out_dim, int in_dim,
                              const int* rowmap, int n_rows, const int* colmap, const float* colscale, int ks_in,
-                             int hoist_col0, int hoist_n, const float* hoist_vec, void* wpack_layer,
-                             float* bias_layer, void* stream) {
+                             int hoist_col0, int hoist_n, const float* hoist_vec, float bias_scale,
+                             void* wpack_layer, float* bias_layer, void* stream) {
     if (n_rows <= 0 || n_rows % 32 || n_rows > MP_BIAS_STRIDE || (ks_in != 2 && ks_in != 3)) return -1;
     hipStream_t st = (hipStream_t)stream;
     if (bias_layer && n_rows < MP_BIAS_STRIDE)
         hipLaunchKernelGGL(k_zero_f, dim3(1), dim3(MP_BIAS_STRIDE), 0, st, bias_layer + n_rows, MP_BIAS_STRIDE - n_rows);
     hipLaunchKernelGGL(k_pack_layer, dim3(n_rows), dim3(64), 0, st, v, g, b, out_dim, in_dim, rowmap, colmap,
-                       colscale, ks_in, hoist_col0, hoist_n, hoist_vec, (__bf16*)wpack_layer, bias_layer);
+                       colscale, ks_in, hoist_col0, hoist_n, hoist_vec, bias_scale, (__bf16*)wpack_layer, bias_layer);
     return (int)hipGetLastError();
 }
 

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmultiply_hip.so")
+LIB_PATH = os.environ.get("MP_LIB_PATH", os.path.join(_HERE, "libmultiply_hip.so"))  # override: experiments only
 
 MAX_LAYERS, MAX_CHUNKS, BIAS_STRIDE = 10, 9, 288
 ACT_NONE, ACT_SOFTPLUS, ACT_RELU = 0, 1, 2
@@ -93,8 +93,11 @@ _REG_FEATURE = np.array([reg_slot_feature(s) for s in range(256)], dtype=np.int6
 class LayerPlan:
     """How one nn.Linear maps onto the packed layout."""
 
-    def __init__(self, lin, rowmap, reg_cols=None, in_cols=None, scale=1.0, hoist=None, act=ACT_NONE, out_chunk=-1):
+    def __init__(self, lin, rowmap, reg_cols=None, in_cols=None, scale=1.0, hoist=None, act=ACT_NONE, out_chunk=-1,
+                 in_scale=None, bias_scale=1.0):
         self.lin, self.act, self.out_chunk = lin, act, out_chunk
+        self.in_scale = float(scale if in_scale is None else in_scale)   # factor on the input-fed K slots
+        self.bias_scale = float(bias_scale)
         rowmap = list(rowmap)
         while len(rowmap) % 32:
             rowmap.append(-1)
@@ -140,7 +143,11 @@ class PackedNet:
         self.bias = torch.zeros(MAX_LAYERS * BIAS_STRIDE, dtype=torch.float32, device=device)
         self.rowmaps = [torch.from_numpy(p.rowmap).to(device) for p in plans]
         self.colmaps = [torch.from_numpy(p.colmap(ks_in)).to(device) for p in plans]
-        self.colscales = [torch.full(((8 + ks_in) * 32,), p.scale, dtype=torch.float32, device=device) for p in plans]
+        self.colscales = []
+        for p in plans:
+            cs = torch.full(((8 + ks_in) * 32,), p.scale, dtype=torch.float32, device=device)
+            cs[256:] = p.in_scale
+            self.colscales.append(cs)
         self.version = None
 
     def _params(self, lin):
@@ -158,7 +165,8 @@ class PackedNet:
         bp = C.c_void_p(self.bias.data_ptr() + 4 * i * BIAS_STRIDE)
         check(lib().mp_pack_layer(ptr(v), ptr(g), ptr(b), v.shape[0], v.shape[1], ptr(self.rowmaps[i]),
                                   len(p.rowmap), ptr(self.colmaps[i]), ptr(self.colscales[i]), self.ks_in, h0, hn,
-                                  ptr(hoist_vec) if hn else None, wp, bp, stream()), "mp_pack_layer")
+                                  ptr(hoist_vec) if hn else None, C.c_float(p.bias_scale), wp, bp, stream()),
+              "mp_pack_layer")
 
     def param_version(self):
         vs = []
@@ -180,10 +188,15 @@ class PackedNet:
         self.version = ver
 
 
+SOFTPLUS_K = 100.0 * math.log2(math.e)   # scaled units of the softplus networks (csrc/mlp_core.hpp)
+
+
 def implicit_plans(net, variant):
     """LayerPlans of an ImplicitNet (fg: d_in 3, L 6, cond 69; bg: d_in 4, L 10, cond 32).
-    variant 'sdf': last layer = sdf row only; 'full': 256 feature rows then the sdf row as the extra out chunk."""
-    E, nl = net.embed_dim, net.num_layers - 1
+    variant 'sdf': last layer = sdf row only; 'full': 256 feature rows then the sdf row as the extra out chunk.
+    Hidden layers work in scaled units z' = K z, h' = K h: biases and input-fed weights x K, register-fed weights
+    unchanged, last (linear) layer's weights x 1/K."""
+    E, nl, K = net.embed_dim, net.num_layers - 1, SOFTPLUS_K
     plans = []
     for l, lin in enumerate(net.layers()):
         out_dim = (lin.weight_v if hasattr(lin, "weight_v") else lin.weight).shape[0]
@@ -191,19 +204,21 @@ def implicit_plans(net, variant):
         act = ACT_NONE if last else ACT_SOFTPLUS
         if last:
             if variant == "sdf":
-                plans.append(LayerPlan(lin, [0], reg_cols=np.arange(256), act=act, out_chunk=0))
+                plans.append(LayerPlan(lin, [0], reg_cols=np.arange(256), scale=1.0 / K, act=act, out_chunk=0))
             else:
-                plans.append(LayerPlan(lin, list(range(1, out_dim)) + [0], reg_cols=np.arange(256), act=act,
-                                       out_chunk=8))
+                plans.append(LayerPlan(lin, list(range(1, out_dim)) + [0], reg_cols=np.arange(256), scale=1.0 / K,
+                                       act=act, out_chunk=8))
         elif l == 0:
             hoist = (E, net.cond_dim) if net.cond_dim > 0 else None
-            plans.append(LayerPlan(lin, range(out_dim), in_cols=np.arange(E), hoist=hoist, act=act))
+            plans.append(LayerPlan(lin, range(out_dim), in_cols=np.arange(E), hoist=hoist, act=act, in_scale=K,
+                                   bias_scale=K))
         elif l in net.skip_in:
             prev = net.dims[l] - E   # width of the previous layer's output
-            plans.append(LayerPlan(lin, range(out_dim), reg_cols=np.arange(prev), in_cols=prev + np.arange(E),
-                                   scale=1.0 / math.sqrt(2.0), act=act))
+            r2 = 1.0 / math.sqrt(2.0)
+            plans.append(LayerPlan(lin, range(out_dim), reg_cols=np.arange(prev), in_cols=prev + np.arange(E), scale=r2,
+                                   in_scale=r2 * K, act=act, bias_scale=K))
         else:
-            plans.append(LayerPlan(lin, range(out_dim), reg_cols=np.arange(net.dims[l]), act=act))
+            plans.append(LayerPlan(lin, range(out_dim), reg_cols=np.arange(net.dims[l]), act=act, bias_scale=K))
     return plans
 
 
@@ -255,7 +270,8 @@ class PoseEmbed:
         lp = self.net.lin_pose
         w, b = lp.weight.detach().contiguous(), lp.bias.detach().contiguous()
         check(lib().mp_pack_layer(ptr(w), None, ptr(b), 8, 69, ptr(self.rowmap), 32, ptr(self.colmap),
-                                  ptr(self.colscale), 2, 0, 69, ptr(cond_vec), None, ptr(self.out), stream()),
+                                  ptr(self.colscale), 2, 0, 69, ptr(cond_vec), C.c_float(1.0), None, ptr(self.out),
+                                  stream()),
               "mp_pack_layer(lin_pose)")
         return self.out  # first 8 floats
 

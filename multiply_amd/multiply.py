@@ -262,18 +262,20 @@ class Multiply(nn.Module):
             nrm = torch.zeros(npts, 3, **f32)
             rgb = torch.zeros(npts, 3, **f32)
             work2 = torch.empty(npts, **i32)
+            need = torch.empty(npts, dtype=torch.uint8, device=dev)
             wc2 = wcount[rs.max_total_iters:]
             ph = self._ph("shade_warp"); ph.__enter__()
             hip.check(L.mp_warp_inverse_shade(hip.ptr(dirs), hip.ptr(pose), hip.ptr(pp["hit_index"]), hip.ptr(pp["count"]),
                                               hip.ptr(zfinal), NZ, S, Rp, hip.ptr(pp["vsorted"]), hip.ptr(pp["cbound"]),
                                               hip.ptr(skin_w), hip.ptr(pp["tfs"]), 1, hip.ptr(beta), hip.ptr(xc), None,
-                                              hip.ptr(sdf), hip.ptr(work2), hip.ptr(wc2), st), "mp_warp_inverse_shade")
+                                              hip.ptr(need), hip.ptr(sdf), hip.ptr(work2), hip.ptr(wc2), st),
+                      "mp_warp_inverse_shade")
             ph.__exit__()
             jinv = torch.empty(npts, 9, **f32)
             ph = self._ph("shade_jacobian"); ph.__enter__()
-            hip.check(L.mp_warp_jacobian(hip.ptr(xc), hip.ptr(work2), hip.ptr(wc2), npts, hip.ptr(dfm.vsorted_c),
-                                         hip.ptr(dfm.cbound_c), hip.ptr(skin_w), hip.ptr(pp["tfs"]), hip.ptr(jinv), st),
-                      "mp_warp_jacobian")
+            hip.check(L.mp_warp_jacobian(hip.ptr(xc), hip.ptr(need), hip.ptr(pp["count"]), Rp, S, 0,
+                                         hip.ptr(dfm.vsorted_c), hip.ptr(dfm.cbound_c), hip.ptr(skin_w), hip.ptr(pp["tfs"]),
+                                         hip.ptr(jinv), st), "mp_warp_jacobian")
             ph.__exit__()
             pk_full = hip.packed(imp, "full", 2)
             pk_full.refresh(pp["cond"])
