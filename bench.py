@@ -29,7 +29,7 @@ M_IMP, M_REN, M_BGIMP, M_BGREN = 542208, 266496, 532736, 40704      # MACs / poi
 PEAK_BF16_TFLOPS = 2500.0                                           # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
-def build_model(n_samples, seed=0, H=512, W=512, P=2):
+def build_model(n_samples, seed=0, H=512, W=512, P=2, tile=8):
     import warnings
     warnings.filterwarnings("ignore")
     from multiply_amd.config import load_config
@@ -44,7 +44,14 @@ def build_model(n_samples, seed=0, H=512, W=512, P=2):
     model = Multiply(opt, sc["smpl_params"][0, :, 76:], smpl_tables=tables).eval()
     t = lambda a: torch.tensor(a, dtype=torch.float32)
     sp = t(sc["smpl_params"])
-    inp = dict(uv=t(sc["uv"]), intrinsics=t(sc["intrinsics"]), pose=t(sc["pose"]), smpl_params=sp,
+    uv = sc["uv"]
+    if tile and H % tile == 0 and W % tile == 0:
+        # ray order inside the batch is the caller's choice (the reference takes any uv list): emit the frame tile by tile
+        # (tile x tile pixels contiguous) so that 64 consecutive rays are spatial neighbours -> coherent nearest-vertex
+        # searches; a convergence group of 512 rays is then a 64x8-pixel block instead of a 512x1 row.
+        idx = np.arange(H * W).reshape(H // tile, tile, W // tile, tile).transpose(0, 2, 1, 3).reshape(-1)
+        uv = uv[:, idx]
+    inp = dict(uv=t(uv), intrinsics=t(sc["intrinsics"]), pose=t(sc["pose"]), smpl_params=sp,
                smpl_pose=sp[:, :, 4:76], smpl_shape=sp[:, :, 76:], smpl_trans=sp[:, :, 1:4], idx=torch.tensor([3]))
     return model, inp, tables, sc
 
@@ -58,7 +65,9 @@ def cpu_baseline(model, inp, tables, sc, n_samples, rows=1, stride=4):
     (which crosses both bodies).  Also returns the GPU-vs-oracle pixel error on that sample."""
     from oracle import multiply_oracle as O
     H = W = int(round(np.sqrt(inp["uv"].shape[1])))
-    sel = (H // 2) * W + torch.arange(0, W, stride)
+    uvx, uvy = inp["uv"][0, :, 0], inp["uv"][0, :, 1]
+    sel = torch.nonzero((uvy == H // 2) & (uvx % stride == 0)).flatten()
+    sel = sel[torch.argsort(uvx[sel])]
     sub = dict(inp)
     sub["uv"] = inp["uv"][:, sel]
     got = model(to_dev(sub))
@@ -84,6 +93,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--samples", type=int, default=128, help="importance samples per ray (N_samples)")
     ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--tile", type=int, default=8, help="emit the frame's rays in tile x tile pixel blocks (0 = row-major)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print per-phase GPU times to stderr")
     args = ap.parse_args()
@@ -99,7 +109,7 @@ def main():
         td.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     # every rank renders its own frame of the synthetic sequence (seed = rank)
-    model, inp, tables, sc = build_model(args.samples, seed=rank, H=args.res, W=args.res)
+    model, inp, tables, sc = build_model(args.samples, seed=rank, H=args.res, W=args.res, tile=args.tile)
     model.convergence_group = 512            # the reference renders frames in chunks of pixel_per_batch = 512 rays
     gin = to_dev(inp)
     R = gin["uv"].shape[1]

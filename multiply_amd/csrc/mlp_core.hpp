@@ -282,6 +282,14 @@ __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restri
 #else
 #define MP_LDS_STMT if (nk < KS_REG || mbl + 1 < CHUNK_MB || has_next) aq[nk % QN] = *(const bf16x8*)src;
 #endif
+#define MP_QSKIP(KS)                                                                                                  \
+    {                                                                                                                 \
+        constexpr int nk = KS + PF;                                                                                   \
+        const char* src = nk < KS_REG ? tile + nk * TILE_BYTES                                                        \
+                          : (mbl + 1 < CHUNK_MB ? tile + mb_bytes(KS_IN) + (nk - KS_REG) * TILE_BYTES                 \
+                                                : slot_next + (nk - KS_REG) * TILE_BYTES);                            \
+        if (nk >= KS_REG) { MP_LDS_STMT }                                                                             \
+    }
 #define MP_KSTEP(KS)                                                                                                  \
     {                                                                                                                 \
         const bf16x8 a = aq[KS % QN];                                                                                 \
@@ -302,8 +310,18 @@ __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restri
         }                                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
     }
-                    MP_KSTEP(0) MP_KSTEP(1) MP_KSTEP(2) MP_KSTEP(3) MP_KSTEP(4) MP_KSTEP(5) MP_KSTEP(6) MP_KSTEP(7)
+                    if (L.use_reg) {
+                        MP_KSTEP(0) MP_KSTEP(1) MP_KSTEP(2) MP_KSTEP(3) MP_KSTEP(4) MP_KSTEP(5) MP_KSTEP(6) MP_KSTEP(7)
+                    } else {
+                        // layer fed only by the encoded input (layer 0): no register K steps; keep the A-tile queue
+                        // in step with the tile stream and finish the pending block's activation
+                        MP_QSKIP(0) MP_QSKIP(1) MP_QSKIP(2) MP_QSKIP(3) MP_QSKIP(4) MP_QSKIP(5) MP_QSKIP(6) MP_QSKIP(7)
+#ifndef MP_EXP_NOACT
+                        if (has_pend) act_from<NB, FWD, HID, 0>(pend, hidden, Bn, pc, ph);
+#endif
+                    }
 #undef MP_KSTEP
+#undef MP_QSKIP
 #undef MP_ACT_STMT
 #undef MP_LDS_STMT
                     if (L.use_in) {
