@@ -181,7 +181,8 @@ int mp_sampler_init(const MpSamplerCfg* cfg, const MpSamplerState* st, const flo
 int mp_sampler_bound(const MpSamplerCfg* cfg, const MpSamplerState* st, const float* beta0, const int* hit_index,
                      const int* hit_count, int max_rays, int group_size, int n_rays_total, int iter, void* stream);
 /* up-sample from the error-bound pdf, or draw the final samples and assemble zfinal (ray_sampler.py:139-209);
- * u_final [max_rays][n_samples] / extra_idx [n_extra] supply the training randomness, NULL = eval linspace */
+ * u_final [max_rays][n_samples] / extra_idx [max_total_iters][n_extra] supply the training randomness (row k-1 =
+ * randperm(n_eval*k)[:n_extra], used when the sorted list holds n_eval*k depths), NULL = eval linspace */
 int mp_sampler_resample(const MpSamplerCfg* cfg, const MpSamplerState* st, const float* beta0, const float* far,
                         const int* hit_index, const int* hit_count, int max_rays, int group_size, int n_rays_total,
                         int iter, const float* u_final, const int* extra_idx, void* stream);
@@ -196,6 +197,61 @@ int mp_composite(int n_rays, int n_person, int n_z, const int* const* inv_index,
                  const float* const* sdf, const float* const* rgb, const float* const* normal, const float* beta,
                  const float* bg_rgb, float* rgb_values, float* fg_rgb_values, float* normal_values, float* acc_map,
                  float* acc_person, float* bg_T, void* stream);
+
+
+/* ---- fp32 training path (layer-wise forward with stash + hand-written backward) ----------------------------------
+ * The reference trains in fp32 through torch autograd (multiply_model.py:192-217).  These entry points are the pieces of
+ * the same computation as explicit forward / adjoint kernels; multiply_amd/train.py chains them inside one
+ * torch.autograd.Function so that the reference's Loss and optimisers work unchanged.
+ * Forward-mode row convention: a tensor of a network evaluated for P points with spatial tangents has 4P rows:
+ * [0,P) values, [P,2P) d/dx, [2P,3P) d/dy, [3P,4P) d/dz.  "ld*" are row strides in floats. */
+/* C[M,N] (+)= A[M,K] . B[N,K]^T (+ bias[N] on rows < bias_rows) (optional ReLU); exact-fp32 MFMA */
+int mp_gemm_nt(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+               const float* bias, int bias_rows, int accumulate, int relu, void* stream);
+/* C[M,N] += A[K,M]^T . B[K,N]  (C must be initialised; fp32 atomics) */
+int mp_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, void* stream);
+/* Fourier features (embedders.py) of x [P][d_in] (d_in 3|4, L octaves) times `scale` into out[.][ld] at col0; fwd != 0 also
+ * writes the three (d_in = 3) tangent row blocks */
+int mp_tr_pe(const float* x, int d_in, int P, int L, int fwd, float scale, float* out, int ld, int col0, void* stream);
+/* nn.Softplus(beta=100) layer on Z [rows][C] -> H at col0 (times scale); P > 0: forward mode (rows = 4P) */
+int mp_tr_softplus_fwd(const float* Z, int ldz, int rows, int C, int P, float scale, float* H, int ldh, int col0,
+                       void* stream);
+int mp_tr_softplus_bwd(const float* Z, int ldz, int rows, int C, int P, float scale, const float* dH, int ldh, int col0,
+                       float* dZ, int lddz, void* stream);
+int mp_tr_relu_bwd(const float* H, int ldh, int rows, int C, const float* dH, int lddh, float* dZ, int lddz, void* stream);
+/* last ImplicitNet layer Z8 [4P][257] -> sdf, normals (multiply.py:606,661) and the colour-net input XA [n][6] = [x_c, n];
+ * the adjoint writes column 0 of a zero-initialised dZ8 (d sdf on value rows, d grad on tangent rows) */
+int mp_tr_shade_in_fwd(const float* Z8, int P, int n_pts, const float* xc, const float* jinv, float* XR, float* nrm,
+                       float* sdf, void* stream);
+int mp_tr_shade_in_bwd(const float* Z8, int P, int n_pts, const float* jinv, const float* dXR, const float* dsdf,
+                       const float* dnrm_extra, float* dZ8, void* stream);
+/* eikonal samples (multiply.py:322-331): grad_theta [E][3] = d sdf/dx of points e0..e0+E of the batch */
+int mp_tr_eik_fwd(const float* Z8, int P, int e0, int E, float* grad_theta, void* stream);
+int mp_tr_eik_bwd(int P, int e0, int E, const float* dgrad, float* dZ8, void* stream);
+int mp_tr_sigmoid_fwd(const float* Z, long long n, float* Y, void* stream);
+int mp_tr_sigmoid_bwd(const float* Y, const float* dY, long long n, float* dZ, void* stream);
+/* weight norm w = g v/|v| (networks.py:82-83): W [out][in] and its transpose WT [in][out]; adjoint dW -> dv, dg */
+int mp_tr_wn_fwd(const float* v, const float* g, int out_dim, int in_dim, float* W, float* WT, void* stream);
+int mp_tr_wn_bwd(const float* v, const float* g, int out_dim, int in_dim, const float* dW, float* dv, float* dg,
+                 void* stream);
+/* per-call constant conditioning folded into the bias: b2 = b + W[:, c0:c0+n] vec ; adjoint dW[:, c0:c0+n] += db2 vec^T */
+int mp_tr_hoist_fwd(const float* W, int out_dim, int in_dim, const float* b, int c0, int n, const float* vec, float* b2,
+                    void* stream);
+int mp_tr_hoist_bwd(const float* db2, int out_dim, int in_dim, int c0, int n, const float* vec, float* dW, void* stream);
+int mp_tr_colsum(const float* dZ, int ld, int rows, int C, float* db, void* stream);
+/* adjoint of mp_composite: d rgb_values / d acc_map / d acc_person -> d sdf[p], d rgb[p], d bg_rgb, d beta (+=) */
+int mp_tr_composite_bwd(int n_rays, int n_person, int n_z, const int* const* inv_index, const float* const* z,
+                        const float* const* sdf, const float* const* rgb, const float* beta, const float* bg_rgb,
+                        const float* d_rgb_values, const float* d_acc, const float* d_acc_person, float* const* d_sdf,
+                        float* const* d_rgb, float* d_bg_rgb, float* d_beta, void* stream);
+/* background branch pieces (multiply.py:682-726) with per-ray depths zbg [R][NBG] */
+int mp_tr_bg_points(const float* dirs, const float* cam, const float* zbg, int R, int NBG, float radius, float* pts,
+                    void* stream);
+int mp_tr_bg_comp_fwd(const float* sdf, const float* rgb, const float* zbg, int R, int NBG, float* out, void* stream);
+int mp_tr_bg_comp_bwd(const float* sdf, const float* rgb, const float* zbg, int R, int NBG, const float* dout, float* dsdf,
+                      float* drgb, void* stream);
+int mp_tr_copy_cols(const float* src, int lds, int c0s, float* dst, int ldd, int c0d, long long rows, int C, float scale,
+                    int accumulate, void* stream);
 
 /* library / device info: returns the gfx arch string compiled in, and checks the current device */
 const char* mp_arch(void);

@@ -278,7 +278,8 @@ __global__ __launch_bounds__(256) void k_sampler_resample(MpSamplerCfg cfg, MpSa
     const int NF = NS + 2 + NX;
     if (lane == 0) { outv[NS] = cfg.near_; outv[NS + 1] = far[hit_index[k]]; }
     for (int j = lane; j < NX; j += 64) {
-        const int idx = extra_idx ? extra_idx[j] : (int)linspace_at(0.0f, (float)(n - 1), NX, j);
+        // training: one randperm(n)[:NX] row per possible list length n = NE * k (ray_sampler.py:202)
+        const int idx = extra_idx ? extra_idx[(n / NE - 1) * NX + j] : (int)linspace_at(0.0f, (float)(n - 1), NX, j);
         outv[NS + 2 + j] = r.Z[min(max(idx, 0), n - 1)];
     }
     wave_sync();

@@ -1,0 +1,542 @@
+// Element-wise / small kernels of the fp32 TRAINING path (layer-wise forward with stash + hand-written backward).
+// Forward-mode convention: a network evaluated for P points in forward mode works on tensors of 4P rows:
+//   rows [0,P) values, rows [P,2P) d/dx, [2P,3P) d/dy, [3P,4P) d/dz  (tangents w.r.t. the canonical point x_c).
+// The backward pass is the reverse sweep over this forward-mode graph, which yields the mixed second derivatives the
+// reference obtains with create_graph=True (normals: multiply.py:620-661, eikonal term: :328-330).
+// Entry points: include/multiply_hip.h (mp_tr_*).
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include "../../include/multiply_hip.h"
+#include "common.hpp"
+
+namespace {
+
+constexpr int TB = 256;
+inline dim3 grid1(long long n) { return dim3((unsigned)((n + TB - 1) / TB)); }
+
+// torch.nn.Softplus(beta=100, threshold=20) and its first two derivatives
+__device__ __forceinline__ void softplus_d012(float z, float& h, float& d1, float& d2) {
+    const float t = 100.0f * z;
+    if (t > 20.0f) { h = z; d1 = 1.0f; d2 = 0.0f; return; }
+    const float e = expf(t);
+    h = log1pf(e) * 0.01f;
+    d1 = e / (1.0f + e);               // sigmoid(100 z)
+    d2 = 100.0f * d1 * (1.0f - d1);
+}
+
+// ---- Fourier features (embedders.py) and their spatial tangents: out [(FWD?4:1)*P rows][ld], columns col0..col0+NF
+template <int D>
+__global__ void k_pe_fwd(const float* __restrict__ x, int P, int L, int fwd, float scale, float* __restrict__ out, int ld,
+                         int col0) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float v[D];
+    for (int a = 0; a < D; ++a) v[a] = x[(size_t)i * D + a];
+    float* o = out + (size_t)i * ld + col0;
+    for (int a = 0; a < D; ++a) o[a] = v[a] * scale;
+    for (int k = 0; k < L; ++k) {
+        const float f = (float)(1 << k);
+        for (int a = 0; a < D; ++a) {
+            o[D + 2 * D * k + a] = sinf(v[a] * f) * scale;
+            o[D + 2 * D * k + D + a] = cosf(v[a] * f) * scale;
+        }
+    }
+    if (fwd) {
+        const int NF = D + 2 * D * L;
+        for (int b = 0; b < D; ++b) {
+            float* ot = out + (size_t)((b + 1) * P + i) * ld + col0;
+            for (int c = 0; c < NF; ++c) ot[c] = 0.0f;
+            ot[b] = scale;
+            for (int k = 0; k < L; ++k) {
+                const float f = (float)(1 << k);
+                ot[D + 2 * D * k + b] = f * cosf(v[b] * f) * scale;
+                ot[D + 2 * D * k + D + b] = -f * sinf(v[b] * f) * scale;
+            }
+        }
+    }
+}
+
+// ---- softplus layer: Z [rows][C] (ldz) -> H [rows][ldh] at col0, times scale; forward mode when P > 0 (rows = 4P)
+__global__ void k_softplus_fwd(const float* __restrict__ Z, int ldz, int rows, int C, int P, float scale,
+                               float* __restrict__ H, int ldh, int col0) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)rows * C) return;
+    const int r = (int)(idx / C), c = (int)(idx % C);
+    float h, d1, d2;
+    if (P > 0 && r >= P) {
+        softplus_d012(Z[(size_t)(r % P) * ldz + c], h, d1, d2);
+        H[(size_t)r * ldh + col0 + c] = d1 * Z[(size_t)r * ldz + c] * scale;
+    } else {
+        softplus_d012(Z[(size_t)r * ldz + c], h, d1, d2);
+        H[(size_t)r * ldh + col0 + c] = h * scale;
+    }
+}
+
+// adjoint: dH (adjoints of the scaled outputs, [rows][ldh] at col0) -> dZ [rows][C]
+//   tangent rows: du = s' * dt * scale ; value rows: dz = s' * dh * scale + sum_k s'' * u_k * dt_k * scale
+__global__ void k_softplus_bwd(const float* __restrict__ Z, int ldz, int rows, int C, int P, float scale,
+                               const float* __restrict__ dH, int ldh, int col0, float* __restrict__ dZ, int lddz) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int vrows = P > 0 ? P : rows;
+    if (idx >= (long long)vrows * C) return;
+    const int r = (int)(idx / C), c = (int)(idx % C);
+    float h, d1, d2;
+    softplus_d012(Z[(size_t)r * ldz + c], h, d1, d2);
+    float dz = d1 * dH[(size_t)r * ldh + col0 + c] * scale;
+    if (P > 0) {
+#pragma unroll
+        for (int k = 1; k <= 3; ++k) {
+            const size_t rk = (size_t)(k * P + r);
+            const float dt = dH[rk * ldh + col0 + c] * scale;
+            dz += d2 * Z[rk * ldz + c] * dt;
+            dZ[rk * lddz + c] = d1 * dt;
+        }
+    }
+    dZ[(size_t)r * lddz + c] = dz;
+}
+
+__global__ void k_relu_bwd(const float* __restrict__ H, int ldh, long long n, int C, const float* __restrict__ dH, int lddh,
+                           float* __restrict__ dZ, int lddz) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const size_t r = idx / C;
+    const int c = (int)(idx % C);
+    dZ[r * lddz + c] = H[r * ldh + c] > 0.0f ? dH[r * lddh + c] : 0.0f;
+}
+
+// ---- normals + render-net input.  Z8 [4P][257]: col 0 = sdf (value rows) / d sdf (tangent rows), cols 1.. = features
+// XA [n][6] = [x_c (3), n (3)] (the colour net reads the 256 features in place from Z8);
+// n = normalize(normalize(g . Jinv), eps 1e-6)   (multiply.py:606, 661)
+__global__ void k_shade_in_fwd(const float* __restrict__ Z8, int P, int n_pts, const float* __restrict__ xc,
+                               const float* __restrict__ jinv, float* __restrict__ XR, float* __restrict__ nrm_out,
+                               float* __restrict__ sdf_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pts) return;
+    const int ld = 257;
+    const float g[3] = {Z8[(size_t)(P + i) * ld], Z8[(size_t)(2 * P + i) * ld], Z8[(size_t)(3 * P + i) * ld]};
+    const float* J = jinv + 9 * (size_t)i;
+    float v[3];
+    for (int j = 0; j < 3; ++j) v[j] = g[0] * J[j] + g[1] * J[3 + j] + g[2] * J[6 + j];
+    const float a = fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
+    float n1[3] = {v[0] / a, v[1] / a, v[2] / a};
+    const float b = fmaxf(sqrtf(n1[0] * n1[0] + n1[1] * n1[1] + n1[2] * n1[2]), 1e-6f);
+    float* o = XR + (size_t)i * 6;
+    for (int j = 0; j < 3; ++j) {
+        o[j] = xc[3 * (size_t)i + j];
+        o[3 + j] = n1[j] / b;
+        nrm_out[3 * (size_t)i + j] = n1[j] / b;
+    }
+    sdf_out[i] = Z8[(size_t)i * ld];
+}
+
+// adjoints: dXA [n][6] (from the colour net), dsdf [n] (from compositing), dnrm_extra [n][3] (direct normal losses, may
+// be null) -> column 0 of dZ8 [4P][257] (value rows: d sdf, tangent rows: d grad); the caller zero-fills dZ8 first and the
+// colour net's backward accumulates the feature adjoints into columns 1.. of the value rows
+__global__ void k_shade_in_bwd(const float* __restrict__ Z8, int P, int n_pts, const float* __restrict__ jinv,
+                               const float* __restrict__ dXR, const float* __restrict__ dsdf,
+                               const float* __restrict__ dnrm_extra, float* __restrict__ dZ8) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pts) return;
+    const int ld = 257;
+    const float g[3] = {Z8[(size_t)(P + i) * ld], Z8[(size_t)(2 * P + i) * ld], Z8[(size_t)(3 * P + i) * ld]};
+    const float* J = jinv + 9 * (size_t)i;
+    float v[3];
+    for (int j = 0; j < 3; ++j) v[j] = g[0] * J[j] + g[1] * J[3 + j] + g[2] * J[6 + j];
+    const float na = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const float a = fmaxf(na, 1e-12f);
+    const float n1[3] = {v[0] / a, v[1] / a, v[2] / a};
+    const float nb = sqrtf(n1[0] * n1[0] + n1[1] * n1[1] + n1[2] * n1[2]);
+    const float b = fmaxf(nb, 1e-6f);
+    const float n[3] = {n1[0] / b, n1[1] / b, n1[2] / b};
+    float dn[3];
+    for (int j = 0; j < 3; ++j) dn[j] = dXR[(size_t)i * 6 + 3 + j] + (dnrm_extra ? dnrm_extra[3 * (size_t)i + j] : 0.0f);
+    // n = n1 / max(|n1|, eps2)
+    float dn1[3];
+    {
+        const float dot = dn[0] * n[0] + dn[1] * n[1] + dn[2] * n[2];
+        for (int j = 0; j < 3; ++j) dn1[j] = nb > 1e-6f ? (dn[j] - n[j] * dot) / b : dn[j] / b;
+    }
+    // n1 = v / max(|v|, eps1)
+    float dv[3];
+    {
+        const float dot = dn1[0] * n1[0] + dn1[1] * n1[1] + dn1[2] * n1[2];
+        for (int j = 0; j < 3; ++j) dv[j] = na > 1e-12f ? (dn1[j] - n1[j] * dot) / a : dn1[j] / a;
+    }
+    for (int k = 0; k < 3; ++k)
+        dZ8[(size_t)((k + 1) * P + i) * ld] = dv[0] * J[3 * k] + dv[1] * J[3 * k + 1] + dv[2] * J[3 * k + 2];
+    dZ8[(size_t)i * ld] = dsdf[i];
+}
+
+// eikonal points: grad_theta [E][3] = d sdf / d x (raw); rows offset e0 inside the batch of P points
+__global__ void k_eik_fwd(const float* __restrict__ Z8, int P, int e0, int E, float* __restrict__ grad_theta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E) return;
+    for (int k = 0; k < 3; ++k) grad_theta[3 * (size_t)i + k] = Z8[(size_t)((k + 1) * P + e0 + i) * 257];
+}
+__global__ void k_eik_bwd(int P, int e0, int E, const float* __restrict__ dgrad, float* __restrict__ dZ8) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E) return;
+    for (int k = 1; k <= 3; ++k) dZ8[(size_t)(k * P + e0 + i) * 257] = dgrad[3 * (size_t)i + k - 1];
+}
+
+__global__ void k_sigmoid_fwd(const float* __restrict__ Z, long long n, float* __restrict__ Y) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) Y[i] = 1.0f / (1.0f + expf(-Z[i]));
+}
+__global__ void k_sigmoid_bwd(const float* __restrict__ Y, const float* __restrict__ dY, long long n, float* __restrict__ dZ) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dZ[i] = dY[i] * Y[i] * (1.0f - Y[i]);
+}
+
+// ---- weight norm: W = g v / |v|_row ; also the transposed copy used by the backward-data GEMMs
+__global__ __launch_bounds__(64) void k_wn_fwd(const float* __restrict__ v, const float* __restrict__ g, int out_dim,
+                                               int in_dim, float* __restrict__ W, float* __restrict__ WT) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    float ss = 0.f;
+    for (int c = lane; c < in_dim; c += 64) ss += v[(size_t)r * in_dim + c] * v[(size_t)r * in_dim + c];
+    ss = mp::wsum(ss);
+    const float s = g ? g[r] / sqrtf(ss) : 1.0f;
+    for (int c = lane; c < in_dim; c += 64) {
+        const float w = v[(size_t)r * in_dim + c] * s;
+        W[(size_t)r * in_dim + c] = w;
+        if (WT) WT[(size_t)c * out_dim + r] = w;
+    }
+}
+// dW -> dv, dg:  dg = dW . v / |v| ; dv = (g/|v|) (dW - (dW . v^) v^)
+__global__ __launch_bounds__(64) void k_wn_bwd(const float* __restrict__ v, const float* __restrict__ g, int out_dim,
+                                               int in_dim, const float* __restrict__ dW, float* __restrict__ dv,
+                                               float* __restrict__ dg) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    float ss = 0.f, dot = 0.f;
+    for (int c = lane; c < in_dim; c += 64) {
+        const float x = v[(size_t)r * in_dim + c];
+        ss += x * x;
+        dot += dW[(size_t)r * in_dim + c] * x;
+    }
+    ss = mp::wsum(ss);
+    dot = mp::wsum(dot);
+    const float nrm = sqrtf(ss);
+    if (!g) {
+        for (int c = lane; c < in_dim; c += 64) dv[(size_t)r * in_dim + c] = dW[(size_t)r * in_dim + c];
+        return;
+    }
+    const float gg = g[r];
+    for (int c = lane; c < in_dim; c += 64)
+        dv[(size_t)r * in_dim + c] = (gg / nrm) * (dW[(size_t)r * in_dim + c] - dot / ss * v[(size_t)r * in_dim + c]);
+    if (lane == 0) dg[r] = dot / nrm;
+}
+
+// hoisted conditioning: b2[r] = b[r] + sum_c W[r][c0+c] vec[c]   /  dW[r][c0+c] += db2[r] vec[c]
+__global__ __launch_bounds__(64) void k_hoist_fwd(const float* __restrict__ W, int in_dim, const float* __restrict__ b, int c0,
+                                                  int n, const float* __restrict__ vec, float* __restrict__ b2) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    float s = 0.f;
+    for (int c = lane; c < n; c += 64) s += W[(size_t)r * in_dim + c0 + c] * vec[c];
+    s = mp::wsum(s);
+    if (lane == 0) b2[r] = b[r] + s;
+}
+__global__ void k_hoist_bwd(const float* __restrict__ db2, int out_dim, int in_dim, int c0, int n,
+                            const float* __restrict__ vec, float* __restrict__ dW) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= out_dim * n) return;
+    const int r = idx / n, c = idx % n;
+    dW[(size_t)r * in_dim + c0 + c] += db2[r] * vec[c];
+}
+
+// column sums of the first `rows` rows: db[c] = sum_r dZ[r][c]
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dZ, int ld, int rows, int C, float* __restrict__ db) {
+    __shared__ float sh[4];
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int r = threadIdx.x; r < rows; r += 256) s += dZ[(size_t)r * ld + c];
+    s = mp::wsum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) db[c] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// ---- compositing backward (one thread per ray; forward: composite.hip)
+constexpr int MAX_P = 8;
+__global__ __launch_bounds__(256) void k_composite_bwd(
+    int n_rays, int P, int n_z, const int* const* __restrict__ inv_index, const float* const* __restrict__ z,
+    const float* const* __restrict__ sdf, const float* const* __restrict__ rgb, const float* __restrict__ beta_p,
+    const float* __restrict__ bg_rgb, const float* __restrict__ d_rgb_values, const float* __restrict__ d_acc,
+    const float* __restrict__ d_acc_person, float* const* __restrict__ d_sdf, float* const* __restrict__ d_rgb,
+    float* __restrict__ d_bg_rgb, float* __restrict__ d_beta) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    float dbeta_local = 0.0f;
+    if (r < n_rays) {
+        const int S = n_z - 1;
+        const float beta = *beta_p;
+        int k[MAX_P], cur[MAX_P];
+        for (int p = 0; p < MAX_P; ++p) { k[p] = p < P ? inv_index[p][r] : -1; cur[p] = 0; }
+        const float dC[3] = {d_rgb_values[3 * r], d_rgb_values[3 * r + 1], d_rgb_values[3 * r + 2]};
+        const float dA = d_acc ? d_acc[r] : 0.0f;
+        // pass 1 (ascending t_end): total free energy before the last sample, and T_bg
+        float E = 0.f, fe_last = 0.f;
+        int n_s = 0;
+        for (;;) {
+            int best = -1; float te = FLT_MAX;
+            for (int p = 0; p < MAX_P; ++p)
+                if (k[p] >= 0 && cur[p] < S) {
+                    const float t = z[p][(size_t)k[p] * n_z + cur[p] + 1];
+                    if (t < te) { te = t; best = p; }
+                }
+            if (best < 0) break;
+            const int i = cur[best];
+            const float ts = z[best][(size_t)k[best] * n_z + i];
+            fe_last = mp::laplace_density(sdf[best][(size_t)k[best] * S + i], beta) * (te - ts);
+            E += fe_last;
+            cur[best] = i + 1;
+            ++n_s;
+        }
+        const float E_excl_last = E - fe_last;          // exponent of T_bg (exclusive transmittance of the last sample)
+        const float Tbg = n_s ? expf(-E_excl_last) : 1.0f;
+        float dTbg = 0.f;
+        for (int a = 0; a < 3; ++a) {
+            const float bg = bg_rgb ? bg_rgb[3 * r + a] : 1.0f;
+            dTbg += dC[a] * bg;
+            if (d_bg_rgb) d_bg_rgb[3 * r + a] = dC[a] * Tbg;
+        }
+        // pass 2 (descending t_end): suffix sums
+        float Eafter = E;       // sum of fe over samples processed so far from the end, subtracted progressively
+        float suffix = 0.f;     // sum_{i > j} dw_i w_i
+        bool first = true;      // the very last sample
+        for (;;) {
+            int best = -1; float te = -FLT_MAX;
+            for (int p = MAX_P - 1; p >= 0; --p)   // ties: higher person last in ascending order -> first here
+                if (k[p] >= 0 && cur[p] > 0) {
+                    const float t = z[p][(size_t)k[p] * n_z + cur[p]];
+                    if (t > te) { te = t; best = p; }
+                }
+            if (best < 0) break;
+            const int p = best, i = cur[p] - 1;
+            const size_t q = (size_t)k[p] * S + i;
+            const float ts = z[p][(size_t)k[p] * n_z + i];
+            const float s = sdf[p][q];
+            const float dt = te - ts;
+            const float sig = mp::laplace_density(s, beta);
+            const float fe = sig * dt;
+            Eafter -= fe;                                // exclusive cumulative free energy of this sample
+            const float T = expf(-Eafter);
+            const float ex = expf(-fe);
+            const float alpha = 1.0f - ex;
+            const float w = alpha * T;
+            const float dw = dC[0] * rgb[p][3 * q] + dC[1] * rgb[p][3 * q + 1] + dC[2] * rgb[p][3 * q + 2] + dA +
+                             (d_acc_person ? d_acc_person[(size_t)r * P + p] : 0.0f);
+            float dfe = dw * T * ex - suffix;
+            if (!first) dfe -= dTbg * Tbg;              // T_bg depends on every sample but the last
+            const float dsig = dfe * dt;
+            // d sigma / d sdf and d sigma / d beta (density.py:20-29)
+            const float eab = expf(-fabsf(s) / beta);
+            const float dsdf = -(0.5f / (beta * beta)) * eab;
+            float dbe;
+            if (s > 0.f) dbe = (0.5f / (beta * beta)) * eab * (s / beta - 1.0f);
+            else if (s < 0.f) dbe = -1.0f / (beta * beta) + (0.5f / (beta * beta)) * eab * (1.0f + s / beta);
+            else dbe = -0.5f / (beta * beta);
+            d_sdf[p][q] = dsig * dsdf;
+            dbeta_local += dsig * dbe;
+            d_rgb[p][3 * q] = w * dC[0]; d_rgb[p][3 * q + 1] = w * dC[1]; d_rgb[p][3 * q + 2] = w * dC[2];
+            suffix += dw * w;
+            first = false;
+            cur[p] = i;
+        }
+    }
+    dbeta_local = mp::wsum(dbeta_local);
+    if ((threadIdx.x & 63) == 0 && dbeta_local != 0.0f) atomicAdd(d_beta, dbeta_local);
+}
+
+// ---- background compositing (multiply.py:682-696) forward with stash-free backward; one thread per ray
+__global__ void k_bg_comp_fwd(const float* __restrict__ sdf, const float* __restrict__ rgb, const float* __restrict__ zbg,
+                              int R, int NBG, float* __restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    float csum = 0.f, acc[3] = {0.f, 0.f, 0.f};
+    for (int i = 0; i < NBG; ++i) {
+        const float dist = i + 1 < NBG ? zbg[(size_t)r * NBG + i] - zbg[(size_t)r * NBG + i + 1] : 1e10f;
+        const float fe = dist * fabsf(sdf[(size_t)r * NBG + i]);
+        const float w = (1.0f - expf(-fe)) * expf(-csum);
+        for (int a = 0; a < 3; ++a) acc[a] += w * rgb[3 * ((size_t)r * NBG + i) + a];
+        csum += fe;
+    }
+    for (int a = 0; a < 3; ++a) out[3 * r + a] = acc[a];
+}
+__global__ void k_bg_comp_bwd(const float* __restrict__ sdf, const float* __restrict__ rgb, const float* __restrict__ zbg,
+                              int R, int NBG, const float* __restrict__ dout, float* __restrict__ dsdf,
+                              float* __restrict__ drgb) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    float E = 0.f;
+    for (int i = 0; i < NBG; ++i) {
+        const float dist = i + 1 < NBG ? zbg[(size_t)r * NBG + i] - zbg[(size_t)r * NBG + i + 1] : 1e10f;
+        E += dist * fabsf(sdf[(size_t)r * NBG + i]);
+    }
+    const float dC[3] = {dout[3 * r], dout[3 * r + 1], dout[3 * r + 2]};
+    float suffix = 0.f;
+    for (int i = NBG - 1; i >= 0; --i) {
+        const size_t q = (size_t)r * NBG + i;
+        const float dist = i + 1 < NBG ? zbg[q] - zbg[q + 1] : 1e10f;
+        const float s = sdf[q];
+        const float fe = dist * fabsf(s);
+        E -= fe;
+        const float T = expf(-E), ex = expf(-fe), w = (1.0f - ex) * T;
+        const float dw = dC[0] * rgb[3 * q] + dC[1] * rgb[3 * q + 1] + dC[2] * rgb[3 * q + 2];
+        const float dfe = dw * T * ex - suffix;
+        dsdf[q] = dfe * dist * (s > 0.f ? 1.0f : (s < 0.f ? -1.0f : 0.0f));
+        for (int a = 0; a < 3; ++a) drgb[3 * q + a] = w * dC[a];
+        suffix += dw * w;
+    }
+}
+
+// NeRF++ background points (multiply.py:698-726) as plain arrays: pts [R*NBG][4], per-ray depths zbg [R][NBG]
+__global__ void k_bg_points(const float* __restrict__ dirs, const float* __restrict__ cam, const float* __restrict__ zbg,
+                            int R, int NBG, float radius, float* __restrict__ pts) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (long long)R * NBG) return;
+    const int ray = (int)(q / NBG);
+    const float d[3] = {dirs[3 * ray], dirs[3 * ray + 1], dirs[3 * ray + 2]};
+    const float ox = cam[0], oy = cam[1], oz = cam[2];
+    const float depth = zbg[q];
+    const float o_dot_d = d[0] * ox + d[1] * oy + d[2] * oz;
+    const float under = o_dot_d * o_dot_d - ((ox * ox + oy * oy + oz * oz) - radius * radius);
+    const float d_sphere = sqrtf(under) - o_dot_d;
+    const float ps[3] = {ox + d_sphere * d[0], oy + d_sphere * d[1], oz + d_sphere * d[2]};
+    const float pm[3] = {ox - o_dot_d * d[0], oy - o_dot_d * d[1], oz - o_dot_d * d[2]};
+    const float pm_n = sqrtf(pm[0] * pm[0] + pm[1] * pm[1] + pm[2] * pm[2]);
+    float ax[3] = {oy * ps[2] - oz * ps[1], oz * ps[0] - ox * ps[2], ox * ps[1] - oy * ps[0]};
+    const float an = sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+    ax[0] /= an; ax[1] /= an; ax[2] /= an;
+    const float phi = asinf(pm_n / radius), theta = asinf(pm_n * depth);
+    float sa, ca;
+    sincosf(phi - theta, &sa, &ca);
+    const float cr[3] = {ax[1] * ps[2] - ax[2] * ps[1], ax[2] * ps[0] - ax[0] * ps[2], ax[0] * ps[1] - ax[1] * ps[0]};
+    const float adp = ax[0] * ps[0] + ax[1] * ps[1] + ax[2] * ps[2];
+    float pn[3];
+    for (int a = 0; a < 3; ++a) pn[a] = ps[a] * ca + cr[a] * sa + ax[a] * adp * (1.0f - ca);
+    const float pnn = sqrtf(pn[0] * pn[0] + pn[1] * pn[1] + pn[2] * pn[2]);
+    for (int a = 0; a < 3; ++a) pts[4 * q + a] = pn[a] / pnn;
+    pts[4 * q + 3] = depth;
+}
+
+__global__ void k_copy_cols(const float* __restrict__ src, int lds, int c0s, float* __restrict__ dst, int ldd, int c0d,
+                            long long rows, int C, float scale, int accumulate) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * C) return;
+    const size_t r = idx / C;
+    const int c = (int)(idx % C);
+    const float v = src[r * lds + c0s + c] * scale;
+    float* d = dst + r * ldd + c0d + c;
+    *d = accumulate ? *d + v : v;
+}
+
+}  // namespace
+
+#define ST (hipStream_t) stream
+extern "C" {
+
+int mp_tr_pe(const float* x, int d_in, int P, int L, int fwd, float scale, float* out, int ld, int col0, void* stream) {
+    if (P <= 0) return 0;
+    if (d_in == 3) hipLaunchKernelGGL(k_pe_fwd<3>, grid1(P), dim3(TB), 0, ST, x, P, L, fwd, scale, out, ld, col0);
+    else if (d_in == 4) hipLaunchKernelGGL(k_pe_fwd<4>, grid1(P), dim3(TB), 0, ST, x, P, L, fwd, scale, out, ld, col0);
+    else return -1;
+    return (int)hipGetLastError();
+}
+int mp_tr_softplus_fwd(const float* Z, int ldz, int rows, int C, int P, float scale, float* H, int ldh, int col0,
+                       void* stream) {
+    hipLaunchKernelGGL(k_softplus_fwd, grid1((long long)rows * C), dim3(TB), 0, ST, Z, ldz, rows, C, P, scale, H, ldh, col0);
+    return (int)hipGetLastError();
+}
+int mp_tr_softplus_bwd(const float* Z, int ldz, int rows, int C, int P, float scale, const float* dH, int ldh, int col0,
+                       float* dZ, int lddz, void* stream) {
+    const int vrows = P > 0 ? P : rows;
+    hipLaunchKernelGGL(k_softplus_bwd, grid1((long long)vrows * C), dim3(TB), 0, ST, Z, ldz, rows, C, P, scale, dH, ldh, col0,
+                       dZ, lddz);
+    return (int)hipGetLastError();
+}
+int mp_tr_relu_bwd(const float* H, int ldh, int rows, int C, const float* dH, int lddh, float* dZ, int lddz, void* stream) {
+    hipLaunchKernelGGL(k_relu_bwd, grid1((long long)rows * C), dim3(TB), 0, ST, H, ldh, (long long)rows * C, C, dH, lddh, dZ,
+                       lddz);
+    return (int)hipGetLastError();
+}
+int mp_tr_shade_in_fwd(const float* Z8, int P, int n_pts, const float* xc, const float* jinv, float* XR, float* nrm,
+                       float* sdf, void* stream) {
+    if (n_pts <= 0) return 0;
+    hipLaunchKernelGGL(k_shade_in_fwd, grid1(n_pts), dim3(TB), 0, ST, Z8, P, n_pts, xc, jinv, XR, nrm, sdf);
+    return (int)hipGetLastError();
+}
+int mp_tr_shade_in_bwd(const float* Z8, int P, int n_pts, const float* jinv, const float* dXR, const float* dsdf,
+                       const float* dnrm_extra, float* dZ8, void* stream) {
+    if (n_pts <= 0) return 0;
+    hipLaunchKernelGGL(k_shade_in_bwd, grid1(n_pts), dim3(TB), 0, ST, Z8, P, n_pts, jinv, dXR, dsdf, dnrm_extra, dZ8);
+    return (int)hipGetLastError();
+}
+int mp_tr_eik_fwd(const float* Z8, int P, int e0, int E, float* grad_theta, void* stream) {
+    if (E <= 0) return 0;
+    hipLaunchKernelGGL(k_eik_fwd, grid1(E), dim3(TB), 0, ST, Z8, P, e0, E, grad_theta);
+    return (int)hipGetLastError();
+}
+int mp_tr_eik_bwd(int P, int e0, int E, const float* dgrad, float* dZ8, void* stream) {
+    if (E <= 0) return 0;
+    hipLaunchKernelGGL(k_eik_bwd, grid1(E), dim3(TB), 0, ST, P, e0, E, dgrad, dZ8);
+    return (int)hipGetLastError();
+}
+int mp_tr_sigmoid_fwd(const float* Z, long long n, float* Y, void* stream) {
+    hipLaunchKernelGGL(k_sigmoid_fwd, grid1(n), dim3(TB), 0, ST, Z, n, Y);
+    return (int)hipGetLastError();
+}
+int mp_tr_sigmoid_bwd(const float* Y, const float* dY, long long n, float* dZ, void* stream) {
+    hipLaunchKernelGGL(k_sigmoid_bwd, grid1(n), dim3(TB), 0, ST, Y, dY, n, dZ);
+    return (int)hipGetLastError();
+}
+int mp_tr_wn_fwd(const float* v, const float* g, int out_dim, int in_dim, float* W, float* WT, void* stream) {
+    hipLaunchKernelGGL(k_wn_fwd, dim3(out_dim), dim3(64), 0, ST, v, g, out_dim, in_dim, W, WT);
+    return (int)hipGetLastError();
+}
+int mp_tr_wn_bwd(const float* v, const float* g, int out_dim, int in_dim, const float* dW, float* dv, float* dg,
+                 void* stream) {
+    hipLaunchKernelGGL(k_wn_bwd, dim3(out_dim), dim3(64), 0, ST, v, g, out_dim, in_dim, dW, dv, dg);
+    return (int)hipGetLastError();
+}
+int mp_tr_hoist_fwd(const float* W, int out_dim, int in_dim, const float* b, int c0, int n, const float* vec, float* b2,
+                    void* stream) {
+    hipLaunchKernelGGL(k_hoist_fwd, dim3(out_dim), dim3(64), 0, ST, W, in_dim, b, c0, n, vec, b2);
+    return (int)hipGetLastError();
+}
+int mp_tr_hoist_bwd(const float* db2, int out_dim, int in_dim, int c0, int n, const float* vec, float* dW, void* stream) {
+    hipLaunchKernelGGL(k_hoist_bwd, grid1((long long)out_dim * n), dim3(TB), 0, ST, db2, out_dim, in_dim, c0, n, vec, dW);
+    return (int)hipGetLastError();
+}
+int mp_tr_colsum(const float* dZ, int ld, int rows, int C, float* db, void* stream) {
+    hipLaunchKernelGGL(k_colsum, dim3(C), dim3(256), 0, ST, dZ, ld, rows, C, db);
+    return (int)hipGetLastError();
+}
+int mp_tr_composite_bwd(int n_rays, int n_person, int n_z, const int* const* inv_index, const float* const* z,
+                        const float* const* sdf, const float* const* rgb, const float* beta, const float* bg_rgb,
+                        const float* d_rgb_values, const float* d_acc, const float* d_acc_person, float* const* d_sdf,
+                        float* const* d_rgb, float* d_bg_rgb, float* d_beta, void* stream) {
+    if (n_person > MAX_P) return -1;
+    if (n_rays <= 0) return 0;
+    hipLaunchKernelGGL(k_composite_bwd, grid1(n_rays), dim3(TB), 0, ST, n_rays, n_person, n_z, inv_index, z, sdf, rgb, beta,
+                       bg_rgb, d_rgb_values, d_acc, d_acc_person, d_sdf, d_rgb, d_bg_rgb, d_beta);
+    return (int)hipGetLastError();
+}
+int mp_tr_bg_points(const float* dirs, const float* cam, const float* zbg, int R, int NBG, float radius, float* pts,
+                    void* stream) {
+    hipLaunchKernelGGL(k_bg_points, grid1((long long)R * NBG), dim3(TB), 0, ST, dirs, cam, zbg, R, NBG, radius, pts);
+    return (int)hipGetLastError();
+}
+int mp_tr_bg_comp_fwd(const float* sdf, const float* rgb, const float* zbg, int R, int NBG, float* out, void* stream) {
+    hipLaunchKernelGGL(k_bg_comp_fwd, grid1(R), dim3(TB), 0, ST, sdf, rgb, zbg, R, NBG, out);
+    return (int)hipGetLastError();
+}
+int mp_tr_bg_comp_bwd(const float* sdf, const float* rgb, const float* zbg, int R, int NBG, const float* dout, float* dsdf,
+                      float* drgb, void* stream) {
+    hipLaunchKernelGGL(k_bg_comp_bwd, grid1(R), dim3(TB), 0, ST, sdf, rgb, zbg, R, NBG, dout, dsdf, drgb);
+    return (int)hipGetLastError();
+}
+int mp_tr_copy_cols(const float* src, int lds, int c0s, float* dst, int ldd, int c0d, long long rows, int C, float scale,
+                    int accumulate, void* stream) {
+    hipLaunchKernelGGL(k_copy_cols, grid1(rows * C), dim3(TB), 0, ST, src, lds, c0s, dst, ldd, c0d, rows, C, scale, accumulate);
+    return (int)hipGetLastError();
+}
+}

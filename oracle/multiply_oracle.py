@@ -403,6 +403,8 @@ def error_bound_sample(cfg, dirs, cam, sdf_fn, beta0, draws=None):
     if cfg.N_samples_extra > 0:
         if draws is not None:
             sidx = draws["extra_idx"]
+            if sidx.dim() == 2:          # one row per possible list length n = N_eval * k
+                sidx = sidx[z_vals.shape[1] // cfg.N_samples_eval - 1]
         else:
             sidx = torch.linspace(0, z_vals.shape[1] - 1, cfg.N_samples_extra).long()
         extra = torch.cat([near, far, z_vals[:, sidx]], -1)
