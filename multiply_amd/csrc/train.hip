@@ -366,11 +366,11 @@ __global__ void k_bg_comp_bwd(const float* __restrict__ sdf, const float* __rest
                               float* __restrict__ drgb) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
+    // E = free energy in front of sample i; starts at the last sample (whose own 1e10-long interval must never enter the
+    // running sum: it would swallow every other term in fp32)
     float E = 0.f;
-    for (int i = 0; i < NBG; ++i) {
-        const float dist = i + 1 < NBG ? zbg[(size_t)r * NBG + i] - zbg[(size_t)r * NBG + i + 1] : 1e10f;
-        E += dist * fabsf(sdf[(size_t)r * NBG + i]);
-    }
+    for (int i = 0; i + 1 < NBG; ++i)
+        E += (zbg[(size_t)r * NBG + i] - zbg[(size_t)r * NBG + i + 1]) * fabsf(sdf[(size_t)r * NBG + i]);
     const float dC[3] = {dout[3 * r], dout[3 * r + 1], dout[3 * r + 2]};
     float suffix = 0.f;
     for (int i = NBG - 1; i >= 0; --i) {
@@ -378,7 +378,7 @@ __global__ void k_bg_comp_bwd(const float* __restrict__ sdf, const float* __rest
         const float dist = i + 1 < NBG ? zbg[q] - zbg[q + 1] : 1e10f;
         const float s = sdf[q];
         const float fe = dist * fabsf(s);
-        E -= fe;
+        if (i + 1 < NBG) E -= fe;
         const float T = expf(-E), ex = expf(-fe), w = (1.0f - ex) * T;
         const float dw = dC[0] * rgb[3 * q] + dC[1] * rgb[3 * q + 1] + dC[2] * rgb[3 * q + 2];
         const float dfe = dw * T * ex - suffix;

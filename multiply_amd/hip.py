@@ -51,8 +51,41 @@ def lib():
             raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                                f"g.build()'` (hipcc --offload-arch=gfx950). The MultiPly hot path has no fallback.")
         _lib = C.CDLL(LIB_PATH)
-        _lib.mp_arch.restype = C.c_char_p
+        _declare_prototypes(_lib)
     return _lib
+
+
+HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "multiply_hip.h")
+
+
+def header_prototypes(path=HEADER_PATH):
+    """{name: (restype, [argtypes])} parsed from include/multiply_hip.h -- the header is the single source of truth
+    for the C ABI; scalars map to their exact ctypes width (a `long long` or `float` passed as a default Python int /
+    double would otherwise be widened or truncated by ctypes' default conversions), every pointer to c_void_p."""
+    import re
+    with open(path) as f:
+        txt = re.sub(r"/\*.*?\*/", " ", f.read(), flags=re.S)
+    txt = re.sub(r"//[^\n]*", " ", txt)
+    scal = {"int": C.c_int, "float": C.c_float, "long long": C.c_longlong, "unsigned": C.c_uint, "void": None}
+    protos = {}
+    for ret, name, args in re.findall(r"\b(int|void|const char\s*\*)\s+(mp_[a-z_0-9]+)\s*\(([^)]*)\)\s*;", txt):
+        at = []
+        for a in [x.strip() for x in args.split(",")]:
+            if a in ("void", ""):
+                continue
+            if "*" in a:
+                at.append(C.c_void_p)
+            else:
+                ty = re.sub(r"\bconst\b", "", a).strip().rsplit(" ", 1)[0].strip()
+                at.append(scal[ty])
+        protos[name] = (C.c_char_p if "char" in ret else (None if ret == "void" else C.c_int), at)
+    return protos
+
+
+def _declare_prototypes(l):
+    for name, (rt, at) in header_prototypes().items():
+        fn = getattr(l, name)
+        fn.restype, fn.argtypes = rt, at
 
 
 def require_device():

@@ -1,0 +1,140 @@
+"""Training objective (reference code/lib/model/loss.py:6-177), same constructor keys, same output dict.
+
+These are a handful of reductions over <= 512 rays / 1024 eikonal points, so they are plain torch ops; their autograd
+adjoints (d rgb_values, d acc_map, d acc_person_list, d grad_theta) are what `Multiply.forward`'s hand-written
+backward (multiply_amd/train.py) consumes.  Terms:
+
+  rgb_loss       mean |rgb - gt| over rays without NaN                                  (loss.py:31-33, 120-122)
+  eikonal_loss   mean (|grad_theta| - 1)^2                                              (loss.py:36-38)
+  bce_loss       -2 mean(a log(a+eps) + (1-a) log(1-a+eps)),  zeroed if NaN            (loss.py:41-43, 124-128)
+  in_shape_loss  mean |acc[index_in_surface] - 1|, weight fades to 0 at epoch 200       (loss.py:51-53, 131-139, 161)
+  sam_mask_loss  clipped L1 between acc_person and sigmoid(sam logits)                  (loss.py:61-78, 143-146)
+  temporal/smpl_surface/zero_pose/depth_order: passed through with their schedules     (loss.py:141-158)
+"""
+import torch
+from torch import nn
+
+
+def _get(opt, key, default):
+    try:
+        return opt.get(key, default)
+    except AttributeError:
+        return getattr(opt, key, default)
+
+
+class Loss(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        for key in ("eikonal_weight", "bce_weight", "opacity_sparse_weight", "in_shape_weight", "sam_mask_weight",
+                    "smpl_surface_milestone"):
+            setattr(self, key, opt[key] if isinstance(opt, dict) else getattr(opt, key))
+        self.smpl_surface_weight = _get(opt, "smpl_surface_weight", 0)
+        self.zero_pose_weight = _get(opt, "zero_pose_weight", 0)
+        self.sam_start_epoch = _get(opt, "sam_start_epoch", 200)
+        self.increase_sam = _get(opt, "increase_sam", False)
+        self.temporal_loss_weight = _get(opt, "temporal_loss_weight", 1.0)
+        self.eps = 1e-6
+        self.milestone = 200
+        self.sam_milestone = 1000
+        self.depth_loss_milestone = 1000
+
+    # -- individual terms (names kept: the reference's trainer logs them one by one)
+    def get_rgb_loss(self, rgb_values, rgb_gt):
+        return (rgb_values - rgb_gt).abs().mean()
+
+    def get_eikonal_loss(self, grad_theta):
+        return (grad_theta.norm(2, dim=-1) - 1).square().mean()
+
+    def get_bce_los(self, acc_map):
+        a = acc_map
+        return -2.0 * (a * (a + self.eps).log() + (1 - a) * (1 - a + self.eps).log()).mean()
+
+    def get_opacity_sparse(self, acc_map, index_off_surface):
+        return acc_map[index_off_surface].abs().mean()
+
+    def get_in_shape_loss(self, acc_map, index_in_surface):
+        return (acc_map[index_in_surface] - 1).abs().mean()
+
+    def get_sam_mask_loss(self, sam_mask, acc_person):
+        prob = torch.sigmoid(sam_mask)
+        ok = prob.sum(dim=1) <= 1.01
+        return (acc_person[ok] - prob[ok]).abs().mean()
+
+    def get_sam_mask_clip_loss(self, sam_mask, acc_person):
+        n_ray, n_person = sam_mask.shape[0], sam_mask.shape[1]
+        prob = torch.sigmoid(sam_mask)
+        ok = prob.sum(dim=1) <= 1.01                       # rays whose SAM masks do not overlap
+        a, m = acc_person[ok].reshape(-1), prob[ok].reshape(-1)
+        agree = ((a < 0.04) & (m < 0.04)) | ((a > 0.96) & (m > 0.96))
+        keep = ~agree
+        if keep.sum() == 0:
+            print("clip_mask is all False")
+            keep[0] = True
+        return (a[keep] - m[keep]).abs().sum() / (n_ray * n_person)
+
+    def get_depth_order_loss_samGT(self, t_list, mean_hitted_vertex_list, sam_mask, cam_loc):
+        import numpy as np
+        front = np.argmin(t_list, axis=0)
+        correct = np.argmax(sam_mask.cpu().numpy(), axis=1)
+        cols = torch.arange(mean_hitted_vertex_list.shape[1])
+        d_front = (mean_hitted_vertex_list[front, cols, :] - cam_loc).norm(dim=-1)
+        d_correct = (mean_hitted_vertex_list[correct, cols, :] - cam_loc).norm(dim=-1)
+        return torch.log(1 + torch.exp(d_correct - d_front)).sum()
+
+    def forward(self, model_outputs, ground_truth):
+        mo = model_outputs
+        dev = mo["acc_map"].device
+        zero = lambda: torch.zeros(1, device=dev)
+        epoch = mo["epoch"]
+
+        if isinstance(mo["fg_rgb_values_each_person_list"], list):        # loss.py:109-110 (always, for this model)
+            depth_order_loss = zero()
+        else:
+            sam = mo["sam_mask"][mo["hitted_mask_idx"]]
+            depth_order_loss = self.get_depth_order_loss_samGT(mo["t_list"], mo["mean_hitted_vertex_list"], sam,
+                                                               mo["cam_loc"][mo["hitted_mask_idx"]])
+
+        finite = ~torch.any(mo["rgb_values"].isnan(), dim=1)
+        rgb_gt = ground_truth["rgb"][0].to(dev)
+        rgb_loss = self.get_rgb_loss(mo["rgb_values"][finite], rgb_gt[finite])
+        eikonal_loss = self.get_eikonal_loss(mo["grad_theta"])
+        bce_loss = self.get_bce_los(mo["acc_map"])
+        if bce_loss.isnan():
+            print("Nan: bce_loss")
+            bce_loss = zero()
+        opacity_sparse_loss = zero()
+        if mo["index_in_surface"] is not None:
+            in_shape_loss = self.get_in_shape_loss(mo["acc_map"], mo["index_in_surface"])
+        else:
+            in_shape_loss = zero()
+        if in_shape_loss.isnan():
+            print("Nan: in_shape_loss")
+            in_shape_loss = zero()
+
+        e200 = min(self.milestone, epoch)
+        temporal_loss = mo["temporal_loss"]
+        smpl_surface_loss = mo["smpl_surface_loss"] * self.smpl_surface_weight
+        if "sam_mask" in mo and epoch >= self.sam_start_epoch:
+            sam_mask_loss = self.get_sam_mask_clip_loss(mo["sam_mask"], mo["acc_person_list"])
+        else:
+            sam_mask_loss = zero()
+        if epoch >= self.sam_start_epoch:
+            depth_order_loss = depth_order_loss * (1 - min(self.depth_loss_milestone, epoch) / self.depth_loss_milestone)
+        else:
+            depth_order_loss = zero()
+        zero_pose_loss = mo["zero_pose_loss"] * self.zero_pose_weight * (1 - min(1000, epoch) / 1000)
+        sam_ramp = min(1.0, epoch / 100) if self.increase_sam else 1.0
+
+        loss = (rgb_loss
+                + self.eikonal_weight * eikonal_loss
+                + self.bce_weight * bce_loss
+                + self.opacity_sparse_weight * (1 + e200 ** 2 / 40) * opacity_sparse_loss
+                + self.in_shape_weight * (1 - e200 / self.milestone) * in_shape_loss
+                + self.temporal_loss_weight * temporal_loss
+                + self.sam_mask_weight * sam_ramp * sam_mask_loss
+                + smpl_surface_loss * (1 - min(self.smpl_surface_milestone, epoch) / self.smpl_surface_milestone)
+                + depth_order_loss + zero_pose_loss)
+        return {"loss": loss, "rgb_loss": rgb_loss, "depth_order_loss": depth_order_loss, "eikonal_loss": eikonal_loss,
+                "bce_loss": bce_loss, "opacity_sparse_loss": opacity_sparse_loss, "in_shape_loss": in_shape_loss,
+                "temporal_loss": temporal_loss, "sam_mask_loss": sam_mask_loss, "smpl_surface_loss": smpl_surface_loss,
+                "zero_pose_loss": mo["zero_pose_loss"]}

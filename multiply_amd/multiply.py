@@ -135,11 +135,14 @@ class Multiply(nn.Module):
 
     def forward(self, input, id=-1, cond_zero_shit=False, canonical_pose=False):
         if self.training:
-            raise NotImplementedError("training-mode forward/backward kernels are not implemented yet (DESIGN.md §scope)")
+            from . import train
+            return train.forward_train(self, input, id, cond_zero_shit, canonical_pose)
         with torch.no_grad():
             return self._forward_eval(input, id, canonical_pose)
 
-    def _forward_eval(self, input, id, canonical_pose):
+    def _setup(self, input, id, canonical_pose):
+        """Rays, SMPL posing, nearest-vertex structures and the box cull for every person of the call
+        (multiply.py:177-266).  Ends with the one host sync of the call (hit counts size the workspaces)."""
         L = hip.lib()
         dev = self.density.beta.device
         f32 = dict(dtype=torch.float32, device=dev)
@@ -149,20 +152,14 @@ class Multiply(nn.Module):
         R = uv.shape[0]
         K = input["intrinsics"].to(dev).float().reshape(16).contiguous()
         pose = input["pose"].to(dev).float().reshape(16).contiguous()
-        smpl_params = input["smpl_params"].to(dev).float()
-        smpl_pose = input["smpl_pose"].to(dev).float()
-        smpl_shape = input["smpl_shape"].to(dev).float()
-        smpl_trans = input["smpl_trans"].to(dev).float()
+        smpl_params = input["smpl_params"].detach().to(dev).float()
+        smpl_pose = input["smpl_pose"].detach().to(dev).float()
+        smpl_shape = input["smpl_shape"].detach().to(dev).float()
+        smpl_trans = input["smpl_trans"].detach().to(dev).float()
         P = smpl_trans.shape[1]
         persons = list(range(P)) if id == -1 else [id]
         rs = self.ray_sampler
-        cfg = self._sampler_cfg()
-        NE, NS, NX = rs.N_samples_eval, rs.N_samples, rs.N_samples_extra
-        NZ = NS + NX + 2
-        S = NZ - 1
-        ZM = NE * rs.max_total_iters
         group = int(self.convergence_group or R)
-        n_groups = (R + group - 1) // group
         beta = (self.density.beta.detach().abs() + self.density.beta_min).reshape(1).float().contiguous()
 
         # rays (rend_util.get_camera_params)
@@ -206,10 +203,88 @@ class Multiply(nn.Module):
                 hip.check(L.mp_ray_cull(hip.ptr(dirs), hip.ptr(pose), hip.ptr(obb), R, group, hip.ptr(hit_index),
                                         hip.ptr(counts[n:n + 1]), hip.ptr(inv_index), hip.ptr(scan_tmp), st),
                           "mp_ray_cull")
-            cond = (smpl_pose[0, p, 3:] / np.pi).contiguous()          # multiply.py:270 (eval: never zeroed)
+            cond = (smpl_pose[0, p, 3:] / np.pi).contiguous()          # multiply.py:270
             per[p] = dict(verts=verts, tfs=tfs, vsorted=vsorted, cbound=cbound, hit_index=hit_index,
                           inv_index=inv_index, count=counts[n:n + 1], cond=cond)
         n_hit = counts.tolist()          # the one host sync of the call: sizes the per-person workspaces
+        return dict(dev=dev, R=R, uv=uv, K=K, pose=pose, dirs=dirs, far=far, per=per, persons=persons, n_hit=n_hit,
+                    group=group, beta=beta, counts=counts)
+
+    def _sample_person(self, cx, n, p, draws=None):
+        """ErrorBoundSampler.get_z_vals for person p's rays (ray_sampler.py:66-220): returns zfinal [R_p][N+N_extra+2],
+        the iteration counters and the per-iteration SDF worklist counts.  draws = None: eval-mode determinism;
+        else the training randomness {t_rand [R_p,NE], u_final [R_p,N], extra_idx [max_iters,N_extra] int32}."""
+        L = hip.lib()
+        dev = cx["dev"]
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        st = hip.stream()
+        rs = self.ray_sampler
+        cfg = self._sampler_cfg()
+        NE, NS, NX = rs.N_samples_eval, rs.N_samples, rs.N_samples_extra
+        NZ = NS + NX + 2
+        ZM = NE * rs.max_total_iters
+        R, group = cx["R"], cx["group"]
+        n_groups = (R + group - 1) // group
+        dirs, far, pose, beta = cx["dirs"], cx["far"], cx["pose"], cx["beta"]
+        pp = cx["per"][p]
+        Rp = max(int(cx["n_hit"][n]), 1)
+        imp = self.foreground_implicit_network_list[p]
+        skin_w = self.smpl_server_list[p].tables.lbs_weights
+        pk_sdf = hip.packed(imp, "sdf", 2)
+        pk_sdf.refresh(pp["cond"])
+        zs = torch.empty(Rp, ZM, **f32); sdfs = torch.empty(Rp, ZM, **f32)
+        nz = torch.empty(Rp, **i32); znew = torch.empty(Rp, NE, **f32); sdfnew = torch.empty(Rp, NE, **f32)
+        betar = torch.empty(Rp, **f32); active = torch.empty(Rp, **i32)
+        gflag = torch.empty((rs.max_total_iters + 1) * n_groups, **i32)
+        zfinal = torch.empty(Rp, NZ, **f32); iters = torch.zeros(n_groups, **i32)
+        any_active = torch.zeros(rs.max_total_iters + 1, **i32)
+        state = hip.MpSamplerState(zs.data_ptr(), sdfs.data_ptr(), nz.data_ptr(), znew.data_ptr(),
+                                   sdfnew.data_ptr(), betar.data_ptr(), active.data_ptr(), gflag.data_ptr(),
+                                   zfinal.data_ptr(), iters.data_ptr(), any_active.data_ptr())
+        train = draws is not None
+        t_rand = hip.ptr(draws["t_rand"]) if train else None
+        u_final = hip.ptr(draws["u_final"]) if train else None
+        extra_idx = hip.ptr(draws["extra_idx"]) if train else None
+        hip.check(L.mp_sampler_init(C.byref(cfg), C.byref(state), hip.ptr(far), hip.ptr(pp["hit_index"]),
+                                    hip.ptr(pp["count"]), Rp, group, R, t_rand, st), "mp_sampler_init")
+        xc_new = torch.empty(Rp * NE, 3, **f32)
+        work = torch.empty(Rp * NE, **i32)
+        wcount = torch.zeros(rs.max_total_iters + 1, **i32)
+        for it in range(rs.max_total_iters):
+            with self._ph("sampler_warp"):
+                hip.check(L.mp_warp_inverse(None, hip.ptr(dirs), hip.ptr(pose), hip.ptr(pp["hit_index"]),
+                                            hip.ptr(pp["count"]), hip.ptr(znew), NE, NE, Rp, hip.ptr(pp["vsorted"]),
+                                            hip.ptr(pp["cbound"]), hip.ptr(skin_w), hip.ptr(pp["tfs"]),
+                                            0 if train else 1,
+                                            hip.ptr(active), hip.ptr(any_active[it:it + 1]), hip.ptr(xc_new), None,
+                                            hip.ptr(sdfnew), hip.ptr(work),
+                                            hip.ptr(wcount[it:it + 1]), st), "mp_warp_inverse")
+            with self._ph("sampler_mlp_sdf"):
+                hip.check(L.mp_mlp_sdf(C.byref(pk_sdf.net), hip.ptr(pk_sdf.wpack), hip.ptr(pk_sdf.bias),
+                                       hip.ptr(xc_new), hip.ptr(work), hip.ptr(wcount[it:it + 1]), Rp * NE,
+                                       hip.ptr(sdfnew), st), "mp_mlp_sdf")
+            with self._ph("sampler_bound"):
+                hip.check(L.mp_sampler_bound(C.byref(cfg), C.byref(state), hip.ptr(beta), hip.ptr(pp["hit_index"]),
+                                             hip.ptr(pp["count"]), Rp, group, R, it, st), "mp_sampler_bound")
+            with self._ph("sampler_resample"):
+                hip.check(L.mp_sampler_resample(C.byref(cfg), C.byref(state), hip.ptr(beta), hip.ptr(far),
+                                                hip.ptr(pp["hit_index"]), hip.ptr(pp["count"]), Rp, group, R, it,
+                                                u_final, extra_idx, st), "mp_sampler_resample")
+        pp["_sampler_keep"] = (zs, sdfs, nz, znew, sdfnew, betar, active, gflag, any_active, xc_new, work, draws)
+        return zfinal, iters, wcount
+
+    def _forward_eval(self, input, id, canonical_pose):
+        L = hip.lib()
+        cx = self._setup(input, id, canonical_pose)
+        dev, R, dirs, far, pose, beta = cx["dev"], cx["R"], cx["dirs"], cx["far"], cx["pose"], cx["beta"]
+        per, persons, n_hit = cx["per"], cx["persons"], cx["n_hit"]
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        st = hip.stream()
+        rs = self.ray_sampler
+        NZ = rs.N_samples + rs.N_samples_extra + 2
+        S = NZ - 1
         stats = {"n_hit": n_hit, "iters": [], "n_sdf_evals": [], "n_shaded": []}
 
         z_l, sdf_l, rgb_l, nrm_l, inv_l = [], [], [], [], []
@@ -219,42 +294,7 @@ class Multiply(nn.Module):
             imp, ren, dfm = self.foreground_implicit_network_list[p], self.foreground_rendering_network_list[p], \
                 self.deformer_list[p]
             skin_w = self.smpl_server_list[p].tables.lbs_weights
-            pk_sdf = hip.packed(imp, "sdf", 2)
-            pk_sdf.refresh(pp["cond"])
-            # ---- sampler state
-            zs = torch.empty(Rp, ZM, **f32); sdfs = torch.empty(Rp, ZM, **f32)
-            nz = torch.empty(Rp, **i32); znew = torch.empty(Rp, NE, **f32); sdfnew = torch.empty(Rp, NE, **f32)
-            betar = torch.empty(Rp, **f32); active = torch.empty(Rp, **i32)
-            gflag = torch.empty((rs.max_total_iters + 1) * n_groups, **i32)
-            zfinal = torch.empty(Rp, NZ, **f32); iters = torch.zeros(n_groups, **i32)
-            any_active = torch.zeros(rs.max_total_iters + 1, **i32)
-            state = hip.MpSamplerState(zs.data_ptr(), sdfs.data_ptr(), nz.data_ptr(), znew.data_ptr(),
-                                       sdfnew.data_ptr(), betar.data_ptr(), active.data_ptr(), gflag.data_ptr(),
-                                       zfinal.data_ptr(), iters.data_ptr(), any_active.data_ptr())
-            hip.check(L.mp_sampler_init(C.byref(cfg), C.byref(state), hip.ptr(far), hip.ptr(pp["hit_index"]),
-                                        hip.ptr(pp["count"]), Rp, group, R, None, st), "mp_sampler_init")
-            xc_new = torch.empty(Rp * NE, 3, **f32)
-            work = torch.empty(Rp * NE, **i32)
-            wcount = torch.zeros(rs.max_total_iters + 1, **i32)
-            for it in range(rs.max_total_iters):
-                with self._ph("sampler_warp"):
-                    hip.check(L.mp_warp_inverse(None, hip.ptr(dirs), hip.ptr(pose), hip.ptr(pp["hit_index"]),
-                                                hip.ptr(pp["count"]), hip.ptr(znew), NE, NE, Rp, hip.ptr(pp["vsorted"]),
-                                                hip.ptr(pp["cbound"]), hip.ptr(skin_w), hip.ptr(pp["tfs"]), 1,
-                                                hip.ptr(active), hip.ptr(any_active[it:it + 1]), hip.ptr(xc_new), None,
-                                                hip.ptr(sdfnew), hip.ptr(work),
-                                                hip.ptr(wcount[it:it + 1]), st), "mp_warp_inverse")
-                with self._ph("sampler_mlp_sdf"):
-                    hip.check(L.mp_mlp_sdf(C.byref(pk_sdf.net), hip.ptr(pk_sdf.wpack), hip.ptr(pk_sdf.bias),
-                                           hip.ptr(xc_new), hip.ptr(work), hip.ptr(wcount[it:it + 1]), Rp * NE,
-                                           hip.ptr(sdfnew), st), "mp_mlp_sdf")
-                with self._ph("sampler_bound"):
-                    hip.check(L.mp_sampler_bound(C.byref(cfg), C.byref(state), hip.ptr(beta), hip.ptr(pp["hit_index"]),
-                                                 hip.ptr(pp["count"]), Rp, group, R, it, st), "mp_sampler_bound")
-                with self._ph("sampler_resample"):
-                    hip.check(L.mp_sampler_resample(C.byref(cfg), C.byref(state), hip.ptr(beta), hip.ptr(far),
-                                                    hip.ptr(pp["hit_index"]), hip.ptr(pp["count"]), Rp, group, R, it,
-                                                    None, None, st), "mp_sampler_resample")
+            zfinal, iters, wcount = self._sample_person(cx, n, p)
             # ---- shading of the final samples (multiply.py:294-308, 403-405)
             npts = Rp * S
             xc = torch.empty(npts, 3, **f32)

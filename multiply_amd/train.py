@@ -26,8 +26,14 @@ def _p(t):
     return hip.ptr(t)
 
 
+_DEBUG_SYNC = bool(int(__import__("os").environ.get("MP_DEBUG_SYNC", "0")))
+
+
 def _chk(code, what):
     hip.check(code, what)
+    if _DEBUG_SYNC:                      # debugging aid: attribute asynchronous faults to the launch that caused them
+        torch.cuda.synchronize()
+        print("[mp sync ok]", what, flush=True)
 
 
 def gemm_nt(A, lda, B, ldb, Cm, ldc, M, N, K, bias=None, bias_rows=0, accumulate=False, relu=False):
@@ -245,3 +251,248 @@ class RenderTrain:
 
     def param_grads(self):
         return list(self.extra_grads) + [g for lw in self.lins for g in lw.param_grads()]
+
+
+# ======================================================================================================================
+# Training-mode Multiply.forward (multiply.py:174-588, `self.training` branches) as ONE autograd node
+# ======================================================================================================================
+N_EIKONAL = 512          # multiply.py:324
+
+
+def _table(ts, dev):
+    return torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device=dev)
+
+
+def make_draws(model, cx, gen=None):
+    """The randomness one training forward consumes (ray_sampler.py:38,171,202; multiply.py:325; sampler.py:100):
+    per person  t_rand [R_p,NE], u_final [R_p,N], extra_idx [max_iters,N_extra], eik_idx [512], eik_noise [512,3];
+    shared      bg_rand [R,N_bg].  Drawn on the device with torch's generator (torch.rand/randperm/randn = what the
+    reference calls)."""
+    rs, dev = model.ray_sampler, cx["dev"]
+    NE, NS, NX = rs.N_samples_eval, rs.N_samples, rs.N_samples_extra
+    kw = dict(device=dev, generator=gen)
+    draws = {"person": {}}
+    for n, p in enumerate(cx["persons"]):
+        Rp = max(int(cx["n_hit"][n]), 1)
+        nv = model.smpl_server_list[p].verts_c.reshape(-1, 3).shape[0]
+        draws["person"][p] = dict(
+            t_rand=torch.rand(Rp, NE, **kw), u_final=torch.rand(Rp, NS, **kw),
+            extra_idx=torch.stack([torch.randperm(NE * k, **kw)[:NX] for k in range(1, rs.max_total_iters + 1)]
+                                  ).to(torch.int32).contiguous(),
+            eik_idx=torch.randperm(nv, **kw)[:N_EIKONAL], eik_noise=torch.randn(N_EIKONAL, 3, **kw))
+    draws["bg_rand"] = torch.rand(cx["R"], rs.N_samples_inverse_sphere, **kw)
+    return draws
+
+
+class TrainGraph:
+    """Everything one training forward keeps for its backward."""
+
+    def __init__(self, model, cx, input, cond_zero, draws):
+        self.model, self.cx, self.input, self.cond_zero, self.draws = model, cx, input, cond_zero, draws
+
+    # ---- forward ------------------------------------------------------------------------------------------------
+    def run(self):
+        m, cx, L = self.model, self.cx, hip.lib()
+        dev, R, dirs, pose, beta = cx["dev"], cx["R"], cx["dirs"], cx["pose"], cx["beta"]
+        st = hip.stream()
+        f32 = dict(dtype=F32, device=dev)
+        rs = m.ray_sampler
+        NZ = rs.N_samples + rs.N_samples_extra + 2
+        S = NZ - 1
+        persons = cx["persons"]
+        self.fg = {}
+        z_l, sdf_l, rgb_l, nrm_l, inv_l = [], [], [], [], []
+        for n, p in enumerate(persons):
+            pp = cx["per"][p]
+            dr = self.draws["person"][p]
+            if self.cond_zero:                                        # multiply.py:271-273
+                pp["cond"] = torch.zeros_like(pp["cond"])
+            Rp = max(int(cx["n_hit"][n]), 1)
+            imp, ren, dfm = m.foreground_implicit_network_list[p], m.foreground_rendering_network_list[p], m.deformer_list[p]
+            server = m.smpl_server_list[p]
+            skin_w = server.tables.lbs_weights
+            zfinal, iters, wcount = m._sample_person(cx, n, p, dr)
+            npts = Rp * S
+            E = N_EIKONAL
+            Pt = npts + E
+            X = torch.empty(Pt, 3, **f32)                             # canonical points: samples, then eikonal points
+            _chk(L.mp_warp_inverse_shade(_p(dirs), _p(pose), _p(pp["hit_index"]), _p(pp["count"]), _p(zfinal), NZ, S, Rp,
+                                         _p(pp["vsorted"]), _p(pp["cbound"]), _p(skin_w), _p(pp["tfs"]), 0, _p(beta),
+                                         _p(X), None, None, None, None, None, st), "mp_warp_inverse_shade")
+            jinv = torch.empty(npts, 9, **f32)
+            _chk(L.mp_warp_jacobian(_p(X), None, None, 0, 0, npts, _p(dfm.vsorted_c), _p(dfm.cbound_c), _p(skin_w),
+                                    _p(pp["tfs"]), _p(jinv), st), "mp_warp_jacobian")
+            # eikonal points near the canonical surface (multiply.py:322-327, sampler.py:84-108 with global_ratio 0)
+            vc = server.verts_c.reshape(-1, 3)
+            X[npts:] = vc[dr["eik_idx"]] + dr["eik_noise"] * m.sampler.local_sigma
+            it = ImplicitTrain(imp, X, pp["cond"], fwd=True)
+            XA = torch.empty(npts, 6, **f32); nrm = torch.empty(npts, 3, **f32); sdf = torch.empty(npts, **f32)
+            _chk(L.mp_tr_shade_in_fwd(_p(it.out), Pt, npts, _p(X), _p(jinv), _p(XA), _p(nrm), _p(sdf), st),
+                 "mp_tr_shade_in_fwd")
+            gth = torch.empty(E, 3, **f32)
+            _chk(L.mp_tr_eik_fwd(_p(it.out), Pt, npts, E, _p(gth), st), "mp_tr_eik_fwd")
+            rt = RenderTrain(ren, XA, off(it.out, 1), 257, npts, pp["cond"])
+            self.fg[p] = dict(it=it, rt=rt, X=X, jinv=jinv, XA=XA, sdf=sdf, nrm=nrm, gth=gth, zfinal=zfinal, iters=iters,
+                              wcount=wcount, npts=npts, Pt=Pt, Rp=Rp)
+            z_l.append(zfinal); sdf_l.append(sdf); rgb_l.append(rt.rgb); nrm_l.append(nrm); inv_l.append(pp["inv_index"])
+
+        # ---- background (multiply.py:482-484, 514-539); depths jittered per ray in training (ray_sampler.py:32-40)
+        self.bg = None
+        bg_rgb = None
+        if self.input.get("idx", None) is not None:
+            key = "image_id" if "image_id" in self.input else "idx"
+            self.frame = int(torch.as_tensor(self.input[key]).reshape(-1)[0])
+            code = m.frame_latent_encoder.weight.detach()[self.frame].contiguous()
+            NB = rs.N_samples_inverse_sphere
+            t = torch.linspace(0.0, 1.0, NB, device=dev)[None].expand(R, NB)
+            mids = 0.5 * (t[:, 1:] + t[:, :-1])
+            upper = torch.cat([mids, t[:, -1:]], -1); lower = torch.cat([t[:, :1], mids], -1)
+            zb = lower + (upper - lower) * self.draws["bg_rand"]
+            zbg = torch.flip(zb * (1.0 / rs.scene_bounding_sphere), dims=[-1]).contiguous()
+            pts = torch.empty(R * NB, 4, **f32)
+            cam = pose.reshape(4, 4)[:3, 3].contiguous()
+            _chk(L.mp_tr_bg_points(_p(dirs), _p(cam), _p(zbg), R, NB, C.c_float(m.sdf_bounding_sphere), _p(pts), st),
+                 "mp_tr_bg_points")
+            bit = ImplicitTrain(m.bg_implicit_network, pts, code, fwd=False)
+            drep = dirs[:, None, :].expand(R, NB, 3).reshape(-1, 3).contiguous()
+            XAb = torch.empty(R * NB, 27, **f32)
+            _chk(L.mp_tr_pe(_p(drep), 3, R * NB, 4, 0, C.c_float(1.0), _p(XAb), 27, 0, st), "mp_tr_pe")
+            brt = RenderTrain(m.bg_rendering_network, XAb, off(bit.out, 1), 257, R * NB, code)
+            sdfb = torch.empty(R * NB, **f32)
+            _chk(L.mp_tr_copy_cols(_p(bit.out), 257, 0, _p(sdfb), 1, 0, R * NB, 1, C.c_float(1.0), 0, st), "mp_tr_copy_cols")
+            bg_rgb = torch.empty(R, 3, **f32)
+            _chk(L.mp_tr_bg_comp_fwd(_p(sdfb), _p(brt.rgb), _p(zbg), R, NB, _p(bg_rgb), st), "mp_tr_bg_comp_fwd")
+            self.bg = dict(it=bit, rt=brt, zbg=zbg, sdfb=sdfb, XAb=XAb, NB=NB, code=code, pts=pts)
+        self.bg_rgb = bg_rgb
+
+        # ---- compositing (multiply.py:425-480, 544-545)
+        self.tabs = tuple(_table(ts, dev) for ts in (inv_l, z_l, sdf_l, rgb_l, nrm_l))
+        t_inv, t_z, t_sdf, t_rgb, t_nrm = self.tabs
+        P = len(persons)
+        rgb_values = torch.empty(R, 3, **f32); fg_rgb_values = torch.empty(R, 3, **f32)
+        normal_values = torch.empty(R, 3, **f32); acc_map = torch.empty(R, **f32)
+        acc_person = torch.empty(R, P, **f32); bg_T = torch.empty(R, **f32)
+        _chk(L.mp_composite(R, P, NZ, _p(t_inv), _p(t_z), _p(t_sdf), _p(t_rgb), _p(t_nrm), _p(beta),
+                            _p(bg_rgb) if bg_rgb is not None else None, _p(rgb_values), _p(fg_rgb_values),
+                            _p(normal_values), _p(acc_map), _p(acc_person), _p(bg_T), st), "mp_composite")
+        grad_theta = torch.cat([self.fg[p]["gth"] for p in persons], 0)[None]       # multiply.py:565
+        self.bg_T = bg_T
+        self.NZ = NZ
+        return rgb_values, normal_values, acc_map, acc_person, grad_theta
+
+    # ---- backward -----------------------------------------------------------------------------------------------
+    def backward(self, d_rgb_values, d_acc_map, d_acc_person, d_grad_theta):
+        """-> {id(parameter): gradient}"""
+        m, cx, L = self.model, self.cx, hip.lib()
+        dev, R, beta = cx["dev"], cx["R"], cx["beta"]
+        st = hip.stream()
+        f32 = dict(dtype=F32, device=dev)
+        persons = cx["persons"]
+        P = len(persons)
+        t_inv, t_z, t_sdf, t_rgb, _ = self.tabs
+        zero = lambda t, shape: torch.zeros(shape, **f32) if t is None else t.contiguous().float()
+        d_rgb_values = zero(d_rgb_values, (R, 3)); d_acc_map = zero(d_acc_map, (R,)); d_acc_person = zero(d_acc_person, (R, P))
+        dsdf_l = [torch.zeros(self.fg[p]["npts"], **f32) for p in persons]
+        drgb_l = [torch.zeros(self.fg[p]["npts"], 3, **f32) for p in persons]
+        d_bg_rgb = torch.zeros(R, 3, **f32)
+        d_beta = torch.zeros(1, **f32)
+        t_dsdf, t_drgb = _table(dsdf_l, dev), _table(drgb_l, dev)
+        _chk(L.mp_tr_composite_bwd(R, P, self.NZ, _p(t_inv), _p(t_z), _p(t_sdf), _p(t_rgb), _p(beta),
+                                   _p(self.bg_rgb) if self.bg_rgb is not None else None, _p(d_rgb_values), _p(d_acc_map),
+                                   _p(d_acc_person), _p(t_dsdf), _p(t_drgb), _p(d_bg_rgb), _p(d_beta), st),
+             "mp_tr_composite_bwd")
+        grads = {}
+
+        def collect(obj):
+            for prm, g in zip(obj.params(), obj.param_grads()):
+                grads[id(prm)] = g if id(prm) not in grads else grads[id(prm)] + g
+
+        for n, p in enumerate(persons):
+            f = self.fg[p]
+            it, rt, npts, Pt = f["it"], f["rt"], f["npts"], f["Pt"]
+            dZ8 = torch.zeros(4 * Pt, 257, **f32)
+            dXA = torch.empty(npts, 6, **f32)
+            rt.backward(drgb_l[n], dXA, off(dZ8, 1), 257)
+            _chk(L.mp_tr_shade_in_bwd(_p(it.out), Pt, npts, _p(f["jinv"]), _p(dXA), _p(dsdf_l[n]), None, _p(dZ8), st),
+                 "mp_tr_shade_in_bwd")
+            if d_grad_theta is not None:
+                dg = d_grad_theta.reshape(-1, 3)[n * N_EIKONAL:(n + 1) * N_EIKONAL].contiguous().float()
+                _chk(L.mp_tr_eik_bwd(Pt, npts, N_EIKONAL, _p(dg), _p(dZ8), st), "mp_tr_eik_bwd")
+            it.backward(dZ8)
+            collect(it); collect(rt)
+        if self.bg is not None:
+            b = self.bg
+            bit, brt, NB = b["it"], b["rt"], b["NB"]
+            rows = R * NB
+            dsdfb = torch.empty(rows, **f32); drgbb = torch.empty(rows, 3, **f32)
+            _chk(L.mp_tr_bg_comp_bwd(_p(b["sdfb"]), _p(brt.rgb), _p(b["zbg"]), R, NB, _p(d_bg_rgb), _p(dsdfb), _p(drgbb),
+                                     st), "mp_tr_bg_comp_bwd")
+            dZ8b = torch.zeros(rows, 257, **f32)
+            dXAb = torch.empty(rows, 27, **f32)
+            dcode = brt.backward(drgbb, dXAb, off(dZ8b, 1), 257)
+            _chk(L.mp_tr_copy_cols(_p(dsdfb), 1, 0, _p(dZ8b), 257, 0, rows, 1, C.c_float(1.0), 0, st), "mp_tr_copy_cols")
+            dcode = dcode + bit.backward(dZ8b)
+            collect(bit); collect(brt)
+            w = m.frame_latent_encoder.weight
+            gw = torch.zeros_like(w)
+            gw[self.frame] = dcode
+            grads[id(w)] = gw
+        bp = m.density.beta
+        grads[id(bp)] = (d_beta.reshape(bp.shape) * torch.sign(bp.detach())).to(bp.dtype)     # density.py:31-33
+        return grads
+
+
+class _TrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, graph, *params):
+        ctx.graph, ctx.params = graph, params
+        outs = graph.run()
+        ctx.mark_non_differentiable(outs[1])          # normal_values: no loss term reads it (loss.py:108-177)
+        return outs
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_nrm, d_acc, d_accp, d_gth):
+        g = ctx.graph.backward(d_rgb, d_acc, d_accp, d_gth)
+        return (None,) + tuple(g.get(id(p)) for p in ctx.params)
+
+
+def forward_train(model, input, id=-1, cond_zero_shit=False, canonical_pose=False, draws=None):
+    """Multiply.forward with self.training == True.  Returns the reference's 19-key dict (multiply.py:566-588); the five
+    tensors rgb_values / acc_map / acc_person_list / grad_theta (/ normal_values, not differentiable) hang off ONE autograd
+    node whose backward is the hand-written adjoint sweep."""
+    epoch = int(input["current_epoch"])
+    if epoch < 250:
+        raise NotImplementedError("current_epoch < 250 needs the canonical-mesh in/off-surface flags "
+                                  "(multiply.py:153-172, kaolin); not built yet (DESIGN.md, scope row a13)")
+    cx = model._setup(input, id, canonical_pose)
+    dev = cx["dev"]
+    cond_zero = epoch < 20 or epoch % 20 == 0 or bool(cond_zero_shit)              # multiply.py:271-273
+    if draws is None:
+        draws = make_draws(model, cx)
+    graph = TrainGraph(model, cx, input, cond_zero, draws)
+    params = [p for p in model.parameters() if p.requires_grad]
+    with torch.enable_grad():                                                       # multiply.py:176
+        rgb_values, normal_values, acc_map, acc_person, grad_theta = _TrainFn.apply(graph, *params)
+        temporal_loss = torch.zeros(1, device=dev)
+        if epoch > 250:                                                             # multiply.py:242-243
+            temporal_loss = torch.mean(torch.square(input["smpl_pose_last"].to(dev) - input["smpl_pose"].to(dev)))
+    last = cx["persons"][-1]
+    fl = graph.fg[last]
+    hit = cx["per"][last]["hit_index"][:fl["Rp"]].long()
+    cam = cx["pose"].reshape(4, 4)[:3, 3]
+    points = cam[None, None, :] + fl["zfinal"][:, :-1, None] * cx["dirs"][hit][:, None, :]
+    zeros1 = lambda: torch.zeros(1, device=dev)
+    out = {
+        "zero_pose_loss": zeros1(), "t_list": [], "fg_rgb_values_each_person_list": [],
+        "cam_loc": cam[None].expand(cx["R"], 3), "hitted_mask_idx": [], "mean_hitted_vertex_list": [],
+        "points": points, "rgb_values": rgb_values, "normal_values": normal_values,
+        "index_outside": input["index_outside"], "index_off_surface": None, "index_in_surface": None,
+        "acc_map": acc_map, "grad_theta": grad_theta, "interpenetration_loss": zeros1(), "temporal_loss": temporal_loss,
+        "acc_person_list": acc_person, "smpl_surface_loss": zeros1(), "epoch": input["current_epoch"],
+    }
+    if "sam_mask" in input:
+        out["sam_mask"] = input["sam_mask"].squeeze()
+    model._last_train = graph
+    model.last_stats = {"n_hit": cx["n_hit"], "iters": [graph.fg[p]["iters"] for p in cx["persons"]],
+                        "n_sdf_evals": [graph.fg[p]["wcount"] for p in cx["persons"]]}
+    return out

@@ -489,14 +489,16 @@ def packed_composite(n_rays, hit_index, z_list, zmax_list, sdf_list, rgb_list, n
     ray_idx = pk[:, 0].long()
     sig_dt = laplace_density(pk[:, 3], beta) * (pk[:, 2] - pk[:, 1])
     alpha = 1.0 - torch.exp(-sig_dt)
-    # exclusive per-ray cumsum
-    csum = torch.cumsum(sig_dt, 0)
+    # exclusive per-ray cumsum (nerfacc scans each ray separately; a global scan minus the ray's base reproduces that
+    # only if it is carried in float64 -- the float32 result is what is used)
+    sd64 = sig_dt.double()
+    csum = torch.cumsum(sd64, 0)
     first = torch.ones_like(ray_idx, dtype=torch.bool)
     first[1:] = ray_idx[1:] != ray_idx[:-1]
     start_pos = torch.nonzero(first).flatten()
     seg_id = torch.cumsum(first.long(), 0) - 1
-    base = (csum - sig_dt)[start_pos][seg_id]
-    excl = csum - sig_dt - base
+    base = (csum - sd64)[start_pos][seg_id]
+    excl = (csum - sd64 - base).float()
     trans = torch.exp(-excl)
     w = alpha * trans
     acc_rgb = torch.zeros(n_rays, 3).index_add_(0, ray_idx, w[:, None] * pk[:, 4:7])
@@ -602,3 +604,66 @@ class MultiplyOracle:
         return dict(acc_map=acc, acc_person_list=acc_person, rgb_values=rgb_values, fg_rgb_values=fg_out,
                     normal_values=nrm, bg_transmittance=bg_T, bg_rgb=bg_rgb, z_vals=z_l, z_max=zmax_l, sdf=sdf_l,
                     rgb_samples=rgb_l, normal_samples=nrm_l, iters=iters_l, x_c=xc_l, ray_dirs=dirs, cam_loc=cam1)
+
+    # ------------------------------------------------------------------------------------------- training forward
+    def background_train(self, dirs, cam, frame_code, t_rand):
+        """background branch with autograd enabled (multiply.py:514-539; depths jittered: ray_sampler.py:32-40)"""
+        R = dirs.shape[0]
+        z_bg = torch.flip(bg_depths(self.cfg, R, t_rand), dims=[-1])
+        N = z_bg.shape[1]
+        pts = depth2pts_outside(cam[:, None, :].expand(-1, N, -1), dirs[:, None, :].expand(-1, N, -1), z_bg,
+                                self.cfg.radius).reshape(-1, 4)
+        out = implicit_forward(self.sd, "bg_implicit_network.", pts, frame_code, multires=10)
+        rgb = rendering_forward_nerf_frame(self.sd, "bg_rendering_network.",
+                                           dirs[:, None, :].expand(-1, N, -1).reshape(-1, 3), out[:, 1:], frame_code)
+        w = bg_volume_weights(z_bg, out[:, :1])
+        return (w[:, :, None] * rgb.reshape(-1, N, 3)).sum(1)
+
+    def forward_train(self, inp, hit_index, z_given, draws, cond_zero=False, person_list=None):
+        """Training-mode Multiply.forward (multiply.py:254-588) from the sampler's output on: `z_given[k]` (R_p, N+N_extra+2)
+        are the depths the sampler returned (it runs under no_grad, ray_sampler.py:86-87, so it is an input here);
+        draws = {'person': {p: {eik_idx, eik_noise}}, 'bg_rand'}.  Every tensor of self.sd that requires grad receives
+        gradients through the returned outputs (torch autograd, incl. the double backward through the normals and
+        the eikonal term)."""
+        dirs, cam1 = get_camera_rays(inp["uv"][0], inp["pose"][0], inp["intrinsics"][0])
+        R = dirs.shape[0]
+        cam = cam1[None].expand(R, -1)
+        scale = inp["smpl_params"][0, :, 0]
+        beta = self.beta()
+        persons = list(range(self.P)) if person_list is None else person_list
+        z_l, zmax_l, sdf_l, rgb_l, nrm_l, hit_l, gth_l = [], [], [], [], [], [], []
+        for k, p in enumerate(persons):
+            with torch.no_grad():
+                so = self.servers[p].forward(scale[p], inp["smpl_trans"][0, p], inp["smpl_pose"][0, p],
+                                             inp["smpl_shape"][0, p])
+            tfs, pv = so["smpl_tfs"], so["smpl_verts"]
+            cond = inp["smpl_pose"][0, p, 3:] / np.pi
+            if cond_zero:
+                cond = cond * 0.0                                                     # multiply.py:271-273
+            idx = hit_index[k]
+            d, c = dirs[idx], cam[idx]
+            person = self.persons[p]
+            zz = z_given[k]
+            zmax, z = zz[:, -1], zz[:, :-1]
+            pts = (c[:, None, :] + z[:, :, None] * d[:, None, :]).reshape(-1, 3)
+            with torch.no_grad():
+                x_c, _ = deform_inverse(pts, tfs, pv, person.server.weights)          # training: outliers keep their sdf
+            rgb, nrm, sdf = self.shade(person, x_c, cond, tfs, create_graph=True)
+            # eikonal samples (multiply.py:322-331)
+            dr = draws["person"][p]
+            xe = (person.server.verts_c[dr["eik_idx"]] + dr["eik_noise"] * 0.01).detach().requires_grad_(True)
+            se = person.implicit(xe, cond)[:, :1]
+            gth = torch.autograd.grad(se, xe, torch.ones_like(se), create_graph=True)[0]
+            S = z.shape[1]
+            z_l.append(z); zmax_l.append(zmax); sdf_l.append(sdf.reshape(-1, S)); hit_l.append(idx)
+            rgb_l.append(rgb.reshape(-1, S, 3)); nrm_l.append(nrm.reshape(-1, S, 3)); gth_l.append(gth)
+        fg_rgb, nrm, acc, acc_person, bg_T = packed_composite(R, hit_l, z_l, zmax_l, sdf_l, rgb_l, nrm_l, beta, persons)
+        if inp.get("idx", None) is not None:
+            code = self.sd["frame_latent_encoder.weight"][int(inp["idx"][0])]
+            bg_rgb = self.background_train(dirs, cam, code, draws["bg_rand"])
+        else:
+            bg_rgb = torch.ones_like(fg_rgb)
+        rgb_values = fg_rgb + bg_T[:, None] * bg_rgb
+        return dict(rgb_values=rgb_values, normal_values=nrm, acc_map=acc, acc_person_list=acc_person,
+                    grad_theta=torch.cat(gth_l, 0)[None], bg_transmittance=bg_T, bg_rgb=bg_rgb, sdf=sdf_l,
+                    rgb_samples=rgb_l)

@@ -1,0 +1,37 @@
+"""multiply_amd.loss.Loss against the reference's Loss.forward outputs stored in the golden fixture (G9)."""
+import numpy as np
+import torch
+
+from multiply_amd.config import load_config
+from multiply_amd.loss import Loss
+
+
+def test_loss_matches_reference_golden(golden):
+    G = golden
+    t = lambda k: torch.tensor(G[k])
+    mo = dict(fg_rgb_values_each_person_list=[], rgb_values=t("g9_in_rgb_values"), grad_theta=t("g9_in_grad_theta"),
+              acc_map=t("g9_in_acc_map"), index_in_surface=t("g9_in_index_in_surface"), index_off_surface=None, epoch=120,
+              temporal_loss=t("g9_in_temporal_loss"), smpl_surface_loss=torch.zeros(1), zero_pose_loss=torch.zeros(1),
+              sam_mask=t("g9_in_sam_mask"), acc_person_list=t("g9_in_acc_person_list"))
+    lo = Loss(load_config().loss)(mo, dict(rgb=t("g9_gt_rgb")))
+    assert set(lo) == {k[7:] for k in G.files if k.startswith("g9_out_")}
+    for k, v in lo.items():
+        want = G["g9_out_" + k].reshape(-1)
+        got = np.asarray(v.detach().numpy(), dtype=np.float32).reshape(-1)
+        assert np.allclose(got, want, rtol=1e-6, atol=1e-7), (k, got, want)
+
+
+def test_loss_nan_rays_are_filtered_and_schedules():
+    lf = Loss(load_config().loss)
+    R = 16
+    rgb = torch.rand(R, 3)
+    rgb[3] = float("nan")
+    mo = dict(fg_rgb_values_each_person_list=[], rgb_values=rgb, grad_theta=torch.randn(1, 64, 3),
+              acc_map=torch.rand(R) * 0.9 + 0.05, index_in_surface=None, index_off_surface=None, epoch=300,
+              temporal_loss=torch.tensor([0.5]), smpl_surface_loss=torch.zeros(1), zero_pose_loss=torch.zeros(1),
+              acc_person_list=torch.rand(R, 2))
+    lo = lf(mo, dict(rgb=torch.rand(1, R, 3)))
+    assert torch.isfinite(lo["loss"]).all()
+    assert float(lo["in_shape_loss"]) == 0.0 and float(lo["sam_mask_loss"]) == 0.0      # no mask given / no flags
+    want = lo["rgb_loss"] + 0.1 * lo["eikonal_loss"] + 5e-3 * lo["bce_loss"] + lo["temporal_loss"]
+    assert torch.allclose(lo["loss"], want)

@@ -108,5 +108,123 @@ def test_rendering_net_backward():
         # ReLU masks of pre-activations within fp32 round-off of 0 can differ between two summation orders: one flipped
         # sample moves an element of a 900-sample gradient by ~1e-3 of the maximum
         assert rel(nme, got[id(p)].reshape(ww.shape), ww) < 1e-2, nme
-    assert rel("d XA", dXA, want[-2]) < 1e-2
-    assert rel("d feat", dZ8[:, 1:], want[-1]) < 1e-2
+    # per-sample data gradients: a flipped ReLU mask touches exactly the sample it belongs to -> all but a couple of rows
+    # must agree tightly
+    for nme, g, w in (("d XA", dXA, want[-2]), ("d feat", dZ8[:, 1:], want[-1])):
+        row_err = (g - w).abs().amax(1) / w.abs().max()
+        bad = int((row_err > 1e-5).sum())
+        print(f"[grad parity] {nme}: rows off by > 1e-5 of max: {bad} of {n}; worst {float(row_err.max()):.3e}")
+        assert bad <= 2, nme
+
+
+def test_background_branch_backward():
+    """bg ImplicitNet (no weight norm, 4-D input, L=10) + bg RenderingNet (nerf_frame_encoding) + inverse-sphere
+    compositing: forward and every parameter / frame-code gradient vs torch autograd on the oracle's formulas."""
+    from multiply_amd import train as T
+    m, _ = seeded_networks(1, 0)
+    m = m.cuda()
+    L = T.hip.lib()
+    torch.manual_seed(3)
+    R, NB = 96, 32
+    dirs = torch.nn.functional.normalize(torch.randn(R, 3, device="cuda") * 0.2 + torch.tensor([0, 0, 1.0], device="cuda"), dim=1)
+    cam = torch.tensor([0.05, -0.1, -2.5], device="cuda")
+    code = torch.randn(32, device="cuda") * 0.3
+    zb = (torch.linspace(0, 1, NB, device="cuda")[None] + torch.rand(R, NB, device="cuda") * 0.01).clamp(0, 1) / 3.0
+    zbg = torch.flip(zb, dims=[-1]).contiguous()
+    pts = torch.empty(R * NB, 4, device="cuda")
+    T._chk(L.mp_tr_bg_points(T._p(dirs), T._p(cam), T._p(zbg), R, NB, C.c_float(3.0), T._p(pts), T.hip.stream()), "bg_points")
+    want_pts = O.depth2pts_outside(cam[None, None].expand(R, NB, 3), dirs[:, None].expand(R, NB, 3), zbg, 3.0).reshape(-1, 4)
+    assert rel("bg points", pts, want_pts) < 1e-5
+    bit = T.ImplicitTrain(m.bg_implicit_network, pts, code, fwd=False)
+    drep = dirs[:, None, :].expand(R, NB, 3).reshape(-1, 3).contiguous()
+    XAb = torch.empty(R * NB, 27, device="cuda")
+    T._chk(L.mp_tr_pe(T._p(drep), 3, R * NB, 4, 0, C.c_float(1.0), T._p(XAb), 27, 0, T.hip.stream()), "pe")
+    brt = T.RenderTrain(m.bg_rendering_network, XAb, T.off(bit.out, 1), 257, R * NB, code)
+    sdfb = bit.out[:, 0].contiguous()
+    out = torch.empty(R, 3, device="cuda")
+    T._chk(L.mp_tr_bg_comp_fwd(T._p(sdfb), T._p(brt.rgb), T._p(zbg), R, NB, T._p(out), T.hip.stream()), "bg_comp")
+    # torch
+    sd = {k: v for k, v in m.named_parameters()}
+    codeg = code.clone().requires_grad_(True)
+    o = O.implicit_forward(sd, "bg_implicit_network.", want_pts, codeg, multires=10)
+    rgb = O.rendering_forward_nerf_frame(sd, "bg_rendering_network.", drep, o[:, 1:], codeg)
+    dens = o[:, :1].abs().reshape(R, NB)
+    dists = torch.cat([zbg[:, :-1] - zbg[:, 1:], 1e10 * torch.ones(R, 1, device="cuda")], -1)
+    free = dists * dens
+    shifted = torch.cat([torch.zeros(R, 1, device="cuda"), free[:, :-1]], -1)
+    w = (1 - torch.exp(-free)) * torch.exp(-torch.cumsum(shifted, -1))
+    want_out = (w[:, :, None] * rgb.reshape(R, NB, 3)).sum(1)
+    assert rel("bg sdf+feat", bit.out, o.detach()) < 1e-5
+    assert rel("bg rgb", out, want_out.detach()) < 1e-5
+    a = torch.randn(R, 3, device="cuda")
+    names = [n for n, p in m.named_parameters() if n.startswith("bg_")]
+    plist = [p for n, p in m.named_parameters() if n.startswith("bg_")]
+    want = torch.autograd.grad((want_out * a).sum(), plist + [codeg])
+    rows = R * NB
+    dsdfb = torch.empty(rows, device="cuda"); drgbb = torch.empty(rows, 3, device="cuda")
+    T._chk(L.mp_tr_bg_comp_bwd(T._p(sdfb), T._p(brt.rgb), T._p(zbg), R, NB, T._p(a), T._p(dsdfb), T._p(drgbb), T.hip.stream()),
+           "bg_comp_bwd")
+    dZ8b = torch.zeros(rows, 257, device="cuda"); dXAb = torch.empty(rows, 27, device="cuda")
+    dcode = brt.backward(drgbb, dXAb, T.off(dZ8b, 1), 257)
+    dZ8b[:, 0] = dsdfb
+    dcode = dcode + bit.backward(dZ8b)
+    got = dict(zip([id(p) for p in bit.params() + brt.params()], bit.param_grads() + brt.param_grads()))
+    errs = {n: rel(n, got[id(p)].reshape(ww.shape), ww) for n, p, ww in zip(names, plist, want)}
+    errs["d frame code"] = rel("d frame code", dcode, want[-1])
+    assert max(errs.values()) < 1e-2, errs
+
+
+def test_composite_backward():
+    """mp_composite / mp_tr_composite_bwd vs the oracle's packed compositing under autograd (two persons, rays hit by
+    both, one or none; includes the exclusive background transmittance and d beta)."""
+    from multiply_amd import train as T
+    L = T.hip.lib()
+    torch.manual_seed(4)
+    R, NZ = 70, 98
+    S = NZ - 1
+    hit = [torch.arange(0, 50), torch.arange(30, 65)]
+    z = [torch.sort(torch.rand(len(h), NZ) * 2.0 + 1.0, dim=1)[0] for h in hit]
+    sdf = [torch.randn(len(h), S) * 0.05 for h in hit]
+    rgb = [torch.rand(len(h), S, 3) for h in hit]
+    nrm = [torch.randn(len(h), S, 3) for h in hit]
+    bg = torch.rand(R, 3)
+    beta_p = torch.tensor(0.02)
+    cu = lambda t: t.cuda().contiguous()
+    inv = []
+    for h in hit:
+        iv = torch.full((R,), -1, dtype=torch.int32)
+        iv[h] = torch.arange(len(h), dtype=torch.int32)
+        inv.append(cu(iv))
+    zc, sc, rc, nc, bgc = [cu(t) for t in z], [cu(t.reshape(-1)) for t in sdf], [cu(t.reshape(-1, 3)) for t in rgb], \
+        [cu(t.reshape(-1, 3)) for t in nrm], cu(bg)
+    beta = cu(beta_p.reshape(1))
+    tabs = [T._table(ts, "cuda") for ts in (inv, zc, sc, rc, nc)]
+    f = lambda *s: torch.empty(*s, device="cuda")
+    rgb_v, fg_v, nrm_v, acc, accp, bgT = f(R, 3), f(R, 3), f(R, 3), f(R), f(R, 2), f(R)
+    T._chk(L.mp_composite(R, 2, NZ, *[T._p(t) for t in tabs], T._p(beta), T._p(bgc), T._p(rgb_v), T._p(fg_v), T._p(nrm_v),
+                          T._p(acc), T._p(accp), T._p(bgT), T.hip.stream()), "composite")
+    # oracle
+    sdf_g = [t.clone().requires_grad_(True) for t in sdf]
+    rgb_g = [t.clone().requires_grad_(True) for t in rgb]
+    bg_g, beta_g = bg.clone().requires_grad_(True), beta_p.clone().requires_grad_(True)
+    fg_o, nrm_o, acc_o, accp_o, bgT_o = O.packed_composite(R, hit, [t[:, :-1] for t in z], [t[:, -1] for t in z], sdf_g, rgb_g,
+                                                           nrm, beta_g, [0, 1])
+    rgb_o = fg_o + bgT_o[:, None] * bg_g
+    assert rel("rgb_values", rgb_v, rgb_o.detach()) < 1e-5
+    assert rel("acc", acc, acc_o.detach()) < 1e-5 and rel("acc_person", accp, accp_o.detach()) < 1e-5
+    assert rel("bg_T", bgT, bgT_o.detach()) < 1e-5 and rel("normal_values", nrm_v, nrm_o.detach()) < 1e-5
+    a_rgb, a_acc, a_accp = torch.randn(R, 3), torch.randn(R), torch.randn(R, 2)
+    want = torch.autograd.grad((rgb_o * a_rgb).sum() + (acc_o * a_acc).sum() + (accp_o * a_accp).sum(),
+                               sdf_g + rgb_g + [bg_g, beta_g])
+    dsdf = [torch.zeros_like(t) for t in sc]; drgb = [torch.zeros_like(t) for t in rc]
+    dbg, dbeta = torch.zeros(R, 3, device="cuda"), torch.zeros(1, device="cuda")
+    td, tr = T._table(dsdf, "cuda"), T._table(drgb, "cuda")
+    g_rgb, g_acc, g_accp = cu(a_rgb), cu(a_acc), cu(a_accp)      # keep the device copies alive across the launch
+    T._chk(L.mp_tr_composite_bwd(R, 2, NZ, T._p(tabs[0]), T._p(tabs[1]), T._p(tabs[2]), T._p(tabs[3]), T._p(beta), T._p(bgc),
+                                 T._p(g_rgb), T._p(g_acc), T._p(g_accp), T._p(td), T._p(tr), T._p(dbg), T._p(dbeta),
+                                 T.hip.stream()), "composite_bwd")
+    for p in range(2):
+        assert rel(f"d sdf[{p}]", dsdf[p].reshape(-1, S), want[p]) < 1e-4
+        assert rel(f"d rgb[{p}]", drgb[p].reshape(-1, S, 3), want[2 + p]) < 1e-5
+    assert rel("d bg_rgb", dbg, want[4]) < 1e-5
+    assert rel("d beta", dbeta.reshape(()), want[5]) < 1e-4
