@@ -14,6 +14,7 @@ The JSON line also carries
   cpu_baseline : the CPU oracle (fp32 torch restatement of the reference path) timed on this host on a bounded sample
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -86,6 +87,60 @@ def cpu_baseline(model, inp, tables, sc, n_samples, rows=1, stride=4):
                        f"oracle, {dt:.1f} s", parity_rgb_max_abs=float(err.max()), parity_rgb_mean_abs=float(err.mean()))
 
 
+def train_iterations(model, gin, steps, warmup, dist, barrier, seed=0, rays=512):
+    """ms/train-iter (BASELINE.json's second metric): forward (training mode) + Loss + backward + Adam step on `rays`
+    random pixels of the frame per rank (confs/dataset: 512 pixels per iteration), current_epoch 301 (no in/off-surface
+    flags, temporal loss on, pose conditioning on).  N > 1: one flat RCCL all-reduce of the gradients per step."""
+    from multiply_amd.config import load_config
+    from multiply_amd.loss import Loss
+    from multiply_amd.parallel import GradientAllReduce
+    dev = gin["uv"].device
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    R = gin["uv"].shape[1]
+    loss_fn = Loss(load_config().loss)
+    opt = torch.optim.Adam(model.parameters(), lr=5.0e-4)            # multiply_model.py configure_optimizers
+    ar = GradientAllReduce(model.parameters())
+    model.train()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    acc = [0.0] * 4
+
+    def one(timed):
+        sel = torch.randperm(R, generator=g)[:rays].to(dev)
+        tin = dict(gin)
+        tin["uv"] = gin["uv"][:, sel].contiguous()
+        tin.update(current_epoch=301, index_outside=torch.zeros(rays, dtype=torch.bool, device=dev),
+                   smpl_pose_last=gin["smpl_pose"] + 0.01)
+        gt = {"rgb": torch.rand(1, rays, 3, generator=g).to(dev)}
+        ev[0].record()
+        out = model(tin)
+        with contextlib.redirect_stdout(sys.stderr):     # Loss prints "Nan: bce_loss" like the reference (loss.py:125)
+            lo = loss_fn(out, gt)
+        ev[1].record()
+        opt.zero_grad(set_to_none=True)
+        lo["loss"].backward()
+        ev[2].record()
+        ar()
+        ev[3].record()
+        opt.step()
+        ev[4].record()
+        if timed:
+            torch.cuda.synchronize()
+            for i in range(4):
+                acc[i] += ev[i].elapsed_time(ev[i + 1])
+        return lo
+
+    for _ in range(warmup):
+        one(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        lo = one(True)
+    barrier()
+    dt = time.perf_counter() - t0
+    model.eval()
+    return dt, [a / max(steps, 1) for a in acc], float(lo["loss"]), model.last_stats
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +149,8 @@ def main():
     ap.add_argument("--samples", type=int, default=128, help="importance samples per ray (N_samples)")
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--tile", type=int, default=8, help="emit the frame's rays in tile x tile pixel blocks (0 = row-major)")
+    ap.add_argument("--train-steps", type=int, default=10, help="timed training iterations for ms/train-iter (0 = skip)")
+    ap.add_argument("--train-warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print per-phase GPU times to stderr")
     args = ap.parse_args()
@@ -139,6 +196,20 @@ def main():
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    render_stats = model.last_stats
+    train = None
+    if args.train_steps > 0:
+        tdt, tph, tloss, tstats = train_iterations(model, gin, args.train_steps, args.train_warmup, dist, barrier, seed=rank)
+        if dist:
+            tt = torch.tensor([tdt], device="cuda")
+            td.all_reduce(tt, op=td.ReduceOp.MAX)
+            tdt = float(tt.item())
+        train = {"metric": "ms/train-iter (forward + loss + backward + gradient all-reduce + Adam step)",
+                 "ms_per_iter": 1e3 * tdt / args.train_steps, "steps": args.train_steps, "warmup": args.train_warmup,
+                 "rays_per_iter_per_gpu": 512, "rays_per_iter": 512 * world, "scaling": "weak", "dtype": "f32",
+                 "gpu_ms": {"forward+loss": tph[0], "backward": tph[1], "allreduce": tph[2], "adam": tph[3]},
+                 "hit_rays": tstats["n_hit"], "last_loss": tloss}
+
     phases = model.phase_times_ms()
     n_shaded = float(sum(int(w.sum()) for s in shaded for w in s)) / args.steps          # per frame
     n_sdf = float(sum(int(w[:-1].sum()) for s in sdf_evals for w in s)) / args.steps
@@ -153,7 +224,7 @@ def main():
         tot = sum(v[1] for v in phases.values())
         for k, (n, m) in sorted(phases.items(), key=lambda kv: -kv[1][1]):
             print(f"  {k:18s} {n:5d} launches {m / args.steps:9.2f} ms/frame {100 * m / tot:5.1f}%", file=sys.stderr)
-        print(f"  shaded points/frame {n_shaded:.0f}  sdf evals/frame {n_sdf:.0f}  hit rays {model.last_stats['n_hit']}",
+        print(f"  shaded points/frame {n_shaded:.0f}  sdf evals/frame {n_sdf:.0f}  hit rays {render_stats['n_hit']}",
               file=sys.stderr)
 
     if rank == 0:
@@ -173,6 +244,8 @@ def main():
                          "algorithmic_flop_per_launch": flops[dom] / launches_per_frame},
             "phases_ms_per_step": {k: v[1] / args.steps for k, v in phases.items()},
         }
+        if train is not None:
+            out["train_iter"] = train
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, inp, tables, sc, args.samples)
         print(json.dumps(out))

@@ -52,3 +52,43 @@ def test_two_rank_gather(n, group):
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res)
     assert all(abs(t - 2.0) < 1e-6 for _, _, t in res)
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+    unused = torch.nn.Parameter(torch.ones(4))                    # a parameter that received no gradient on this rank
+    params = list(net.parameters()) + [unused]
+    x = torch.full((2, 5), float(rank + 1))
+    net(x).sum().backward()
+    mine = [p.grad.clone() for p in net.parameters()]
+    ar = parallel.GradientAllReduce(params)
+    flat = ar()
+    # expected: mean over ranks of the local gradients (inputs differ per rank by a known factor)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, [g.numpy() for g in mine])
+    ok = True
+    for i, p in enumerate(net.parameters()):
+        want = sum(torch.tensor(g[i]) for g in gathered) / world
+        ok = ok and torch.allclose(p.grad, want, atol=1e-6)
+    ok = ok and float(unused.grad.abs().sum()) == 0.0 and flat.numel() == sum(p.numel() for p in params)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok))
+
+
+def test_two_rank_gradient_allreduce():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
