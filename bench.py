@@ -227,6 +227,21 @@ def main():
         print(f"  shaded points/frame {n_shaded:.0f}  sdf evals/frame {n_sdf:.0f}  hit rays {render_stats['n_hit']}",
               file=sys.stderr)
 
+    # HBM traffic of the dominant kernel: rocprofv3 PMC passes of this same command (FETCH_SIZE and WRITE_SIZE in
+    # separate runs, gfx950 half-count correction on reads) are kept under profiles/; the counters cannot be read from
+    # inside the process, so the committed measurement is attached when it was taken on this workload.
+    traffic = None
+    kern = {"mlp_shade": "k_mlp_shade", "mlp_color": "k_mlp_color", "background": "k_background",
+            "sampler_mlp_sdf": "k_mlp_sdf"}[dom]
+    pmc_file = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(pmc_file) and args.res == 512 and args.samples == 128:
+        with open(pmc_file) as f:
+            e = json.load(f).get(kern)
+        if e:
+            traffic = {"bytes_per_launch": e["hbm_read_bytes_corrected"] + e["hbm_write_bytes_uncalibrated"],
+                       "read": e["hbm_read_bytes_corrected"], "write": e["hbm_write_bytes_uncalibrated"],
+                       "source": "profiles/r01_pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+
     if rank == 0:
         out = {
             "metric": "rays/sec rendering full 512x512 frames (eval forward, all persons, with background)",
@@ -239,7 +254,7 @@ def main():
                                    f"convergence groups of 512 rays (reference pixel_per_batch), geometric-init weights",
                        "rays_per_step": R, "frames_per_rank": args.steps, "parallelism": f"frame-sharded dp{world}"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "avg_launch_ms": 1e3 * per_launch_s, "launches_per_step": launches_per_frame,
                          "algorithmic_flop_per_launch": flops[dom] / launches_per_frame},
             "phases_ms_per_step": {k: v[1] / args.steps for k, v in phases.items()},

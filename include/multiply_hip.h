@@ -253,6 +253,14 @@ int mp_tr_bg_comp_bwd(const float* sdf, const float* rgb, const float* zbg, int 
 int mp_tr_copy_cols(const float* src, int lds, int c0s, float* dst, int ldd, int c0d, long long rows, int C, float scale,
                     int accumulate, void* stream);
 
+/* ---- in / off-surface flags (multiply.py:153-167; training, current_epoch < 250) -------------------------------
+ * signed distance of canonical points to a triangle mesh given as face_verts [F][3][3] (= mesh_face_vertices_list[p]):
+ * |d| = distance to the closest triangle, negative inside (ray-casting parity), then per ray (n_s consecutive points)
+ * off = min > threshold, in = min <= 0.  kaolin 0.13 in the reference (third party): restated, see csrc/mesh.hip. */
+int mp_mesh_signed_distance(const float* pts, int n, const float* face_verts, int n_faces, float* sdist, void* stream);
+int mp_mesh_ray_flags(const float* sdist, int n_rays, int n_s, float threshold, unsigned char* off, unsigned char* in,
+                      void* stream);
+
 /* library / device info: returns the gfx arch string compiled in, and checks the current device */
 const char* mp_arch(void);
 int mp_device_ok(void);

@@ -287,8 +287,9 @@ def make_draws(model, cx, gen=None):
 class TrainGraph:
     """Everything one training forward keeps for its backward."""
 
-    def __init__(self, model, cx, input, cond_zero, draws):
+    def __init__(self, model, cx, input, cond_zero, draws, surface_flags=False):
         self.model, self.cx, self.input, self.cond_zero, self.draws = model, cx, input, cond_zero, draws
+        self.surface_flags = surface_flags
 
     # ---- forward ------------------------------------------------------------------------------------------------
     def run(self):
@@ -322,6 +323,14 @@ class TrainGraph:
             jinv = torch.empty(npts, 9, **f32)
             _chk(L.mp_warp_jacobian(_p(X), None, None, 0, 0, npts, _p(dfm.vsorted_c), _p(dfm.cbound_c), _p(skin_w),
                                     _p(pp["tfs"]), _p(jinv), st), "mp_warp_jacobian")
+            flags = None
+            if self.surface_flags:        # multiply.py:311-315: in / off-surface rays w.r.t. the current canonical mesh
+                fv = m.mesh_face_vertices_list[p].detach().reshape(-1, 9).to(dev).float().contiguous()
+                sd = torch.empty(npts, **f32)
+                _chk(L.mp_mesh_signed_distance(_p(X), npts, _p(fv), fv.shape[0], _p(sd), st), "mp_mesh_signed_distance")
+                off_p = torch.empty(Rp, dtype=torch.uint8, device=dev); in_p = torch.empty(Rp, dtype=torch.uint8, device=dev)
+                _chk(L.mp_mesh_ray_flags(_p(sd), Rp, S, C.c_float(m.threshold), _p(off_p), _p(in_p), st), "mp_mesh_ray_flags")
+                flags = (off_p.bool(), in_p.bool(), sd)
             # eikonal points near the canonical surface (multiply.py:322-327, sampler.py:84-108 with global_ratio 0)
             vc = server.verts_c.reshape(-1, 3)
             X[npts:] = vc[dr["eik_idx"]] + dr["eik_noise"] * m.sampler.local_sigma
@@ -333,7 +342,7 @@ class TrainGraph:
             _chk(L.mp_tr_eik_fwd(_p(it.out), Pt, npts, E, _p(gth), st), "mp_tr_eik_fwd")
             rt = RenderTrain(ren, XA, off(it.out, 1), 257, npts, pp["cond"])
             self.fg[p] = dict(it=it, rt=rt, X=X, jinv=jinv, XA=XA, sdf=sdf, nrm=nrm, gth=gth, zfinal=zfinal, iters=iters,
-                              wcount=wcount, npts=npts, Pt=Pt, Rp=Rp)
+                              wcount=wcount, npts=npts, Pt=Pt, Rp=Rp, flags=flags)
             z_l.append(zfinal); sdf_l.append(sdf); rgb_l.append(rt.rgb); nrm_l.append(nrm); inv_l.append(pp["inv_index"])
 
         # ---- background (multiply.py:482-484, 514-539); depths jittered per ray in training (ray_sampler.py:32-40)
@@ -461,15 +470,12 @@ def forward_train(model, input, id=-1, cond_zero_shit=False, canonical_pose=Fals
     tensors rgb_values / acc_map / acc_person_list / grad_theta (/ normal_values, not differentiable) hang off ONE autograd
     node whose backward is the hand-written adjoint sweep."""
     epoch = int(input["current_epoch"])
-    if epoch < 250:
-        raise NotImplementedError("current_epoch < 250 needs the canonical-mesh in/off-surface flags "
-                                  "(multiply.py:153-172, kaolin); not built yet (DESIGN.md, scope row a13)")
     cx = model._setup(input, id, canonical_pose)
     dev = cx["dev"]
     cond_zero = epoch < 20 or epoch % 20 == 0 or bool(cond_zero_shit)              # multiply.py:271-273
     if draws is None:
         draws = make_draws(model, cx)
-    graph = TrainGraph(model, cx, input, cond_zero, draws)
+    graph = TrainGraph(model, cx, input, cond_zero, draws, surface_flags=epoch < 250)
     params = [p for p in model.parameters() if p.requires_grad]
     with torch.enable_grad():                                                       # multiply.py:176
         rgb_values, normal_values, acc_map, acc_person, grad_theta = _TrainFn.apply(graph, *params)
@@ -482,11 +488,23 @@ def forward_train(model, input, id=-1, cond_zero_shit=False, canonical_pose=Fals
     cam = cx["pose"].reshape(4, 4)[:3, 3]
     points = cam[None, None, :] + fl["zfinal"][:, :-1, None] * cx["dirs"][hit][:, None, :]
     zeros1 = lambda: torch.zeros(1, device=dev)
+    index_off_surface = index_in_surface = None
+    if epoch < 250:                                                                 # multiply.py:549-557
+        P = len(cx["persons"])
+        off_all = torch.ones(cx["R"], P, dtype=torch.bool, device=dev)
+        in_all = torch.zeros(cx["R"], P, dtype=torch.bool, device=dev)
+        for n, p in enumerate(cx["persons"]):
+            f = graph.fg[p]
+            rays = cx["per"][p]["hit_index"][:f["Rp"]].long()
+            off_all[rays, n] = f["flags"][0]
+            in_all[rays, n] = f["flags"][1]
+        index_off_surface, index_in_surface = off_all.all(dim=1), in_all.any(dim=1)
     out = {
         "zero_pose_loss": zeros1(), "t_list": [], "fg_rgb_values_each_person_list": [],
         "cam_loc": cam[None].expand(cx["R"], 3), "hitted_mask_idx": [], "mean_hitted_vertex_list": [],
         "points": points, "rgb_values": rgb_values, "normal_values": normal_values,
-        "index_outside": input["index_outside"], "index_off_surface": None, "index_in_surface": None,
+        "index_outside": input.get("index_outside"), "index_off_surface": index_off_surface,
+        "index_in_surface": index_in_surface,
         "acc_map": acc_map, "grad_theta": grad_theta, "interpenetration_loss": zeros1(), "temporal_loss": temporal_loss,
         "acc_person_list": acc_person, "smpl_surface_loss": zeros1(), "epoch": input["current_epoch"],
     }

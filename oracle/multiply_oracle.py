@@ -237,6 +237,58 @@ def deform_inverse(x, tfs, posed_verts, skin_w):
     return skinning(x, w, tfs, inverse=True), outlier
 
 
+# ----------------------------------------------------------------------------- canonical-mesh flags
+def mesh_signed_distance(pts, face_verts, chunk=256):
+    """kaolin.metrics.trianglemesh.point_to_mesh_distance (sqrt taken, multiply.py:155-157) and kaolin.ops.mesh.check_sign
+    (multiply.py:158-160) restated in float64: |d| = distance to the closest triangle; negative when the ray
+    p + t(1,0,0), t > 0 crosses the surface an odd number of times.  kaolin 0.13 is third party and absent from
+    /root/reference: parity unpinned (closed-form geometry; differences can only arise in degenerate ray/edge hits).
+    pts (N,3), face_verts (F,3,3) -> (N,) float64."""
+    P = pts.double()
+    A, B, C = [face_verts[:, i].double() for i in range(3)]
+    nrm = torch.cross(B - A, C - A, dim=-1)
+    n2 = (nrm * nrm).sum(-1)
+    out = torch.empty(P.shape[0], dtype=torch.float64)
+
+    def seg(p, u, v):
+        uv = (v - u)[None]
+        t = (((p[:, None] - u[None]) * uv).sum(-1) / (uv * uv).sum(-1).clamp_min(1e-300)).clamp(0.0, 1.0)
+        q = u[None] + t[..., None] * uv
+        return ((p[:, None] - q) ** 2).sum(-1)
+
+    for s0 in range(0, P.shape[0], chunk):
+        p = P[s0:s0 + chunk]
+        ap = p[:, None] - A[None]
+        dpl = (ap * nrm[None]).sum(-1)
+        inside = torch.ones(p.shape[0], A.shape[0], dtype=torch.bool)
+        for u, v in ((A, B), (B, C), (C, A)):
+            e = torch.cross((v - u)[None].expand(p.shape[0], -1, -1), p[:, None] - u[None], dim=-1)
+            inside &= (e * nrm[None]).sum(-1) >= 0
+        d2 = torch.where(inside & (n2[None] > 0), dpl ** 2 / n2[None].clamp_min(1e-300),
+                         torch.minimum(torch.minimum(seg(p, A, B), seg(p, B, C)), seg(p, C, A)))
+        dist = d2.min(1)[0].sqrt()
+        # crossings of the +x ray: (y,z) crossing-number rule, then the x of the plane point
+        cn = torch.zeros(p.shape[0], A.shape[0], dtype=torch.long)
+        for u, v in ((A, B), (B, C), (C, A)):
+            uy, vy = u[None, :, 1] > p[:, None, 1], v[None, :, 1] > p[:, None, 1]
+            t = (p[:, None, 1] - u[None, :, 1]) / (v[None, :, 1] - u[None, :, 1])
+            zc = u[None, :, 2] + t * (v[None, :, 2] - u[None, :, 2])
+            cn += ((uy != vy) & (zc > p[:, None, 2])).long()
+        x = A[None, :, 0] - (nrm[None, :, 1] * (p[:, None, 1] - A[None, :, 1]) +
+                             nrm[None, :, 2] * (p[:, None, 2] - A[None, :, 2])) / nrm[None, :, 0]
+        hit = (cn % 2 == 1) & (nrm[None, :, 0] != 0) & (x > p[:, None, 0])
+        inside_mesh = hit.sum(1) % 2 == 1
+        out[s0:s0 + chunk] = torch.where(inside_mesh, -dist, dist)
+    return out
+
+
+def off_in_surface_flags(x_cano, n_samples, face_verts, threshold=0.05):
+    """Multiply.check_off_in_surface_points_cano_mesh (multiply.py:153-167)."""
+    sd = mesh_signed_distance(x_cano, face_verts).reshape(-1, n_samples)
+    m = sd.min(1)[0]
+    return m > threshold, m <= 0.0, sd
+
+
 # ----------------------------------------------------------------------------- scene model
 class PersonOracle:
     def __init__(self, sd, p, server):
