@@ -141,19 +141,20 @@ int mp_warp_inverse(const float* pts, const float* dirs, const float* pose, cons
                     float* xc, unsigned char* outlier, float* sdf_out, int* worklist, int* work_count, void* stream);
 /* The same for the final samples of the shading pass (z rows hold n_s+1 depths).  eval_mode: outliers get sdf 4 and are
  * dropped from the worklist only when their compositing alpha 1-exp(-sigma(4) dt) is exactly 0 in fp32.
- * need_flag [id] (optional) = 1 for every point that was appended. */
+ * need_flag [id] (optional) = 1 for every point that was appended; nn_index [id] (optional) = the nearest posed vertex
+ * whose skinning weights were used (the training backward needs it: deformer.py:47 detaches the weights). */
 int mp_warp_inverse_shade(const float* dirs, const float* pose, const int* hit_index, const int* hit_count,
                           const float* z, int z_stride, int n_s, int max_rays, const float* vsorted, const float* cbound,
                           const float* skin_w, const float* tfs, int eval_mode, const float* beta, float* xc,
                           unsigned char* outlier, unsigned char* need_flag, float* sdf_out, int* worklist,
-                          int* work_count, void* stream);
+                          int* work_count, int* nn_index, void* stream);
 /* Jacobian of forward skinning at canonical points (deformer.py:31-35 + multiply.py:625-641): nearest CANONICAL
  * vertex -> weights -> J = (sum_j w_j T_j)[:3,:3] -> jinv [id][9].
  * n_s > 0: points are the samples of the hit rays (id = k*n_s + s, as in mp_warp_inverse_shade) and only ids with
  * need[id] != 0 are processed; n_s == 0: explicit list of n_pts points (need, hit_count ignored). */
 int mp_warp_jacobian(const float* xc, const unsigned char* need, const int* hit_count, int max_rays, int n_s, int n_pts,
                      const float* vsorted_c, const float* cbound_c, const float* skin_w, const float* tfs, float* jinv,
-                     void* stream);
+                     int* nn_index, void* stream);
 
 /* ---- VolSDF error-bound sampler (ray_sampler.py:66-220), split at the SDF queries ---------------
  * State per hit ray k (row stride zmax = 640): zs/sdfs sorted samples and their sdf, nz count, znew/sdfnew [128]
@@ -224,7 +225,7 @@ int mp_tr_relu_bwd(const float* H, int ldh, int rows, int C, const float* dH, in
 int mp_tr_shade_in_fwd(const float* Z8, int P, int n_pts, const float* xc, const float* jinv, float* XR, float* nrm,
                        float* sdf, void* stream);
 int mp_tr_shade_in_bwd(const float* Z8, int P, int n_pts, const float* jinv, const float* dXR, const float* dsdf,
-                       const float* dnrm_extra, float* dZ8, void* stream);
+                       const float* dnrm_extra, float* dZ8, float* djinv, void* stream);
 /* eikonal samples (multiply.py:322-331): grad_theta [E][3] = d sdf/dx of points e0..e0+E of the batch */
 int mp_tr_eik_fwd(const float* Z8, int P, int e0, int E, float* grad_theta, void* stream);
 int mp_tr_eik_bwd(int P, int e0, int E, const float* dgrad, float* dZ8, void* stream);
@@ -250,6 +251,18 @@ int mp_tr_bg_points(const float* dirs, const float* cam, const float* zbg, int R
 int mp_tr_bg_comp_fwd(const float* sdf, const float* rgb, const float* zbg, int R, int NBG, float* out, void* stream);
 int mp_tr_bg_comp_bwd(const float* sdf, const float* rgb, const float* zbg, int R, int NBG, const float* dout, float* dsdf,
                       float* drgb, void* stream);
+/* pose optimisation (the reference back-propagates into BodyModelParams: smpl_pose / smpl_trans / smpl_shape):
+ *   mp_tr_pe_bwd    : adjoint of the Fourier features (value + tangent rows) w.r.t. the point, dx [P][d_in] +=
+ *   mp_tr_warp_bwd  : adjoint of x_c = (sum_j w_j tfs_j)^-1 x and of Jinv w.r.t. tfs (deformer.py:19-50, 72-88; the
+ *                     skinning weights of the nearest posed / canonical vertex are constants), dtfs [24][16] +=
+ *   mp_smpl_pose_bwd: adjoint of SMPLServer.forward's smpl_tfs (smpl.py:50-94, lbs.py:276-377) w.r.t. the 86 parameters
+ *                     [scale, transl 3, thetas 72, betas 10] (betas through the rest joints only: j_shapedirs
+ *                     [24][3][10] = J_regressor . shapedirs, or NULL); rest_joints [24][3] of the forward call */
+int mp_tr_pe_bwd(const float* x, int d_in, int P, int L, int fwd, const float* dIN, int ld, float* dx, void* stream);
+int mp_tr_warp_bwd(const float* xc, const float* dxc, const float* jinv, const float* djinv, const int* nn_posed,
+                   const int* nn_cano, int n, const float* skin_w, const float* tfs, float* dtfs, void* stream);
+int mp_smpl_pose_bwd(const int* parents, const float* params, const float* tfs_c_inv, const float* rest_joints,
+                     const float* j_shapedirs, const float* dtfs, float* dparams, void* stream);
 int mp_tr_copy_cols(const float* src, int lds, int c0s, float* dst, int ldd, int c0d, long long rows, int C, float scale,
                     int accumulate, void* stream);
 

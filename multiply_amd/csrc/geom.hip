@@ -320,7 +320,7 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
     const float* __restrict__ skin_w, const float* __restrict__ tfs, int mode, const int* __restrict__ ray_active,
     const float* __restrict__ beta_p, const int* __restrict__ launch_active, float* __restrict__ xc,
     unsigned char* __restrict__ outlier, unsigned char* __restrict__ need_flag, float* __restrict__ sdf_out,
-    int* __restrict__ worklist, int* __restrict__ work_count) {
+    int* __restrict__ worklist, int* __restrict__ work_count, int* __restrict__ nn_index) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (launch_active && *launch_active == 0) return;  // no ray of this launch is still being sampled
     float4* vs = (float4*)smem;
@@ -402,6 +402,7 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
                 xc[3 * (size_t)pid] = I[0] * qx + I[1] * qy + I[2] * qz;
                 xc[3 * (size_t)pid + 1] = I[3] * qx + I[4] * qy + I[5] * qz;
                 xc[3 * (size_t)pid + 2] = I[6] * qx + I[7] * qy + I[8] * qz;
+                if (nn_index) nn_index[pid] = bi;
                 append = worklist != nullptr;
             }
         }
@@ -426,7 +427,8 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_jacobian(const float* __r
                                                                 int n_pts, const float* __restrict__ vsorted_c,
                                                                 const float* __restrict__ cbound_c,
                                                                 const float* __restrict__ skin_w,
-                                                                const float* __restrict__ tfs, float* __restrict__ jinv) {
+                                                                const float* __restrict__ tfs, float* __restrict__ jinv,
+                                                                int* __restrict__ nn_index) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* vs = (float4*)smem;
     float4* cb = vs + NC * CL;
@@ -458,6 +460,7 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_jacobian(const float* __r
             inv3(T, I);
 #pragma unroll
             for (int i = 0; i < 9; ++i) jinv[9 * (size_t)id + i] = I[i];
+            if (nn_index) nn_index[id] = bi;
         }
     }
 }
@@ -736,7 +739,7 @@ extern "C" int mp_warp_inverse(const float* pts, const float* dirs, const float*
     hipLaunchKernelGGL(k_warp_inverse, dim3(warp_grid(n_slab, nw)), dim3(WARP_THREADS), WARP_LDS, st, pts, dirs, pose,
                        hit_index, hit_count, z, z_stride, n_s, max_rays, pts ? max_rays : 0, vsorted, cbound, skin_w, tfs,
                        mode & 3, ray_active, (const float*)nullptr, launch_active, xc, outlier, (unsigned char*)nullptr, sdf_out,
-                       worklist, work_count);
+                       worklist, work_count, (int*)nullptr);
     return (int)hipGetLastError();
 }
 
@@ -745,7 +748,7 @@ extern "C" int mp_warp_inverse_shade(const float* dirs, const float* pose, const
                                      const float* z, int z_stride, int n_s, int max_rays, const float* vsorted,
                                      const float* cbound, const float* skin_w, const float* tfs, int eval_mode,
                                      const float* beta, float* xc, unsigned char* outlier, unsigned char* need_flag,
-                                     float* sdf_out, int* worklist, int* work_count, void* stream) {
+                                     float* sdf_out, int* worklist, int* work_count, int* nn_index, void* stream) {
     if (max_rays <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     static int once = (int)hipFuncSetAttribute((const void*)k_warp_inverse, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -756,13 +759,13 @@ extern "C" int mp_warp_inverse_shade(const float* dirs, const float* pose, const
     hipLaunchKernelGGL(k_warp_inverse, dim3(warp_grid(n_slab, nw)), dim3(WARP_THREADS), WARP_LDS, st,
                        (const float*)nullptr, dirs, pose, hit_index, hit_count, z, z_stride, n_s, max_rays, 0, vsorted,
                        cbound, skin_w, tfs, eval_mode ? 2 : 0, (const int*)nullptr, beta, (const int*)nullptr, xc, outlier,
-                       need_flag, sdf_out, worklist, work_count);
+                       need_flag, sdf_out, worklist, work_count, nn_index);
     return (int)hipGetLastError();
 }
 
 extern "C" int mp_warp_jacobian(const float* xc, const unsigned char* need, const int* hit_count, int max_rays, int n_s,
                                 int n_pts, const float* vsorted_c, const float* cbound_c, const float* skin_w,
-                                const float* tfs, float* jinv, void* stream) {
+                                const float* tfs, float* jinv, int* nn_index, void* stream) {
     if ((n_s > 0 ? max_rays : n_pts) <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     static int once = (int)hipFuncSetAttribute((const void*)k_warp_jacobian, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -771,6 +774,6 @@ extern "C" int mp_warp_jacobian(const float* xc, const unsigned char* need, cons
     const int nw = WARP_THREADS / 64;
     const int n_slab = n_s > 0 ? ((max_rays + 63) / 64) * n_s : (n_pts + 63) / 64;
     hipLaunchKernelGGL(k_warp_jacobian, dim3(warp_grid(n_slab, nw)), dim3(WARP_THREADS), WARP_LDS, st, xc, need, hit_count,
-                       max_rays, n_s, n_pts, vsorted_c, cbound_c, skin_w, tfs, jinv);
+                       max_rays, n_s, n_pts, vsorted_c, cbound_c, skin_w, tfs, jinv, nn_index);
     return (int)hipGetLastError();
 }

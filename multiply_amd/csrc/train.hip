@@ -134,7 +134,8 @@ __global__ void k_shade_in_fwd(const float* __restrict__ Z8, int P, int n_pts, c
 // colour net's backward accumulates the feature adjoints into columns 1.. of the value rows
 __global__ void k_shade_in_bwd(const float* __restrict__ Z8, int P, int n_pts, const float* __restrict__ jinv,
                                const float* __restrict__ dXR, const float* __restrict__ dsdf,
-                               const float* __restrict__ dnrm_extra, float* __restrict__ dZ8) {
+                               const float* __restrict__ dnrm_extra, float* __restrict__ dZ8,
+                               float* __restrict__ djinv) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pts) return;
     const int ld = 257;
@@ -165,6 +166,9 @@ __global__ void k_shade_in_bwd(const float* __restrict__ Z8, int P, int n_pts, c
     for (int k = 0; k < 3; ++k)
         dZ8[(size_t)((k + 1) * P + i) * ld] = dv[0] * J[3 * k] + dv[1] * J[3 * k + 1] + dv[2] * J[3 * k + 2];
     dZ8[(size_t)i * ld] = dsdf[i];
+    if (djinv)   // v_j = sum_k g_k Jinv[k][j]
+        for (int k = 0; k < 3; ++k)
+            for (int j = 0; j < 3; ++j) djinv[9 * (size_t)i + 3 * k + j] = g[k] * dv[j];
 }
 
 // eikonal points: grad_theta [E][3] = d sdf / d x (raw); rows offset e0 inside the batch of P points
@@ -429,6 +433,252 @@ __global__ void k_copy_cols(const float* __restrict__ src, int lds, int c0s, flo
     *d = accumulate ? *d + v : v;
 }
 
+
+// ---- adjoint of the Fourier features w.r.t. the point: dIN [(fwd?4:1)*P][ld] -> dx [P][D] (+=)
+//   value row : x_a, sin(f x_a), cos(f x_a);  tangent row a : 1, f cos(f x_a), -f sin(f x_a)  (only dimension a's columns)
+template <int D>
+__global__ void k_pe_bwd(const float* __restrict__ x, int P, int L, int fwd, const float* __restrict__ dIN, int ld,
+                         float* __restrict__ dx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float* dv = dIN + (size_t)i * ld;
+    for (int a = 0; a < D; ++a) {
+        const float xa = x[(size_t)i * D + a];
+        const float* dt = fwd ? dIN + (size_t)((a + 1) * P + i) * ld : nullptr;
+        float acc = dv[a];
+        for (int k = 0; k < L; ++k) {
+            const float f = (float)(1 << k);
+            float sn, cs;
+            sincosf(xa * f, &sn, &cs);
+            const int cs_ = D + 2 * D * k + a, cc_ = cs_ + D;
+            acc += f * (cs * dv[cs_] - sn * dv[cc_]);
+            if (fwd) acc -= f * f * (sn * dt[cs_] + cs * dt[cc_]);
+        }
+        dx[(size_t)i * D + a] += acc;
+    }
+}
+
+// ---- adjoint of the canonical warp w.r.t. the bone transforms (deformer.py:19-50, 72-88; multiply.py:625-641)
+//   x_c = R^-1 (x - t),  [R t] = sum_j w_j tfs_j  (w = skinning weights of the nearest POSED vertex, detached)
+//   Jinv = Rc^-1,        Rc    = sum_j wc_j tfs_j[:3,:3]  (wc = weights of the nearest CANONICAL vertex)
+//   d R = -R^-T dx_c x_c^T ; d t = -R^-T dx_c ; d Rc = -Jinv^T dJinv Jinv^T ; d tfs_j += w_j [dR dt] + wc_j [dRc 0]
+// Accumulated per workgroup in LDS (24 x 12 floats), flushed with one atomic per entry.
+__global__ __launch_bounds__(256) void k_warp_bwd(const float* __restrict__ xc, const float* __restrict__ dxc,
+                                                  const float* __restrict__ jinv, const float* __restrict__ djinv,
+                                                  const int* __restrict__ nn_posed, const int* __restrict__ nn_cano, int n,
+                                                  const float* __restrict__ skin_w, const float* __restrict__ tfs,
+                                                  float* __restrict__ dtfs) {
+    constexpr int NJ = 24;
+    __shared__ float acc[NJ * 12];
+    __shared__ float tl[NJ * 16];
+    for (int i = threadIdx.x; i < NJ * 12; i += blockDim.x) acc[i] = 0.f;
+    for (int i = threadIdx.x; i < NJ * 16; i += blockDim.x) tl[i] = tfs[i];
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float* w = skin_w + (size_t)nn_posed[i] * NJ;
+        float R[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int j = 0; j < NJ; ++j) {
+            const float wj = w[j];
+            if (wj != 0.f)
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) R[3 * a + b] += wj * tl[16 * j + 4 * a + b];
+        }
+        // inverse of R
+        const float c0 = R[4] * R[8] - R[5] * R[7], c1 = R[5] * R[6] - R[3] * R[8], c2 = R[3] * R[7] - R[4] * R[6];
+        const float r = 1.0f / (R[0] * c0 + R[1] * c1 + R[2] * c2);
+        const float I[9] = {c0 * r, (R[2] * R[7] - R[1] * R[8]) * r, (R[1] * R[5] - R[2] * R[4]) * r,
+                            c1 * r, (R[0] * R[8] - R[2] * R[6]) * r, (R[2] * R[3] - R[0] * R[5]) * r,
+                            c2 * r, (R[1] * R[6] - R[0] * R[7]) * r, (R[0] * R[4] - R[1] * R[3]) * r};
+        const float d[3] = {dxc[3 * (size_t)i], dxc[3 * (size_t)i + 1], dxc[3 * (size_t)i + 2]};
+        const float q[3] = {xc[3 * (size_t)i], xc[3 * (size_t)i + 1], xc[3 * (size_t)i + 2]};
+        float u[3];   // u = R^-T dx_c
+        for (int a = 0; a < 3; ++a) u[a] = I[a] * d[0] + I[3 + a] * d[1] + I[6 + a] * d[2];
+        float dT[12];
+        for (int a = 0; a < 3; ++a) {
+            for (int b = 0; b < 3; ++b) dT[4 * a + b] = -u[a] * q[b];
+            dT[4 * a + 3] = -u[a];
+        }
+        for (int j = 0; j < NJ; ++j) {
+            const float wj = w[j];
+            if (wj != 0.f)
+                for (int e = 0; e < 12; ++e) atomicAdd(&acc[12 * j + e], wj * dT[e]);
+        }
+        if (djinv) {
+            const float* M = jinv + 9 * (size_t)i;
+            const float* dM = djinv + 9 * (size_t)i;
+            float t1[9], dRc[9];   // dRc = -M^T dM M^T
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) {
+                    float sacc = 0.f;
+                    for (int k = 0; k < 3; ++k) sacc += M[3 * k + a] * dM[3 * k + b];
+                    t1[3 * a + b] = sacc;
+                }
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) {
+                    float sacc = 0.f;
+                    for (int k = 0; k < 3; ++k) sacc += t1[3 * a + k] * M[3 * b + k];
+                    dRc[3 * a + b] = -sacc;
+                }
+            const float* wc = skin_w + (size_t)nn_cano[i] * NJ;
+            for (int j = 0; j < NJ; ++j) {
+                const float wj = wc[j];
+                if (wj != 0.f)
+                    for (int a = 0; a < 3; ++a)
+                        for (int b = 0; b < 3; ++b) atomicAdd(&acc[12 * j + 4 * a + b], wj * dRc[3 * a + b]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NJ * 12; e += blockDim.x)
+        if (acc[e] != 0.f) atomicAdd(&dtfs[16 * (e / 12) + (e % 12)], acc[e]);
+}
+
+// ---- adjoint of SMPLServer.forward's bone transforms (smpl.py:50-94, lbs.py:276-377) w.r.t. the 86 SMPL parameters
+//   [scale, transl(3), thetas(72), betas(10)];  one thread: 24 joints, a few hundred flops each.
+//   Only the transforms are differentiated: the posed vertices enter the hot path through a nearest-vertex index.
+__global__ void k_smpl_pose_bwd(const int* __restrict__ parents, const float* __restrict__ params,
+                                const float* __restrict__ tfs_c_inv, const float* __restrict__ rest_joints,
+                                const float* __restrict__ j_shapedirs, const float* __restrict__ dtfs,
+                                float* __restrict__ dparams) {
+    constexpr int NJ = 24;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float scale = params[0];
+    const float* transl = params + 1;
+    const float* th = params + 4;
+    const float* J = rest_joints;
+    float R[NJ][9], G[NJ][12], dG[NJ][12], dJ[NJ][3], dR[NJ][9];
+    for (int j = 0; j < NJ; ++j) {
+        const float ax = th[3 * j] + 1e-8f, ay = th[3 * j + 1] + 1e-8f, az = th[3 * j + 2] + 1e-8f;
+        const float ang = sqrtf(ax * ax + ay * ay + az * az);
+        const float n[3] = {th[3 * j] / ang, th[3 * j + 1] / ang, th[3 * j + 2] / ang};
+        float s, c;
+        sincosf(ang, &s, &c);
+        const float K[9] = {0.f, -n[2], n[1], n[2], 0.f, -n[0], -n[1], n[0], 0.f};
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                float kk = 0.f;
+                for (int k = 0; k < 3; ++k) kk += K[3 * a + k] * K[3 * k + b];
+                R[j][3 * a + b] = (a == b ? 1.f : 0.f) + s * K[3 * a + b] + (1.f - c) * kk;
+            }
+        const int p = parents[j];
+        float rel[3];
+        for (int a = 0; a < 3; ++a) rel[a] = J[3 * j + a] - (j > 0 ? J[3 * p + a] : 0.f);
+        if (j == 0) {
+            for (int a = 0; a < 3; ++a) { for (int b = 0; b < 3; ++b) G[0][4 * a + b] = R[0][3 * a + b]; G[0][4 * a + 3] = rel[a]; }
+        } else {
+            for (int a = 0; a < 3; ++a) {
+                for (int b = 0; b < 3; ++b) {
+                    float v = 0.f;
+                    for (int k = 0; k < 3; ++k) v += G[p][4 * a + k] * R[j][3 * k + b];
+                    G[j][4 * a + b] = v;
+                }
+                float v = G[p][4 * a + 3];
+                for (int k = 0; k < 3; ++k) v += G[p][4 * a + k] * rel[k];
+                G[j][4 * a + 3] = v;
+            }
+        }
+        for (int a = 0; a < 3; ++a) dJ[j][a] = 0.f;
+    }
+    float dscale = 0.f, dtr[3] = {0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) {
+        // tfs_j = tf_j C_j  ->  d tf = dtfs C^T  (rows 0..2; C's last row is [0,0,0,1] for the absolute case C = I)
+        float dtf[12];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 4; ++b) {
+                float v = 0.f;
+                if (tfs_c_inv) for (int k = 0; k < 4; ++k) v += dtfs[16 * j + 4 * a + k] * tfs_c_inv[16 * j + 4 * b + k];
+                else v = dtfs[16 * j + 4 * a + b];
+                dtf[4 * a + b] = v;
+            }
+        // A = G with translation column  A[a][3] = G[a][3] - sum_k G[a][k] J_j[k];  tf = scale A, tf[a][3] += scale transl[a]
+        float dA[12];
+        for (int a = 0; a < 3; ++a) {
+            float A3 = G[j][4 * a + 3];
+            for (int k = 0; k < 3; ++k) A3 -= G[j][4 * a + k] * J[3 * j + k];
+            for (int b = 0; b < 3; ++b) dscale += dtf[4 * a + b] * G[j][4 * a + b];
+            dscale += dtf[4 * a + 3] * (A3 + transl[a]);
+            dtr[a] += scale * dtf[4 * a + 3];
+            for (int b = 0; b < 4; ++b) dA[4 * a + b] = scale * dtf[4 * a + b];
+        }
+        for (int a = 0; a < 3; ++a) {
+            for (int k = 0; k < 3; ++k) {
+                dG[j][4 * a + k] = dA[4 * a + k] - dA[4 * a + 3] * J[3 * j + k];
+                dJ[j][k] -= dA[4 * a + 3] * G[j][4 * a + k];
+            }
+            dG[j][4 * a + 3] = dA[4 * a + 3];
+        }
+    }
+    for (int j = NJ - 1; j >= 1; --j) {   // G_j = G_p [R_j | rel_j]
+        const int p = parents[j];
+        float rel[3];
+        for (int a = 0; a < 3; ++a) rel[a] = J[3 * j + a] - J[3 * p + a];
+        float drel[3] = {0.f, 0.f, 0.f};
+        for (int b = 0; b < 3; ++b)
+            for (int c2 = 0; c2 < 3; ++c2) {
+                float v = 0.f;
+                for (int a = 0; a < 3; ++a) v += G[p][4 * a + b] * dG[j][4 * a + c2];
+                dR[j][3 * b + c2] = v;
+            }
+        for (int b = 0; b < 3; ++b)
+            for (int a = 0; a < 3; ++a) drel[b] += G[p][4 * a + b] * dG[j][4 * a + 3];
+        for (int a = 0; a < 3; ++a) {
+            for (int b = 0; b < 3; ++b) {
+                float v = dG[j][4 * a + 3] * rel[b];
+                for (int c2 = 0; c2 < 3; ++c2) v += dG[j][4 * a + c2] * R[j][3 * b + c2];
+                dG[p][4 * a + b] += v;
+            }
+            dG[p][4 * a + 3] += dG[j][4 * a + 3];
+        }
+        for (int a = 0; a < 3; ++a) { dJ[j][a] += drel[a]; dJ[p][a] -= drel[a]; }
+    }
+    for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) dR[0][3 * a + b] = dG[0][4 * a + b];
+        dJ[0][a] += dG[0][4 * a + 3];
+    }
+    for (int i = 0; i < 86; ++i) dparams[i] = 0.f;
+    dparams[0] = dscale;
+    for (int a = 0; a < 3; ++a) dparams[1 + a] = dtr[a];
+    for (int j = 0; j < NJ; ++j) {   // Rodrigues with angle = |theta + 1e-8|, axis = theta / angle (lbs.py:290-296)
+        const float t3[3] = {th[3 * j], th[3 * j + 1], th[3 * j + 2]};
+        const float e3[3] = {t3[0] + 1e-8f, t3[1] + 1e-8f, t3[2] + 1e-8f};
+        const float ang = sqrtf(e3[0] * e3[0] + e3[1] * e3[1] + e3[2] * e3[2]);
+        const float n[3] = {t3[0] / ang, t3[1] / ang, t3[2] / ang};
+        float s, c;
+        sincosf(ang, &s, &c);
+        const float K[9] = {0.f, -n[2], n[1], n[2], 0.f, -n[0], -n[1], n[0], 0.f};
+        float KK[9];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                float kk = 0.f;
+                for (int k = 0; k < 3; ++k) kk += K[3 * a + k] * K[3 * k + b];
+                KK[3 * a + b] = kk;
+            }
+        float dang = 0.f;
+        for (int e = 0; e < 9; ++e) dang += dR[j][e] * (c * K[e] + s * KK[e]);
+        // dK (adjoint of K): from s K and (1-c) K K  ->  dK = s dR + (1-c) (dR K^T + K^T dR)
+        float dK[9];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                float v = s * dR[j][3 * a + b];
+                for (int k = 0; k < 3; ++k) v += (1.f - c) * (dR[j][3 * a + k] * K[3 * b + k] + K[3 * k + a] * dR[j][3 * k + b]);
+                dK[3 * a + b] = v;
+            }
+        const float dn[3] = {dK[7] - dK[5], dK[2] - dK[6], dK[3] - dK[1]};
+        float ndot = 0.f;
+        for (int k = 0; k < 3; ++k) ndot += dn[k] * t3[k];
+        for (int i = 0; i < 3; ++i)
+            dparams[4 + 3 * j + i] = dang * e3[i] / ang + dn[i] / ang - ndot * e3[i] / (ang * ang * ang);
+    }
+    if (j_shapedirs)
+        for (int l = 0; l < 10; ++l) {
+            float v = 0.f;
+            for (int j = 0; j < NJ; ++j)
+                for (int k = 0; k < 3; ++k) v += dJ[j][k] * j_shapedirs[(3 * j + k) * 10 + l];
+            dparams[76 + l] = v;
+        }
+}
+
 }  // namespace
 
 #define ST (hipStream_t) stream
@@ -465,9 +715,9 @@ int mp_tr_shade_in_fwd(const float* Z8, int P, int n_pts, const float* xc, const
     return (int)hipGetLastError();
 }
 int mp_tr_shade_in_bwd(const float* Z8, int P, int n_pts, const float* jinv, const float* dXR, const float* dsdf,
-                       const float* dnrm_extra, float* dZ8, void* stream) {
+                       const float* dnrm_extra, float* dZ8, float* djinv, void* stream) {
     if (n_pts <= 0) return 0;
-    hipLaunchKernelGGL(k_shade_in_bwd, grid1(n_pts), dim3(TB), 0, ST, Z8, P, n_pts, jinv, dXR, dsdf, dnrm_extra, dZ8);
+    hipLaunchKernelGGL(k_shade_in_bwd, grid1(n_pts), dim3(TB), 0, ST, Z8, P, n_pts, jinv, dXR, dsdf, dnrm_extra, dZ8, djinv);
     return (int)hipGetLastError();
 }
 int mp_tr_eik_fwd(const float* Z8, int P, int e0, int E, float* grad_theta, void* stream) {
@@ -532,6 +782,25 @@ int mp_tr_bg_comp_fwd(const float* sdf, const float* rgb, const float* zbg, int 
 int mp_tr_bg_comp_bwd(const float* sdf, const float* rgb, const float* zbg, int R, int NBG, const float* dout, float* dsdf,
                       float* drgb, void* stream) {
     hipLaunchKernelGGL(k_bg_comp_bwd, grid1(R), dim3(TB), 0, ST, sdf, rgb, zbg, R, NBG, dout, dsdf, drgb);
+    return (int)hipGetLastError();
+}
+int mp_tr_pe_bwd(const float* x, int d_in, int P, int L, int fwd, const float* dIN, int ld, float* dx, void* stream) {
+    if (P <= 0) return 0;
+    if (d_in == 3) hipLaunchKernelGGL(k_pe_bwd<3>, grid1(P), dim3(TB), 0, ST, x, P, L, fwd, dIN, ld, dx);
+    else if (d_in == 4) hipLaunchKernelGGL(k_pe_bwd<4>, grid1(P), dim3(TB), 0, ST, x, P, L, fwd, dIN, ld, dx);
+    else return -1;
+    return (int)hipGetLastError();
+}
+int mp_tr_warp_bwd(const float* xc, const float* dxc, const float* jinv, const float* djinv, const int* nn_posed,
+                   const int* nn_cano, int n, const float* skin_w, const float* tfs, float* dtfs, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_warp_bwd, grid1(n), dim3(TB), 0, ST, xc, dxc, jinv, djinv, nn_posed, nn_cano, n, skin_w, tfs, dtfs);
+    return (int)hipGetLastError();
+}
+int mp_smpl_pose_bwd(const int* parents, const float* params, const float* tfs_c_inv, const float* rest_joints,
+                     const float* j_shapedirs, const float* dtfs, float* dparams, void* stream) {
+    hipLaunchKernelGGL(k_smpl_pose_bwd, dim3(1), dim3(64), 0, ST, parents, params, tfs_c_inv, rest_joints, j_shapedirs, dtfs,
+                       dparams);
     return (int)hipGetLastError();
 }
 int mp_tr_copy_cols(const float* src, int lds, int c0s, float* dst, int ldd, int c0d, long long rows, int C, float scale,

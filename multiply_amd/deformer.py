@@ -63,5 +63,5 @@ class SMPLDeformer(nn.Module):
         tfs = smpl_tfs.detach().float().reshape(24, 16).contiguous()
         hip.check(hip.lib().mp_warp_jacobian(hip.ptr(xc), None, None, 0, 0, n, hip.ptr(self.vsorted_c),
                                              hip.ptr(self.cbound_c), hip.ptr(self.smpl_weights[0].contiguous()),
-                                             hip.ptr(tfs), hip.ptr(jinv), hip.stream()), "mp_warp_jacobian")
+                                             hip.ptr(tfs), hip.ptr(jinv), None, hip.stream()), "mp_warp_jacobian")
         return jinv.reshape(n, 3, 3)

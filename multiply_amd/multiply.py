@@ -205,7 +205,8 @@ class Multiply(nn.Module):
                           "mp_ray_cull")
             cond = (smpl_pose[0, p, 3:] / np.pi).contiguous()          # multiply.py:270
             per[p] = dict(verts=verts, tfs=tfs, vsorted=vsorted, cbound=cbound, hit_index=hit_index,
-                          inv_index=inv_index, count=counts[n:n + 1], cond=cond)
+                          inv_index=inv_index, count=counts[n:n + 1], cond=cond, prm=prm,
+                          rest_joints=server.rest_joints() if self.training else None)
         n_hit = counts.tolist()          # the one host sync of the call: sizes the per-person workspaces
         return dict(dev=dev, R=R, uv=uv, K=K, pose=pose, dirs=dirs, far=far, per=per, persons=persons, n_hit=n_hit,
                     group=group, beta=beta, counts=counts)
@@ -308,14 +309,14 @@ class Multiply(nn.Module):
             hip.check(L.mp_warp_inverse_shade(hip.ptr(dirs), hip.ptr(pose), hip.ptr(pp["hit_index"]), hip.ptr(pp["count"]),
                                               hip.ptr(zfinal), NZ, S, Rp, hip.ptr(pp["vsorted"]), hip.ptr(pp["cbound"]),
                                               hip.ptr(skin_w), hip.ptr(pp["tfs"]), 1, hip.ptr(beta), hip.ptr(xc), None,
-                                              hip.ptr(need), hip.ptr(sdf), hip.ptr(work2), hip.ptr(wc2), st),
+                                              hip.ptr(need), hip.ptr(sdf), hip.ptr(work2), hip.ptr(wc2), None, st),
                       "mp_warp_inverse_shade")
             ph.__exit__()
             jinv = torch.empty(npts, 9, **f32)
             ph = self._ph("shade_jacobian"); ph.__enter__()
             hip.check(L.mp_warp_jacobian(hip.ptr(xc), hip.ptr(need), hip.ptr(pp["count"]), Rp, S, 0,
                                          hip.ptr(dfm.vsorted_c), hip.ptr(dfm.cbound_c), hip.ptr(skin_w), hip.ptr(pp["tfs"]),
-                                         hip.ptr(jinv), st), "mp_warp_jacobian")
+                                         hip.ptr(jinv), None, st), "mp_warp_jacobian")
             ph.__exit__()
             pk_full = hip.packed(imp, "full", 2)
             pk_full.refresh(pp["cond"])

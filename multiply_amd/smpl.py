@@ -57,6 +57,9 @@ class SMPLDeviceTables:
         self.parents_np = parents
         self.parents = f(parents.astype(np.int32))
         self.faces = np.asarray(tables["f"]).astype(np.int64)
+        # d rest-joints / d betas (J = J_regressor (v_template + shapedirs betas)): a constant table, used by the
+        # pose/shape backward (mp_smpl_pose_bwd)
+        self.j_shapedirs = torch.einsum("jv,vkl->jkl", self.j_regressor, self.shapedirs).contiguous()   # (24,3,10)
         assert self.v_template.shape == (NUM_VERTS, 3) and self.lbs_weights.shape == (NUM_VERTS, NUM_JOINTS)
 
 
@@ -130,6 +133,10 @@ class SMPLServer(nn.Module):
                                          hip.ptr(params86), None if absolute else hip.ptr(self.tfs_c_inv), hip.ptr(verts),
                                          hip.ptr(tfs), hip.ptr(joints), hip.ptr(self._work), hip.stream()),
                   "mp_smpl_pose")
+
+    def rest_joints(self):
+        """J (24,3) of the most recent pose_into() call (kernel work buffer, csrc/geom.hip W_J)"""
+        return self._work[3 * NUM_VERTS:3 * NUM_VERTS + 3 * NUM_JOINTS].clone()
 
     def forward(self, scale, transl, thetas, betas, absolute=False):
         dev = self.param_canonical.device

@@ -6,7 +6,8 @@ mode = value + spatial tangents, colour net, compositing, background) is evaluat
 MFMA GEMMs of csrc/gemm.hip, every pre-activation is kept, and the adjoint sweep -- including the mixed second
 derivatives through the normals and the eikonal term -- is the reverse pass over that forward-mode graph.
 Gradients are produced for every network parameter (weight-norm g/v, biases, lin_pose), density.beta and the frame
-latent code.  Gradients w.r.t. the SMPL pose / translation (BodyModelParams) are NOT produced yet.
+latent code, and -- when the caller's smpl_pose / smpl_trans / smpl_shape require grad (BodyModelParams in the reference's
+trainer) -- for those too, through the canonical warp, the normals' Jacobian, the pose conditioning and SMPL's bone transforms.
 
 The non-differentiable sampler (VolSDF Algorithm 1, ray_sampler.py:81-191, `torch.no_grad()` in the reference) runs on
 the fused bf16 kernels exactly like in eval mode, with the training-mode randomness drawn by torch.rand on the device.
@@ -86,7 +87,7 @@ class ImplicitTrain:
 
     def __init__(self, net, x, cond_vec, fwd):
         L = hip.lib()
-        self.net, self.fwd = net, fwd
+        self.net, self.fwd, self.x = net, fwd, x
         dev = x.device
         self.P = P = x.shape[0]
         self.rows = rows = 4 * P if fwd else P
@@ -126,14 +127,16 @@ class ImplicitTrain:
             self.X.append(Xl)
         self.out = self.Z[-1]            # [rows][257]
 
-    def backward(self, dZ_last):
-        """dZ_last [rows][257] -> accumulates dW/db of every layer; returns d cond (hoisted conditioning adjoint)"""
+    def backward(self, dZ_last, want_dx=False):
+        """dZ_last [rows][257] -> accumulates dW/db of every layer; returns d cond (hoisted conditioning adjoint).
+        want_dx: also the adjoint of the input points, self.dx [P][d_in] (pose optimisation)."""
         L = hip.lib()
         net, rows, P, E = self.net, self.rows, self.P, self.E
         Pm = P if self.fwd else 0
         r2 = 1.0 / math.sqrt(2.0)
         dZ = dZ_last
         dcond = None
+        dIN = torch.zeros(rows, E, dtype=F32, device=dZ.device) if want_dx else None
         for l in range(len(self.lins) - 1, -1, -1):
             lw, Xl = self.lins[l], self.X[l]
             out = lw.out_dim
@@ -146,10 +149,18 @@ class ImplicitTrain:
                      "mp_tr_hoist_bwd")
                 dcond = torch.zeros(net.cond_dim, dtype=F32, device=dZ.device)
                 gemm_tn(_p(lw.db), 1, off(lw.W, E), lw.in_dim, _p(dcond), net.cond_dim, 1, net.cond_dim, out)
+                if want_dx:
+                    gemm_nt(_p(dZ), out, _p(lw.WT), out, _p(dIN), E, rows, E, out, accumulate=True)
+                    self.dx = torch.zeros(P, net.d_in, dtype=F32, device=dZ.device)
+                    _chk(L.mp_tr_pe_bwd(_p(self.x), net.d_in, P, net.multires, int(self.fwd), _p(dIN), E, _p(self.dx),
+                                        hip.stream()), "mp_tr_pe_bwd")
                 break
             prev_out = self.lins[l - 1].out_dim
             dX = torch.empty(rows, lw.in_dim, dtype=F32, device=dZ.device)
             gemm_nt(_p(dZ), out, _p(lw.WT), out, _p(dX), lw.in_dim, rows, lw.in_dim, out)
+            if want_dx and l in net.skip_in:      # the skip connection's copy of the encoded input
+                _chk(L.mp_tr_copy_cols(_p(dX), lw.in_dim, prev_out, _p(dIN), E, 0, rows, E, C.c_float(r2), 1, hip.stream()),
+                     "mp_tr_copy_cols")
             dZp = torch.empty(rows, prev_out, dtype=F32, device=dZ.device)
             scale = r2 if l in net.skip_in else 1.0
             _chk(L.mp_tr_softplus_bwd(_p(self.Z[l - 1]), prev_out, rows, prev_out, Pm, C.c_float(scale), _p(dX), lw.in_dim,
@@ -287,9 +298,9 @@ def make_draws(model, cx, gen=None):
 class TrainGraph:
     """Everything one training forward keeps for its backward."""
 
-    def __init__(self, model, cx, input, cond_zero, draws, surface_flags=False):
+    def __init__(self, model, cx, input, cond_zero, draws, surface_flags=False, pose_grad=False):
         self.model, self.cx, self.input, self.cond_zero, self.draws = model, cx, input, cond_zero, draws
-        self.surface_flags = surface_flags
+        self.surface_flags, self.pose_grad = surface_flags, pose_grad
 
     # ---- forward ------------------------------------------------------------------------------------------------
     def run(self):
@@ -317,12 +328,14 @@ class TrainGraph:
             E = N_EIKONAL
             Pt = npts + E
             X = torch.empty(Pt, 3, **f32)                             # canonical points: samples, then eikonal points
+            nn_posed = torch.empty(npts, dtype=torch.int32, device=dev) if self.pose_grad else None
+            nn_cano = torch.empty(npts, dtype=torch.int32, device=dev) if self.pose_grad else None
             _chk(L.mp_warp_inverse_shade(_p(dirs), _p(pose), _p(pp["hit_index"]), _p(pp["count"]), _p(zfinal), NZ, S, Rp,
                                          _p(pp["vsorted"]), _p(pp["cbound"]), _p(skin_w), _p(pp["tfs"]), 0, _p(beta),
-                                         _p(X), None, None, None, None, None, st), "mp_warp_inverse_shade")
+                                         _p(X), None, None, None, None, None, _p(nn_posed), st), "mp_warp_inverse_shade")
             jinv = torch.empty(npts, 9, **f32)
             _chk(L.mp_warp_jacobian(_p(X), None, None, 0, 0, npts, _p(dfm.vsorted_c), _p(dfm.cbound_c), _p(skin_w),
-                                    _p(pp["tfs"]), _p(jinv), st), "mp_warp_jacobian")
+                                    _p(pp["tfs"]), _p(jinv), _p(nn_cano), st), "mp_warp_jacobian")
             flags = None
             if self.surface_flags:        # multiply.py:311-315: in / off-surface rays w.r.t. the current canonical mesh
                 fv = m.mesh_face_vertices_list[p].detach().reshape(-1, 9).to(dev).float().contiguous()
@@ -342,7 +355,8 @@ class TrainGraph:
             _chk(L.mp_tr_eik_fwd(_p(it.out), Pt, npts, E, _p(gth), st), "mp_tr_eik_fwd")
             rt = RenderTrain(ren, XA, off(it.out, 1), 257, npts, pp["cond"])
             self.fg[p] = dict(it=it, rt=rt, X=X, jinv=jinv, XA=XA, sdf=sdf, nrm=nrm, gth=gth, zfinal=zfinal, iters=iters,
-                              wcount=wcount, npts=npts, Pt=Pt, Rp=Rp, flags=flags)
+                              wcount=wcount, npts=npts, Pt=Pt, Rp=Rp, flags=flags, nn_posed=nn_posed,
+                              nn_cano=nn_cano)
             z_l.append(zfinal); sdf_l.append(sdf); rgb_l.append(rt.rgb); nrm_l.append(nrm); inv_l.append(pp["inv_index"])
 
         # ---- background (multiply.py:482-484, 514-539); depths jittered per ray in training (ray_sampler.py:32-40)
@@ -411,6 +425,7 @@ class TrainGraph:
                                    _p(d_acc_person), _p(t_dsdf), _p(t_drgb), _p(d_bg_rgb), _p(d_beta), st),
              "mp_tr_composite_bwd")
         grads = {}
+        self.pose_grads = {}
 
         def collect(obj):
             for prm, g in zip(obj.params(), obj.param_grads()):
@@ -422,13 +437,31 @@ class TrainGraph:
             dZ8 = torch.zeros(4 * Pt, 257, **f32)
             dXA = torch.empty(npts, 6, **f32)
             rt.backward(drgb_l[n], dXA, off(dZ8, 1), 257)
-            _chk(L.mp_tr_shade_in_bwd(_p(it.out), Pt, npts, _p(f["jinv"]), _p(dXA), _p(dsdf_l[n]), None, _p(dZ8), st),
-                 "mp_tr_shade_in_bwd")
+            djinv = torch.empty(npts, 9, **f32) if self.pose_grad else None
+            _chk(L.mp_tr_shade_in_bwd(_p(it.out), Pt, npts, _p(f["jinv"]), _p(dXA), _p(dsdf_l[n]), None, _p(dZ8),
+                                      _p(djinv), st), "mp_tr_shade_in_bwd")
             if d_grad_theta is not None:
                 dg = d_grad_theta.reshape(-1, 3)[n * N_EIKONAL:(n + 1) * N_EIKONAL].contiguous().float()
                 _chk(L.mp_tr_eik_bwd(Pt, npts, N_EIKONAL, _p(dg), _p(dZ8), st), "mp_tr_eik_bwd")
-            it.backward(dZ8)
+            dcond = it.backward(dZ8, want_dx=self.pose_grad)
             collect(it); collect(rt)
+            if self.pose_grad:
+                # x_c enters the SDF net (value + tangent rows) and the colour net (XA[:, :3]); the transforms also shape
+                # the normals through Jinv.  -> d tfs -> d (scale, transl, thetas, betas)   (multiply.py:196-206, 270)
+                pp = cx["per"][p]
+                server = m.smpl_server_list[p]
+                dxc = (it.dx[:npts] + dXA[:, :3]).contiguous()
+                dtfs = torch.zeros(24, 16, **f32)
+                _chk(L.mp_tr_warp_bwd(_p(f["X"]), _p(dxc), _p(f["jinv"]), _p(djinv), _p(f["nn_posed"]), _p(f["nn_cano"]),
+                                      npts, _p(server.tables.lbs_weights), _p(pp["tfs"]), _p(dtfs), st), "mp_tr_warp_bwd")
+                dprm = torch.empty(86, **f32)
+                _chk(L.mp_smpl_pose_bwd(_p(server.tables.parents), _p(pp["prm"]), _p(server.tfs_c_inv),
+                                        _p(pp["rest_joints"]), _p(server.tables.j_shapedirs), _p(dtfs), _p(dprm), st),
+                     "mp_smpl_pose_bwd")
+                if not self.cond_zero:                                   # cond = smpl_pose[3:] / pi  (multiply.py:270)
+                    dc = dcond + torch.mv(rt.lp_w.t(), rt.extra_grads[1])
+                    dprm[7:76] += dc / math.pi
+                self.pose_grads[p] = dprm
         if self.bg is not None:
             b = self.bg
             bit, brt, NB = b["it"], b["rt"], b["NB"]
@@ -453,16 +486,27 @@ class TrainGraph:
 
 class _TrainFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, graph, *params):
+    def forward(ctx, graph, smpl_pose, smpl_trans, smpl_shape, *params):
         ctx.graph, ctx.params = graph, params
+        ctx.body = (smpl_pose, smpl_trans, smpl_shape)
         outs = graph.run()
         ctx.mark_non_differentiable(outs[1])          # normal_values: no loss term reads it (loss.py:108-177)
         return outs
 
     @staticmethod
     def backward(ctx, d_rgb, d_nrm, d_acc, d_accp, d_gth):
-        g = ctx.graph.backward(d_rgb, d_acc, d_accp, d_gth)
-        return (None,) + tuple(g.get(id(p)) for p in ctx.params)
+        graph = ctx.graph
+        g = graph.backward(d_rgb, d_acc, d_accp, d_gth)
+        body = [None, None, None]
+        if graph.pose_grad:
+            sl = ((4, 76), (1, 4), (76, 86))
+            for k, t in enumerate(ctx.body):
+                if t is not None and ctx.needs_input_grad[1 + k]:
+                    gt = torch.zeros_like(t)
+                    for p, dprm in graph.pose_grads.items():
+                        gt[0, p] = dprm[sl[k][0]:sl[k][1]].to(t.device)
+                    body[k] = gt
+        return (None, *body) + tuple(g.get(id(p)) for p in ctx.params)
 
 
 def forward_train(model, input, id=-1, cond_zero_shit=False, canonical_pose=False, draws=None):
@@ -475,10 +519,12 @@ def forward_train(model, input, id=-1, cond_zero_shit=False, canonical_pose=Fals
     cond_zero = epoch < 20 or epoch % 20 == 0 or bool(cond_zero_shit)              # multiply.py:271-273
     if draws is None:
         draws = make_draws(model, cx)
-    graph = TrainGraph(model, cx, input, cond_zero, draws, surface_flags=epoch < 250)
+    body = [input["smpl_pose"], input["smpl_trans"], input["smpl_shape"]]
+    pose_grad = (not canonical_pose) and any(torch.is_tensor(t) and t.requires_grad for t in body)
+    graph = TrainGraph(model, cx, input, cond_zero, draws, surface_flags=epoch < 250, pose_grad=pose_grad)
     params = [p for p in model.parameters() if p.requires_grad]
     with torch.enable_grad():                                                       # multiply.py:176
-        rgb_values, normal_values, acc_map, acc_person, grad_theta = _TrainFn.apply(graph, *params)
+        rgb_values, normal_values, acc_map, acc_person, grad_theta = _TrainFn.apply(graph, *body, *params)
         temporal_loss = torch.zeros(1, device=dev)
         if epoch > 250:                                                             # multiply.py:242-243
             temporal_loss = torch.mean(torch.square(input["smpl_pose_last"].to(dev) - input["smpl_pose"].to(dev)))

@@ -175,9 +175,9 @@ def smpl_server_forward(T, scale, transl, thetas, betas, tfs_c_inv=None):
     verts, joints, A, W = smpl_lbs(T, betas, thetas)
     out_verts = verts * scale + transl * scale                                           # smpl.py:77-78
     out_joints = joints * scale + transl * scale
-    tf = A.clone()
-    tf[:, :3, :] = tf[:, :3, :] * scale                                                  # smpl.py:87
-    tf[:, :3, 3] = tf[:, :3, 3] + transl * scale                                         # smpl.py:88
+    top = A[:, :3, :] * scale                                                            # smpl.py:87
+    top = torch.cat([top[:, :, :3], top[:, :, 3:] + (transl * scale).reshape(1, 3, 1)], 2)   # smpl.py:88
+    tf = torch.cat([top, A[:, 3:, :]], 1)                                                # (out-of-place: autograd-safe)
     if tfs_c_inv is not None:
         tf = torch.einsum("nij,njk->nik", tf, tfs_c_inv)
     return dict(smpl_verts=out_verts, smpl_jnts=out_joints, smpl_tfs=tf, smpl_weights=W)
@@ -589,7 +589,8 @@ class MultiplyOracle:
         J = d(forward_skinning)/d x_c with the canonical-space nearest-vertex weights (deformer.py:31-35); because
         the weights are detached, J is the upper-left 3x3 of the blended transform."""
         sv = person.server
-        x_c = x_c.detach().requires_grad_(True)
+        if not x_c.requires_grad:       # (training with pose optimisation: x_c carries the graph back to the bone transforms,
+            x_c = x_c.detach().requires_grad_(True)     # multiply.py:623 `pnts_c.requires_grad_(True)` on a non-leaf)
         w_c, _, _ = query_weights(x_c.detach(), sv.verts_c, sv.weights)
         Jm = torch.einsum("pn,nij->pij", w_c, tfs)[:, :3, :3]
         out = person.implicit(x_c, cond)
@@ -684,11 +685,12 @@ class MultiplyOracle:
         beta = self.beta()
         persons = list(range(self.P)) if person_list is None else person_list
         z_l, zmax_l, sdf_l, rgb_l, nrm_l, hit_l, gth_l = [], [], [], [], [], [], []
+        body_grad = any(inp[k].requires_grad for k in ("smpl_pose", "smpl_trans", "smpl_shape"))
         for k, p in enumerate(persons):
-            with torch.no_grad():
+            with torch.set_grad_enabled(body_grad):
                 so = self.servers[p].forward(scale[p], inp["smpl_trans"][0, p], inp["smpl_pose"][0, p],
                                              inp["smpl_shape"][0, p])
-            tfs, pv = so["smpl_tfs"], so["smpl_verts"]
+            tfs, pv = so["smpl_tfs"], so["smpl_verts"].detach()
             cond = inp["smpl_pose"][0, p, 3:] / np.pi
             if cond_zero:
                 cond = cond * 0.0                                                     # multiply.py:271-273
@@ -698,7 +700,7 @@ class MultiplyOracle:
             zz = z_given[k]
             zmax, z = zz[:, -1], zz[:, :-1]
             pts = (c[:, None, :] + z[:, :, None] * d[:, None, :]).reshape(-1, 3)
-            with torch.no_grad():
+            with torch.set_grad_enabled(body_grad):   # weights are detached (deformer.py:47), the transforms are not
                 x_c, _ = deform_inverse(pts, tfs, pv, person.server.weights)          # training: outliers keep their sdf
             rgb, nrm, sdf = self.shade(person, x_c, cond, tfs, create_graph=True)
             # eikonal samples (multiply.py:322-331)

@@ -134,3 +134,71 @@ def test_training_step_reduces_loss():
         losses.append(float(lo["loss"]))
     print("[info] losses", losses)
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_smpl_pose_backward_matches_autograd(smpl_tables):
+    """mp_smpl_pose_bwd: adjoint of the bone transforms w.r.t. [scale, transl, thetas, betas] vs torch autograd on the
+    oracle's SMPLServer restatement (incl. the |theta + 1e-8| Rodrigues quirk and a zero rotation)."""
+    from multiply_amd import hip
+    from multiply_amd.smpl import SMPLServer
+    betas = np.linspace(-0.5, 0.5, 10).astype(np.float32)
+    server = SMPLServer(betas=betas, smpl_tables=smpl_tables)
+    so = O.SMPLServerOracle(smpl_tables, betas)
+    g = torch.Generator().manual_seed(7)
+    prm = torch.zeros(86)
+    prm[0] = 1.1
+    prm[1:4] = torch.randn(3, generator=g) * 0.3
+    prm[4:76] = torch.randn(72, generator=g) * 0.3
+    prm[4 + 3 * 5:4 + 3 * 6] = 0.0                      # one joint with exactly zero rotation
+    prm[76:] = torch.tensor(betas) + 0.1
+    a = torch.randn(24, 4, 4, generator=g)
+    a[:, 3, :] = 0
+    pg = prm.clone().requires_grad_(True)
+    out = so.forward(pg[0], pg[1:4], pg[4:76], pg[76:])
+    want = torch.autograd.grad((out["smpl_tfs"] * a).sum(), pg)[0]
+    d = prm.cuda()
+    verts = torch.empty(6890, 3, device="cuda"); tfs = torch.empty(24, 4, 4, device="cuda"); jn = torch.empty(24, 3, device="cuda")
+    server.pose_into(d, verts, tfs, jn)
+    assert (tfs.cpu() - out["smpl_tfs"].detach()).abs().max() < 1e-5
+    dprm = torch.empty(86, device="cuda")
+    da = a.cuda().reshape(24, 16).contiguous()
+    rj = server.rest_joints()
+    hip.check(hip.lib().mp_smpl_pose_bwd(hip.ptr(server.tables.parents), hip.ptr(d), hip.ptr(server.tfs_c_inv), hip.ptr(rj),
+                                         hip.ptr(server.tables.j_shapedirs), hip.ptr(da), hip.ptr(dprm), hip.stream()), "bwd")
+    got = dprm.cpu()
+    for name, sl in (("scale", slice(0, 1)), ("transl", slice(1, 4)), ("thetas", slice(4, 76)), ("betas", slice(76, 86))):
+        e = (got[sl] - want[sl]).abs().max().item() / (want[sl].abs().max().item() + 1e-12)
+        print(f"[grad parity] smpl backward {name}: rel-to-max err {e:.3e}")
+        assert e < 2e-4, name
+
+
+def test_training_gradients_to_body_model_params():
+    """smpl_pose / smpl_trans / smpl_shape (BodyModelParams in the reference's trainer) receive gradients through the
+    canonical warp, the normals' Jacobian and the pose conditioning."""
+    model, oracle, inp, gin, gt, loss_fn, train = _train_setup()
+    R = inp["uv"].shape[1]
+    hit = [torch.arange(R), torch.arange(R)]
+    for k in ("smpl_pose", "smpl_trans", "smpl_shape"):
+        gin[k] = gin[k].clone().requires_grad_(True)
+    gin["smpl_pose_last"] = gin["smpl_pose"].detach() + 0.01
+    out = model({**gin, "hit_index": hit})
+    lo = loss_fn(out, gt)
+    lo["loss"].backward()
+    torch.cuda.synchronize()
+    graph = model._last_train
+    oin = dict(inp)
+    for k in ("smpl_pose", "smpl_trans", "smpl_shape"):
+        oin[k] = inp[k].clone().requires_grad_(True)
+    z_given = [graph.fg[p]["zfinal"].cpu() for p in range(2)]
+    want = oracle.forward_train(oin, hit, z_given, _cpu(graph.draws))
+    tl = torch.mean(torch.square(inp["smpl_pose"] + 0.01 - oin["smpl_pose"]))
+    want.update(fg_rgb_values_each_person_list=[], index_in_surface=None, epoch=301, temporal_loss=tl,
+                smpl_surface_loss=torch.zeros(1), zero_pose_loss=torch.zeros(1), sam_mask=gin["sam_mask"].squeeze().cpu())
+    lw = loss_fn(want, gt)
+    gw = torch.autograd.grad(lw["loss"], [oin[k] for k in ("smpl_pose", "smpl_trans", "smpl_shape")])
+    assert abs(float(lo["loss"]) - float(lw["loss"])) < 1e-4
+    for k, w in zip(("smpl_pose", "smpl_trans", "smpl_shape"), gw):
+        a = gin[k].grad.cpu()
+        e = (a - w).abs().max().item() / (w.abs().max().item() + 1e-12)
+        print(f"[grad parity] d loss / d {k}: rel-to-max err {e:.3e} (|want|max {w.abs().max().item():.3e})")
+        assert e < 5e-3, k
