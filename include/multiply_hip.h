@@ -274,6 +274,13 @@ int mp_mesh_signed_distance(const float* pts, int n, const float* face_verts, in
 int mp_mesh_ray_flags(const float* sdist, int n_rays, int n_s, float threshold, unsigned char* off, unsigned char* in,
                       void* stream);
 
+/* ---- general deformer queries (deformer.py:19-50, 72-88) for K <= 8 nearest vertices; the render / training path uses
+ * the fused K = 1 kernels above.  weights [n][24] = sum_k conf_k skin_w[idx_k], conf = exp(-min(d^2,4)) normalised;
+ * outlier (optional) = sqrt(min(d_0^2, 4)) > 0.1.  mp_skinning: x' = (sum_j w_j tfs_j) x, or its inverse. */
+int mp_query_weights(const float* pts, int n, const float* verts, int n_verts, const float* skin_w, int K, float* weights,
+                     unsigned char* outlier, void* stream);
+int mp_skinning(const float* pts, const float* weights, int n, const float* tfs, int inverse, float* out, void* stream);
+
 /* library / device info: returns the gfx arch string compiled in, and checks the current device */
 const char* mp_arch(void);
 int mp_device_ok(void);

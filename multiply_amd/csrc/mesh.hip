@@ -141,3 +141,94 @@ extern "C" int mp_mesh_ray_flags(const float* sdist, int n_rays, int n_s, float 
                        threshold, off, in);
     return (int)hipGetLastError();
 }
+
+// ---- general skinning-weight query (deformer.py:37-50) with K <= 8 nearest vertices, and skinning with explicit weights
+// (deformer.py:72-88).  Not on the render/training path (K = 1 there, fused into the warp kernels); the reference's
+// trainer switches K to 7 when it transfers weights to an extracted mesh (multiply_model.py:1174-1177).
+namespace {
+constexpr int QK_MAX = 8, QV_TILE = 2048;
+
+__global__ __launch_bounds__(256) void k_query_weights(const float* __restrict__ pts, int n, const float* __restrict__ verts,
+                                                       int V, const float* __restrict__ skin_w, int K,
+                                                       float* __restrict__ weights, unsigned char* __restrict__ outlier) {
+    __shared__ float vt[QV_TILE * 3];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float p[3] = {0.f, 0.f, 0.f};
+    if (i < n) { p[0] = pts[3 * (size_t)i]; p[1] = pts[3 * (size_t)i + 1]; p[2] = pts[3 * (size_t)i + 2]; }
+    float bd[QK_MAX];
+    int bi[QK_MAX];
+    for (int k = 0; k < QK_MAX; ++k) { bd[k] = FLT_MAX; bi[k] = -1; }
+    for (int v0 = 0; v0 < V; v0 += QV_TILE) {
+        const int nv = min(QV_TILE, V - v0);
+        __syncthreads();
+        for (int k = threadIdx.x; k < nv * 3; k += blockDim.x) vt[k] = verts[(size_t)v0 * 3 + k];
+        __syncthreads();
+        if (i < n)
+            for (int v = 0; v < nv; ++v) {
+                const float dx = p[0] - vt[3 * v], dy = p[1] - vt[3 * v + 1], dz = p[2] - vt[3 * v + 2];
+                float d = dx * dx + dy * dy + dz * dz;
+                if (d < bd[K - 1]) {   // insertion into the sorted list (ties keep the lower vertex id first)
+                    int id = v0 + v;
+#pragma unroll
+                    for (int k = 0; k < QK_MAX; ++k)
+                        if (k < K && d < bd[k]) {
+                            const float td = bd[k]; const int ti = bi[k];
+                            bd[k] = d; bi[k] = id; d = td; id = ti;
+                        }
+                }
+            }
+    }
+    if (i >= n) return;
+    float conf[QK_MAX], csum = 0.f;
+    for (int k = 0; k < K; ++k) { conf[k] = expf(-fminf(bd[k], 4.0f)); csum += conf[k]; }
+    for (int j = 0; j < 24; ++j) {
+        float w = 0.f;
+        for (int k = 0; k < K; ++k) w += skin_w[(size_t)bi[k] * 24 + j] * (conf[k] / csum);
+        weights[(size_t)i * 24 + j] = w;
+    }
+    if (outlier) outlier[i] = sqrtf(fminf(bd[0], 4.0f)) > 0.1f ? 1 : 0;
+}
+
+__global__ void k_skinning(const float* __restrict__ pts, const float* __restrict__ weights, int n,
+                           const float* __restrict__ tfs, int inverse, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float T[16];
+    for (int e = 0; e < 16; ++e) T[e] = 0.f;
+    for (int j = 0; j < 24; ++j) {
+        const float w = weights[(size_t)i * 24 + j];
+        if (w != 0.f) for (int e = 0; e < 16; ++e) T[e] += w * tfs[16 * j + e];
+    }
+    const float x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+    float o[3];
+    if (!inverse) {
+        for (int a = 0; a < 3; ++a) o[a] = T[4 * a] * x + T[4 * a + 1] * y + T[4 * a + 2] * z + T[4 * a + 3];
+    } else {   // first three components of T^-1 [x,1] for T = [R t; 0 0 0 s]: R^-1 (x - t / s)
+        const float a = T[0], b = T[1], c = T[2], d = T[4], e = T[5], f = T[6], g = T[8], h = T[9], k = T[10];
+        const float c0 = e * k - f * h, c1 = f * g - d * k, c2 = d * h - e * g;
+        const float r = 1.0f / (a * c0 + b * c1 + c * c2);
+        const float qx = x - T[3] / T[15], qy = y - T[7] / T[15], qz = z - T[11] / T[15];
+        o[0] = (c0 * qx + (c * h - b * k) * qy + (b * f - c * e) * qz) * r;
+        o[1] = (c1 * qx + (a * k - c * g) * qy + (c * d - a * f) * qz) * r;
+        o[2] = (c2 * qx + (b * g - a * h) * qy + (a * e - b * d) * qz) * r;
+    }
+    for (int a2 = 0; a2 < 3; ++a2) out[3 * (size_t)i + a2] = o[a2];
+}
+}  // namespace
+
+extern "C" int mp_query_weights(const float* pts, int n, const float* verts, int n_verts, const float* skin_w, int K,
+                                float* weights, unsigned char* outlier, void* stream) {
+    if (n <= 0) return 0;
+    if (K < 1 || K > QK_MAX) return -1;
+    hipLaunchKernelGGL(k_query_weights, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pts, n, verts, n_verts,
+                       skin_w, K, weights, outlier);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_skinning(const float* pts, const float* weights, int n, const float* tfs, int inverse, float* out,
+                           void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_skinning, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pts, weights, n, tfs, inverse,
+                       out);
+    return (int)hipGetLastError();
+}

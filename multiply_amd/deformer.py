@@ -32,21 +32,29 @@ class SMPLDeformer(nn.Module):
                                          hip.ptr(self.vsorted_c), hip.ptr(self.cbound_c), hip.stream()), "mp_knn_build")
 
     def forward(self, x, smpl_tfs, return_weights=True, inverse=False, smpl_verts=None):
-        """deformer.py:19-30 for the hot-path call pattern (inverse=True, K=1): returns (x_c, outlier_mask)."""
+        """deformer.py:19-30.  The hot-path call pattern (return_weights=False, inverse=True, K=1) takes the fused warp
+        kernel; every other combination (weights only, forward skinning, K up to 8) goes through mp_query_weights /
+        mp_skinning.  Returns weights (1,N,24), or (x_transformed (N,3), outlier_mask (N,))."""
         if x.shape[0] == 0:
             return x
-        if return_weights or not inverse or self.K != 1:
-            raise NotImplementedError("only forward(..., return_weights=False, inverse=True) with K=1 is on the hot path; "
-                                      "K>1 skinning-weight queries (mesh export) are a 'next' row (SURVEY.md §8f)")
         L = hip.lib()
         dev = x.device
         x = x.detach().float().contiguous()
         verts = (self.smpl_verts if smpl_verts is None else smpl_verts)[0].detach().float().contiguous()
+        n = x.shape[0]
+        if return_weights or not inverse or self.K != 1:
+            w, outl = self._query(x, verts)
+            if return_weights:
+                return w[None]
+            tfs = smpl_tfs.detach().float().reshape(24, 16).contiguous()
+            out = torch.empty(n, 3, dtype=torch.float32, device=dev)
+            hip.check(L.mp_skinning(hip.ptr(x), hip.ptr(w), n, hip.ptr(tfs), int(bool(inverse)), hip.ptr(out), hip.stream()),
+                      "mp_skinning")
+            return out, outl.bool()
         vs = torch.empty(hip.KNN_NC * hip.KNN_CLUSTER, 4, dtype=torch.float32, device=dev)
         cb = torch.empty(hip.KNN_NC, 4, dtype=torch.float32, device=dev)
         hip.check(L.mp_knn_build(hip.ptr(verts), hip.ptr(self.knn_perm), hip.ptr(vs), hip.ptr(cb), hip.stream()),
                   "mp_knn_build")
-        n = x.shape[0]
         xc = torch.empty(n, 3, dtype=torch.float32, device=dev)
         outl = torch.empty(n, dtype=torch.uint8, device=dev)
         tfs = smpl_tfs.detach().float().reshape(24, 16).contiguous()
@@ -54,6 +62,34 @@ class SMPLDeformer(nn.Module):
                                     hip.ptr(self.smpl_weights[0].contiguous()), hip.ptr(tfs), 0, None, None, hip.ptr(xc),
                                     hip.ptr(outl), None, None, None, hip.stream()), "mp_warp_inverse")
         return xc, outl.bool()
+
+    def _query(self, x, verts):
+        n = x.shape[0]
+        w = torch.empty(n, 24, dtype=torch.float32, device=x.device)
+        outl = torch.empty(n, dtype=torch.uint8, device=x.device)
+        hip.check(hip.lib().mp_query_weights(hip.ptr(x), n, hip.ptr(verts), verts.shape[0],
+                                             hip.ptr(self.smpl_weights[0].contiguous()), int(self.K), hip.ptr(w),
+                                             hip.ptr(outl), hip.stream()), "mp_query_weights")
+        return w, outl
+
+    def query_skinning_weights_smpl_multi(self, pts, smpl_verts, smpl_weights=None):
+        """deformer.py:37-50: pts (1,N,3), smpl_verts (V,3) -> weights (1,N,24) (detached), outlier_mask (N,)"""
+        w, outl = self._query(pts[0].detach().float().contiguous(), smpl_verts.detach().float().contiguous())
+        return w[None], outl.bool()
+
+    def query_weights(self, xc):
+        """deformer.py:52-54: skinning weights of canonical points (K nearest canonical vertices)"""
+        return self.forward(xc, None, return_weights=True, inverse=False)
+
+    def forward_skinning(self, xc, cond, smpl_tfs):
+        """deformer.py:31-35: canonical -> deformed, xc (1,N,3) -> (1,N,3)"""
+        x = xc[0].detach().float().contiguous()
+        w, _ = self._query(x, self.smpl_verts[0].contiguous())
+        tfs = smpl_tfs.detach().float().reshape(24, 16).contiguous()
+        out = torch.empty_like(x)
+        hip.check(hip.lib().mp_skinning(hip.ptr(x), hip.ptr(w), x.shape[0], hip.ptr(tfs), 0, hip.ptr(out), hip.stream()),
+                  "mp_skinning")
+        return out[None]
 
     def forward_skinning_jacobian_inverse(self, xc, smpl_tfs):
         """inverse of d(forward_skinning)/d x_c at canonical points (deformer.py:31-35 + multiply.py:625-641)."""

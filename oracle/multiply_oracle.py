@@ -220,6 +220,19 @@ def query_weights(pts, verts, skin_w):
     return skin_w[idx].detach(), torch.sqrt(d2) > 0.1, idx
 
 
+def query_weights_k(pts, verts, skin_w, K):
+    """SMPLDeformer.query_skinning_weights_smpl_multi for general K (deformer.py:37-50): K nearest vertices (pytorch3d
+    knn_points = exact K-NN on squared distances), conf = exp(-min(d2,4)) normalised over the K, weights =
+    sum_k conf_k skin_w[idx_k]; outlier from the nearest one."""
+    d2 = ((pts[:, None, :] - verts[None, :, :]) ** 2).sum(-1)
+    dk, idx = torch.topk(d2, K, dim=1, largest=False)
+    dk = torch.clamp(dk, max=4)
+    conf = torch.exp(-dk)
+    conf = conf / conf.sum(-1, keepdim=True)
+    w = (skin_w[idx] * conf[..., None]).sum(1)
+    return w.detach(), torch.sqrt(dk[:, 0]) > 0.1
+
+
 def skinning(x, w, tfs, inverse):
     """skinning() (deformer.py:72-88).  x (N,3), w (N,24), tfs (24,4,4)."""
     xh = F.pad(x, (0, 1), value=1.0)

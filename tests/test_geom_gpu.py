@@ -74,3 +74,33 @@ def test_rays(golden):
     assert err("ray dirs vs reference golden", dirs, golden["g1_dirs"][0]) < 5e-7
     d, c = O.get_camera_rays(uv, pose, K)
     assert err("far", far, O.sphere_far(c[None].expand(R, -1), d, 3.0)[:, 0]) < 5e-6
+
+
+def test_general_k_weight_query_and_skinning(smpl_tables):
+    """deformer.K = 7 (the trainer's mesh-export setting): weights, forward and inverse skinning vs the oracle."""
+    from multiply_amd.smpl import SMPLServer
+    from multiply_amd.deformer import SMPLDeformer
+    betas = np.zeros(10, dtype=np.float32)
+    server = SMPLServer(betas=betas, smpl_tables=smpl_tables)
+    d = SMPLDeformer(betas=betas, server=server)
+    so = O.SMPLServerOracle(smpl_tables, betas)
+    g = torch.Generator().manual_seed(11)
+    idx = torch.randint(0, 6890, (3000,), generator=g)
+    pts = so.verts_c[idx] + torch.randn(3000, 3, generator=g) * 0.03
+    th = torch.randn(72, generator=g) * 0.2
+    out = so.forward(torch.tensor(1.0), torch.tensor([0.1, -0.2, 0.05]), th, torch.tensor(betas))
+    tfs = out["smpl_tfs"]
+    for K in (1, 3, 7):
+        d.K = K
+        w_want, out_want = O.query_weights_k(pts, so.verts_c, so.weights, K)
+        w = d.query_weights(pts.cuda())
+        assert w.shape == (1, 3000, 24)
+        e = (w[0].cpu() - w_want).abs().max().item()
+        xf = d.forward_skinning(pts.cuda()[None], None, tfs.cuda()[None])[0].cpu()
+        xf_want = O.skinning(pts, w_want, tfs, inverse=False)
+        xi, outl = d.forward(pts.cuda(), tfs.cuda()[None], return_weights=False, inverse=True, smpl_verts=server.verts_c)
+        xi_want = O.skinning(pts, w_want, tfs, inverse=True)
+        print(f"[parity] K={K}: weights {e:.2e} fwd skinning {(xf - xf_want).abs().max().item():.2e} "
+              f"inverse {(xi.cpu() - xi_want).abs().max().item():.2e}")
+        assert e < 1e-5 and (xf - xf_want).abs().max() < 1e-5 and (xi.cpu() - xi_want).abs().max() < 1e-5
+        assert torch.equal(outl.cpu(), out_want)
