@@ -210,7 +210,8 @@ int mp_composite(int n_rays, int n_person, int n_z, const int* const* inv_index,
 int mp_gemm_nt(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
                const float* bias, int bias_rows, int accumulate, int relu, void* stream);
 /* C[M,N] += A[K,M]^T . B[K,N]  (C must be initialised; fp32 atomics) */
-int mp_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, void* stream);
+int mp_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, float* colsum,
+               int colsum_rows, void* stream);
 /* Fourier features (embedders.py) of x [P][d_in] (d_in 3|4, L octaves) times `scale` into out[.][ld] at col0; fwd != 0 also
  * writes the three (d_in = 3) tangent row blocks */
 int mp_tr_pe(const float* x, int d_in, int P, int L, int fwd, float scale, float* out, int ld, int col0, void* stream);

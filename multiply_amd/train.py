@@ -42,8 +42,9 @@ def gemm_nt(A, lda, B, ldb, Cm, ldc, M, N, K, bias=None, bias_rows=0, accumulate
                               hip.stream()), "mp_gemm_nt")
 
 
-def gemm_tn(A, lda, B, ldb, Cm, ldc, M, N, K):
-    _chk(hip.lib().mp_gemm_tn(A, lda, B, ldb, Cm, ldc, M, N, K, hip.stream()), "mp_gemm_tn")
+def gemm_tn(A, lda, B, ldb, Cm, ldc, M, N, K, colsum=None, colsum_rows=0):
+    """Cm[M,N] += A[K,M]^T B[K,N];  colsum[M] += column sums of A's first colsum_rows rows (the bias gradient)"""
+    _chk(hip.lib().mp_gemm_tn(A, lda, B, ldb, Cm, ldc, M, N, K, colsum, colsum_rows, hip.stream()), "mp_gemm_tn")
 
 
 def off(t, n_floats):
@@ -141,8 +142,7 @@ class ImplicitTrain:
             lw, Xl = self.lins[l], self.X[l]
             out = lw.out_dim
             kin = E if l == 0 else lw.in_dim
-            gemm_tn(_p(dZ), out, _p(Xl), Xl.shape[1], _p(lw.dW), lw.in_dim, out, kin, rows)
-            _chk(L.mp_tr_colsum(_p(dZ), out, P, out, _p(lw.db), hip.stream()), "mp_tr_colsum")
+            gemm_tn(_p(dZ), out, _p(Xl), Xl.shape[1], _p(lw.dW), lw.in_dim, out, kin, rows, _p(lw.db), P)
             if l == 0:
                 # hoisted conditioning: dW0[:, E:] += db (x) cond ; d cond = W0[:, E:]^T db
                 _chk(L.mp_tr_hoist_bwd(_p(lw.db), out, lw.in_dim, E, net.cond_dim, _p(self.cond), _p(lw.dW), hip.stream()),
@@ -230,8 +230,7 @@ class RenderTrain:
         for l in range(nl - 1, 0, -1):
             lw, Hp = self.lins[l], self.H[l - 1]
             pout = self.lins[l - 1].out_dim
-            gemm_tn(_p(dZ), lw.out_dim, _p(Hp), pout, _p(lw.dW), lw.in_dim, lw.out_dim, lw.in_dim, n)
-            _chk(L.mp_tr_colsum(_p(dZ), lw.out_dim, n, lw.out_dim, _p(lw.db), hip.stream()), "mp_tr_colsum")
+            gemm_tn(_p(dZ), lw.out_dim, _p(Hp), pout, _p(lw.dW), lw.in_dim, lw.out_dim, lw.in_dim, n, _p(lw.db), n)
             dH = torch.empty(n, pout, dtype=F32, device=dev)
             gemm_nt(_p(dZ), lw.out_dim, _p(lw.WT), lw.out_dim, _p(dH), pout, n, pout, lw.out_dim)
             dZp = torch.empty(n, pout, dtype=F32, device=dev)
@@ -239,9 +238,8 @@ class RenderTrain:
             dZ = dZp
         lw0 = self.lins[0]
         o0 = lw0.out_dim
-        gemm_tn(_p(dZ), o0, _p(self.XA), self.na, _p(lw0.dW), lw0.in_dim, o0, self.na, n)
+        gemm_tn(_p(dZ), o0, _p(self.XA), self.na, _p(lw0.dW), lw0.in_dim, o0, self.na, n, _p(lw0.db), n)
         gemm_tn(_p(dZ), o0, self.feat_ptr, self.feat_ld, off(lw0.dW, self.c_feat), lw0.in_dim, o0, 256, n)
-        _chk(L.mp_tr_colsum(_p(dZ), o0, n, o0, _p(lw0.db), hip.stream()), "mp_tr_colsum")
         _chk(L.mp_tr_hoist_bwd(_p(lw0.db), o0, lw0.in_dim, self.c_h0, self.n_h, _p(self.hvec), _p(lw0.dW), hip.stream()),
              "mp_tr_hoist_bwd")
         dh = torch.zeros(self.n_h, dtype=F32, device=dev)

@@ -31,11 +31,13 @@ def test_gemms():
         assert rel(f"gemm_nt {M}x{N}x{K}", Cm, want) < 2e-6
         T.gemm_nt(T._p(A), K, T._p(B), K, T._p(Cm), N, M, N, K, None, 0, accumulate=True, relu=True)
         assert rel("gemm_nt accumulate+relu", Cm, torch.relu(want + A @ B.T)) < 2e-6
-    for (M, N, K) in [(256, 256, 50000), (257, 39, 3000), (3, 128, 777)]:
+    for (M, N, K) in [(256, 256, 50000), (257, 39, 3000), (3, 128, 777), (256, 257, 100001)]:
         A = torch.randn(K, M, device="cuda"); B = torch.randn(K, N, device="cuda")
         Cm = torch.ones(M, N, device="cuda")
-        T.gemm_tn(T._p(A), M, T._p(B), N, T._p(Cm), N, M, N, K)
+        cs = torch.zeros(M, device="cuda")
+        T.gemm_tn(T._p(A), M, T._p(B), N, T._p(Cm), N, M, N, K, T._p(cs), K // 2)
         assert rel(f"gemm_tn {M}x{N}x{K}", Cm, 1.0 + A.T @ B) < 2e-5
+        assert rel("gemm_tn fused column sum", cs, A[:K // 2].sum(0)) < 2e-5
 
 
 def _implicit_torch(sd, prefix, x, cond, multires):
