@@ -184,12 +184,21 @@ def main():
     shaded, sdf_evals = [], []
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    host_t = [time.perf_counter()]
+    step_ev[0].record()
+    for i in range(args.steps):
         model(gin)
+        step_ev[i + 1].record()
+        host_t.append(time.perf_counter())
         shaded.append(model.last_stats["n_shaded"])
         sdf_evals.append(model.last_stats["n_sdf_evals"])
     barrier()
     elapsed = time.perf_counter() - t0
+    if args.breakdown and rank == 0:
+        print("  per-step GPU ms (events):", [round(step_ev[i].elapsed_time(step_ev[i + 1]), 1) for i in range(args.steps)],
+              " host ms between returns:", [round(1e3 * (host_t[i + 1] - host_t[i]), 1) for i in range(args.steps)],
+              file=sys.stderr)
     model.profile = False
     if dist:
         tt = torch.tensor([elapsed], device="cuda")

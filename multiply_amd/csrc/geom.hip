@@ -260,19 +260,36 @@ __device__ __forceinline__ void knn_capped(const float4* vs, const float4* cb, f
     }
 }
 
-// Unbounded exact search: grow the cap geometrically for the lanes that found nothing (far points need few rounds; every
-// round re-culls the clusters in parallel).  want: lane participates.
+// Unbounded exact search.  An upper bound of the nearest-vertex distance is cheap: every cluster's bounding sphere
+// contains at least one vertex, so d_nn <= min_c (|p - centre_c| + radius_c)  (108 broadcast LDS reads per lane).  With
+// that per-lane cap a single culled pass finds the exact neighbour of near and far points alike (the previous scheme,
+// growing a fixed cap geometrically, re-culled the clusters up to 7 times for the far samples of a training ray).
+// want: lane participates.
+template <bool NEAR_FIRST>
 __device__ __forceinline__ void knn_unbounded(const float4* vs, const float4* cb, float px, float py, float pz, bool want,
                                               float& best, int& bi) {
-    float cap = 0.0064f;  // (0.08)^2
     best = -1.0f;
     bi = INT_MAX;
     bool todo = want;
-    while (__any(todo)) {
+    if constexpr (NEAR_FIRST) {   // canonical shading points sit near the surface: growing fixed radii resolve them fastest
+        float cap = 0.0064f;      // (0.08)^2, then (0.16)^2, (0.32)^2
+        for (int round = 0; round < 3 && __any(todo); ++round) {
+            float b2; int i2;
+            knn_capped(vs, cb, px, py, pz, todo ? cap : -1.0f, b2, i2);
+            if (todo && i2 != INT_MAX) { best = b2; bi = i2; todo = false; }
+            cap *= 4.0f;
+        }
+    }
+    if (__any(todo)) {
+        float ub = FLT_MAX;
+        for (int c = 0; c < NC; ++c) {
+            const float4 b = cb[c];
+            const float ex = px - b.x, ey = py - b.y, ez = pz - b.z;
+            ub = fminf(ub, sqrtf(ex * ex + ey * ey + ez * ez) + b.w);
+        }
         float b2; int i2;
-        knn_capped(vs, cb, px, py, pz, todo ? cap : -1.0f, b2, i2);
-        if (todo && i2 != INT_MAX) { best = b2; bi = i2; todo = false; }
-        cap *= 4.0f;
+        knn_capped(vs, cb, px, py, pz, todo ? ub * ub * 1.0005f + 1e-12f : -1.0f, b2, i2);
+        if (todo) { best = b2; bi = i2; }
     }
 }
 
@@ -369,7 +386,7 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
                                             zz <= box[5]);
         float best = -1.0f;
         int bi = INT_MAX;
-        if (mode == 0) knn_unbounded(vs, cb, x, y, zz, pid >= 0, best, bi);
+        if (mode == 0) knn_unbounded<false>(vs, cb, x, y, zz, pid >= 0, best, bi);
         else if (__any(pid >= 0 && near_box))
             knn_capped(vs, cb, x, y, zz, (pid >= 0 && near_box) ? cap2 : -1.0f, best, bi);  // idle lanes open no cluster
         bool append = false, need_far = false, need = false, is_out = false;
@@ -389,7 +406,7 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
         }
         if (__any(need_far)) {
             float b2; int i2;
-            knn_unbounded(vs, cb, x, y, zz, need_far, b2, i2);
+            knn_unbounded<false>(vs, cb, x, y, zz, need_far, b2, i2);
             if (need_far) { best = b2; bi = i2; }
         }
         if (pid >= 0) {
@@ -453,7 +470,7 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_jacobian(const float* __r
         float x = 0.f, y = 0.f, z = 0.f;
         if (id >= 0) { x = xc[3 * (size_t)id]; y = xc[3 * (size_t)id + 1]; z = xc[3 * (size_t)id + 2]; }
         float best; int bi;
-        knn_unbounded(vs, cb, x, y, z, id >= 0, best, bi);
+        knn_unbounded<true>(vs, cb, x, y, z, id >= 0, best, bi);
         if (id >= 0) {
             float T[12], s33, I[9];
             blend_tf(skin_w, tl, bi, T, s33);
