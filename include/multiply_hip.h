@@ -151,10 +151,12 @@ int mp_warp_inverse_shade(const float* dirs, const float* pose, const int* hit_i
 /* Jacobian of forward skinning at canonical points (deformer.py:31-35 + multiply.py:625-641): nearest CANONICAL
  * vertex -> weights -> J = (sum_j w_j T_j)[:3,:3] -> jinv [id][9].
  * n_s > 0: points are the samples of the hit rays (id = k*n_s + s, as in mp_warp_inverse_shade) and only ids with
- * need[id] != 0 are processed; n_s == 0: explicit list of n_pts points (need, hit_count ignored). */
+ * need[id] != 0 are processed; n_s == 0: explicit list of n_pts points (need, hit_count ignored).
+ * seed [id] (optional, with verts_c [V][3] = the canonical vertices in original order): a vertex id per point whose
+ * canonical distance bounds the search (the posed nearest vertex from mp_warp_inverse_shade); the result stays exact. */
 int mp_warp_jacobian(const float* xc, const unsigned char* need, const int* hit_count, int max_rays, int n_s, int n_pts,
                      const float* vsorted_c, const float* cbound_c, const float* skin_w, const float* tfs, float* jinv,
-                     int* nn_index, void* stream);
+                     int* nn_index, const int* seed, const float* verts_c, void* stream);
 
 /* ---- VolSDF error-bound sampler (ray_sampler.py:66-220), split at the SDF queries ---------------
  * State per hit ray k (row stride zmax = 640): zs/sdfs sorted samples and their sdf, nz count, znew/sdfnew [128]

@@ -445,7 +445,9 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_jacobian(const float* __r
                                                                 const float* __restrict__ cbound_c,
                                                                 const float* __restrict__ skin_w,
                                                                 const float* __restrict__ tfs, float* __restrict__ jinv,
-                                                                int* __restrict__ nn_index) {
+                                                                int* __restrict__ nn_index,
+                                                                const int* __restrict__ seed,
+                                                                const float* __restrict__ verts_c) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* vs = (float4*)smem;
     float4* cb = vs + NC * CL;
@@ -470,7 +472,19 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_jacobian(const float* __r
         float x = 0.f, y = 0.f, z = 0.f;
         if (id >= 0) { x = xc[3 * (size_t)id]; y = xc[3 * (size_t)id + 1]; z = xc[3 * (size_t)id + 2]; }
         float best; int bi;
-        knn_unbounded<true>(vs, cb, x, y, z, id >= 0, best, bi);
+        if (seed) {
+            // the nearest POSED vertex of the deformed point is (almost always) also the nearest canonical vertex of x_c:
+            // its canonical distance is a tight search radius, so one culled pass over very few clusters is exact
+            float cap2 = -1.0f;
+            if (id >= 0) {
+                const int sv = seed[id];
+                const float ex = x - verts_c[3 * sv], ey = y - verts_c[3 * sv + 1], ez = z - verts_c[3 * sv + 2];
+                cap2 = (ex * ex + ey * ey + ez * ez) * 1.0005f + 1e-12f;
+            }
+            knn_capped(vs, cb, x, y, z, cap2, best, bi);
+        } else {
+            knn_unbounded<true>(vs, cb, x, y, z, id >= 0, best, bi);
+        }
         if (id >= 0) {
             float T[12], s33, I[9];
             blend_tf(skin_w, tl, bi, T, s33);
@@ -782,7 +796,8 @@ extern "C" int mp_warp_inverse_shade(const float* dirs, const float* pose, const
 
 extern "C" int mp_warp_jacobian(const float* xc, const unsigned char* need, const int* hit_count, int max_rays, int n_s,
                                 int n_pts, const float* vsorted_c, const float* cbound_c, const float* skin_w,
-                                const float* tfs, float* jinv, int* nn_index, void* stream) {
+                                const float* tfs, float* jinv, int* nn_index, const int* seed, const float* verts_c,
+                                void* stream) {
     if ((n_s > 0 ? max_rays : n_pts) <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     static int once = (int)hipFuncSetAttribute((const void*)k_warp_jacobian, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -791,6 +806,6 @@ extern "C" int mp_warp_jacobian(const float* xc, const unsigned char* need, cons
     const int nw = WARP_THREADS / 64;
     const int n_slab = n_s > 0 ? ((max_rays + 63) / 64) * n_s : (n_pts + 63) / 64;
     hipLaunchKernelGGL(k_warp_jacobian, dim3(warp_grid(n_slab, nw)), dim3(WARP_THREADS), WARP_LDS, st, xc, need, hit_count,
-                       max_rays, n_s, n_pts, vsorted_c, cbound_c, skin_w, tfs, jinv, nn_index);
+                       max_rays, n_s, n_pts, vsorted_c, cbound_c, skin_w, tfs, jinv, nn_index, seed, verts_c);
     return (int)hipGetLastError();
 }

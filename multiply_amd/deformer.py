@@ -24,6 +24,7 @@ class SMPLDeformer(nn.Module):
         # canonical ("A-pose") vertices of this shape = SMPLServer(betas).verts_c (deformer.py:12-18)
         self.smpl_verts = server.verts_c
         self.smpl_weights = server.tables.lbs_weights[None]
+        self.verts_c_flat = self.smpl_verts[0].detach().float().contiguous()      # (V,3), original vertex order
         dev = self.smpl_verts.device
         self.knn_perm = torch.from_numpy(knn_cluster_perm(self.smpl_verts[0].cpu().numpy())).to(dev)
         self.vsorted_c = torch.empty(hip.KNN_NC * hip.KNN_CLUSTER, 4, dtype=torch.float32, device=dev)
@@ -99,5 +100,5 @@ class SMPLDeformer(nn.Module):
         tfs = smpl_tfs.detach().float().reshape(24, 16).contiguous()
         hip.check(hip.lib().mp_warp_jacobian(hip.ptr(xc), None, None, 0, 0, n, hip.ptr(self.vsorted_c),
                                              hip.ptr(self.cbound_c), hip.ptr(self.smpl_weights[0].contiguous()),
-                                             hip.ptr(tfs), hip.ptr(jinv), None, hip.stream()), "mp_warp_jacobian")
+                                             hip.ptr(tfs), hip.ptr(jinv), None, None, None, hip.stream()), "mp_warp_jacobian")
         return jinv.reshape(n, 3, 3)

@@ -304,19 +304,20 @@ class Multiply(nn.Module):
             rgb = torch.zeros(npts, 3, **f32)
             work2 = torch.empty(npts, **i32)
             need = torch.empty(npts, dtype=torch.uint8, device=dev)
+            nn_posed = torch.empty(npts, **i32)
             wc2 = wcount[rs.max_total_iters:]
             ph = self._ph("shade_warp"); ph.__enter__()
             hip.check(L.mp_warp_inverse_shade(hip.ptr(dirs), hip.ptr(pose), hip.ptr(pp["hit_index"]), hip.ptr(pp["count"]),
                                               hip.ptr(zfinal), NZ, S, Rp, hip.ptr(pp["vsorted"]), hip.ptr(pp["cbound"]),
                                               hip.ptr(skin_w), hip.ptr(pp["tfs"]), 1, hip.ptr(beta), hip.ptr(xc), None,
-                                              hip.ptr(need), hip.ptr(sdf), hip.ptr(work2), hip.ptr(wc2), None, st),
+                                              hip.ptr(need), hip.ptr(sdf), hip.ptr(work2), hip.ptr(wc2), hip.ptr(nn_posed), st),
                       "mp_warp_inverse_shade")
             ph.__exit__()
             jinv = torch.empty(npts, 9, **f32)
             ph = self._ph("shade_jacobian"); ph.__enter__()
             hip.check(L.mp_warp_jacobian(hip.ptr(xc), hip.ptr(need), hip.ptr(pp["count"]), Rp, S, 0,
                                          hip.ptr(dfm.vsorted_c), hip.ptr(dfm.cbound_c), hip.ptr(skin_w), hip.ptr(pp["tfs"]),
-                                         hip.ptr(jinv), None, st), "mp_warp_jacobian")
+                                         hip.ptr(jinv), None, hip.ptr(nn_posed), hip.ptr(dfm.verts_c_flat), st), "mp_warp_jacobian")
             ph.__exit__()
             pk_full = hip.packed(imp, "full", 2)
             pk_full.refresh(pp["cond"])
