@@ -144,8 +144,8 @@ def train_iterations(model, gin, steps, warmup, dist, barrier, seed=0, rays=512)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--samples", type=int, default=128, help="importance samples per ray (N_samples)")
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--tile", type=int, default=8, help="emit the frame's rays in tile x tile pixel blocks (0 = row-major)")

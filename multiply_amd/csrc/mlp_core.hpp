@@ -194,9 +194,13 @@ __device__ __forceinline__ void act_piece(f32x4 (&p)[NB], bool hidden, NB_T& Bn,
                 const float u = __builtin_amdgcn_exp2f(-fabsf(z));
                 const float w = 1.0f + u;
                 const float h = relu_f(z) + __builtin_amdgcn_logf(w);
-                const float rr = __builtin_amdgcn_rcpf(w);
+                // sigmoid(z') = 2^z' / (1 + 2^z') = 2^(z' - h'):  two instructions instead of rcp + compare + mul + select
+                // (this kernel is bound by the NUMBER of VALU issue slots between MFMAs, not by transcendental rate)
+                const float s = __builtin_amdgcn_exp2f(z - h);   // meaningful in the value lanes
 #endif
-                const float s = z >= 0.0f ? rr : u * rr;   // sigmoid(100 z_unscaled); meaningful in the value lanes
+#ifdef MP_EXP_NOTRANS
+                const float s = z >= 0.0f ? rr : u * rr;
+#endif
                 // lanes 8..15 of every 16-lane row take s from lane-8 (row_shr:8); value lanes keep their own
                 const float sf = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, s),
                                                                                         __builtin_bit_cast(int, s),
