@@ -141,6 +141,56 @@ def train_iterations(model, gin, steps, warmup, dist, barrier, seed=0, rays=512)
     return dt, [a / max(steps, 1) for a in acc], float(lo["loss"]), model.last_stats
 
 
+def train_cpu_baseline(model, gin, inp, tables, sc, n_samples, rays=128, seed=0):
+    """One training iteration of the CPU oracle (fp32 torch autograd incl. the double backward through the normals and
+    the eikonal term) on a bounded sample: `rays` random pixels of the frame instead of 512.  The sampler's depths and the
+    random draws are taken from a GPU call on the same pixels (the sampler runs without gradients in the reference)."""
+    from oracle import multiply_oracle as O
+    from multiply_amd.config import load_config
+    from multiply_amd.loss import Loss
+    dev = gin["uv"].device
+    g = torch.Generator().manual_seed(seed)
+    R = gin["uv"].shape[1]
+    sel = torch.randperm(R, generator=g)[:rays]
+    tin = dict(gin)
+    tin["uv"] = gin["uv"][:, sel.to(dev)].contiguous()
+    tin.update(current_epoch=301, index_outside=torch.zeros(rays, dtype=torch.bool, device=dev),
+               smpl_pose_last=gin["smpl_pose"] + 0.01)
+    model.train()
+    with contextlib.redirect_stdout(sys.stderr):
+        model(tin)
+    torch.cuda.synchronize()
+    graph = model._last_train
+    model.eval()
+    cx = graph.cx
+    hit = [cx["per"][p]["hit_index"][:graph.fg[p]["Rp"]].long().cpu() for p in cx["persons"]]
+    z_given = [graph.fg[p]["zfinal"].cpu() for p in cx["persons"]]
+    draws = {"person": {p: {k: v.cpu() for k, v in d.items()} for p, d in graph.draws["person"].items()},
+             "bg_rand": graph.draws["bg_rand"].cpu()}
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+    oracle = O.MultiplyOracle(sd, tables, sc["smpl_params"][0, :, 76:], O.SamplerCfg(N_samples=n_samples,
+                                                                                    N_samples_eval=max(128, n_samples)))
+    oracle.sd = sd
+    for pp in oracle.persons:
+        pp.sd = sd
+    oin = dict(inp)
+    oin["uv"] = inp["uv"][:, sel]
+    loss_fn = Loss(load_config().loss)
+    gt = {"rgb": torch.rand(1, rays, 3, generator=g)}
+    t0 = time.time()
+    want = oracle.forward_train(oin, hit, z_given, draws)
+    want.update(fg_rgb_values_each_person_list=[], index_in_surface=None, epoch=301, temporal_loss=torch.zeros(1),
+                smpl_surface_loss=torch.zeros(1), zero_pose_loss=torch.zeros(1))
+    with contextlib.redirect_stdout(sys.stderr):
+        lo = loss_fn(want, gt)
+    torch.autograd.grad(lo["loss"], [v for v in sd.values() if v.requires_grad], allow_unused=True)
+    dt = time.time() - t0
+    return {"value": 1e3 * dt, "unit": "ms/train-iter", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"ONE iteration on {rays} rays (the GPU number is for 512 rays): forward from the sampler's depths + "
+                      f"loss + autograd on the fp32 torch oracle, {dt:.1f} s", "rays": rays,
+            "ms_per_iter_scaled_to_512_rays": 1e3 * dt * 512.0 / rays}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -273,6 +323,8 @@ def main():
             out["train_iter"] = train
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, inp, tables, sc, args.samples)
+            if train is not None:
+                train["cpu_baseline"] = train_cpu_baseline(model, gin, inp, tables, sc, args.samples)
         print(json.dumps(out))
     if dist:
         td.barrier()

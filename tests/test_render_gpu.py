@@ -80,3 +80,35 @@ def test_forward_eval_box_cull_is_conservative():
     assert all(c < a for c, a in zip(n_cull, n_all))
     for k in ["rgb_values", "acc_map", "normal_values", "acc_person_list"]:
         assert report("cull vs all: " + k, cull[k], full[k].cpu())[0] < 1e-5
+
+
+def test_forward_eval_four_persons_256_samples():
+    """BASELINE.json configs[3] as a parity case: 4-person synthetic scene, N_samples = 256 (289 composited samples per ray
+    and person), own box cull.  Same tolerances as the 2-person test."""
+    import warnings
+    warnings.filterwarnings("ignore")
+    from multiply_amd.config import load_config
+    from multiply_amd.multiply import Multiply
+    from multiply_amd.synthetic import make_scene, make_smpl_tables
+    tables = make_smpl_tables(0)
+    sc = make_scene(4, seed=1, H=9, W=9)
+    opt = load_config()
+    opt.ray_sampler.N_samples = 256
+    opt.ray_sampler.N_samples_eval = 256
+    torch.manual_seed(0)
+    model = Multiply(opt, sc["smpl_params"][0, :, 76:], smpl_tables=tables).eval()
+    sp = t32(sc["smpl_params"])
+    inp = dict(uv=t32(sc["uv"]), intrinsics=t32(sc["intrinsics"]), pose=t32(sc["pose"]), smpl_params=sp,
+               smpl_pose=sp[:, :, 4:76], smpl_shape=sp[:, :, 76:], smpl_trans=sp[:, :, 1:4], idx=torch.tensor([5]))
+    got = model({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inp.items()})
+    torch.cuda.synchronize()
+    hit = [model._last["per"][p]["hit_index"][:n].long().cpu() for p, n in zip(range(4), model.last_stats["n_hit"])]
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    oracle = O.MultiplyOracle(sd, tables, sc["smpl_params"][0, :, 76:], O.SamplerCfg(N_samples=256, N_samples_eval=256))
+    want = oracle.forward_eval(inp, hit)
+    print("[info] hit rays per person", model.last_stats["n_hit"], "iterations", want["iters"])
+    assert got["acc_person_list"].shape == (81, 4)
+    assert within(report("4p rgb_values", got["rgb_values"], want["rgb_values"]), 0.1, 2e-3)
+    assert within(report("4p acc_map", got["acc_map"], want["acc_map"]), 0.15, 3e-3)
+    assert within(report("4p acc_person_list", got["acc_person_list"], want["acc_person_list"]), 0.15, 3e-3)
+    assert within(report("4p normal_values", got["normal_values"], want["normal_values"]), 0.15, 3e-3)
