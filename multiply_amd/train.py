@@ -512,6 +512,9 @@ def forward_train(model, input, id=-1, cond_zero_shit=False, canonical_pose=Fals
     tensors rgb_values / acc_map / acc_person_list / grad_theta (/ normal_values, not differentiable) hang off ONE autograd
     node whose backward is the hand-written adjoint sweep."""
     epoch = int(input["current_epoch"])
+    if model.smpl_surface_weight > 0 or model.zero_pose_weight > 0:
+        raise NotImplementedError("the smpl_surface / zero_pose regularisers (multiply.py:336-394, weight 0 in the shipped "
+                                  "configs) are not built; set their weights to 0")
     cx = model._setup(input, id, canonical_pose)
     dev = cx["dev"]
     cond_zero = epoch < 20 or epoch % 20 == 0 or bool(cond_zero_shit)              # multiply.py:271-273
