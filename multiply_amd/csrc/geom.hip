@@ -325,7 +325,7 @@ __device__ __forceinline__ void inv3(const float (&T)[12], float (&I)[9]) {
     I[6] = c2 * r; I[7] = (b * g - a * h) * r; I[8] = (a * e - b * d) * r;
 }
 
-constexpr int WARP_THREADS = 512;
+constexpr int WARP_THREADS = 1024;
 constexpr int WARP_LDS = NC * CL * 16 + NC * 16 + NJ * 16 * 4 + 32;
 
 // mode 0: all points -> xc + worklist; mode 1: eval, outliers get sdf 4 and are skipped;
