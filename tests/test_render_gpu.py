@@ -112,3 +112,95 @@ def test_forward_eval_four_persons_256_samples():
     assert within(report("4p acc_map", got["acc_map"], want["acc_map"]), 0.15, 3e-3)
     assert within(report("4p acc_person_list", got["acc_person_list"], want["acc_person_list"]), 0.15, 3e-3)
     assert within(report("4p normal_values", got["normal_values"], want["normal_values"]), 0.15, 3e-3)
+
+
+def _gpu(inp):
+    return {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inp.items()}
+
+
+def test_single_person_id_and_no_background():
+    """forward(id=p) renders one person only (multiply.py:244-247); idx=None -> white background (multiply.py:541-542)."""
+    model, oracle, inp = build(H=14, W=14)
+    R = inp["uv"].shape[1]
+    inp2 = dict(inp)
+    inp2["idx"] = None
+    got = model({**_gpu(inp2), "hit_index": [torch.arange(R), torch.arange(R)]}, id=1)
+    torch.cuda.synchronize()
+    want = oracle.forward_eval(inp2, [torch.arange(R), torch.arange(R)], person_list=[1])
+    assert got["acc_person_list"].shape == (R, 1)
+    assert within(report("id=1 rgb_values", got["rgb_values"], want["rgb_values"]), 0.1, 2e-3)
+    assert within(report("id=1 acc_map", got["acc_map"], want["acc_map"]), 0.15, 3e-3)
+    # without a background the composite is fg + T_bg * 1 = fg_rgb_values
+    assert torch.equal(got["rgb_values"], got["fg_rgb_values"])
+
+
+def test_ragged_and_empty_hit_sets():
+    """A batch where no ray meets a person's box falls back to ray 0 (multiply.py:262-263); ray counts that are not
+    multiples of the wave / tile sizes; a single ray."""
+    model, oracle, inp = build(H=16, W=16)
+    gin = _gpu(inp)
+    uv = inp["uv"]
+    # pixels far outside the image: these rays miss both bodies' boxes
+    corner = (uv[0, :, 0] < 3) & (uv[0, :, 1] < 3)
+    inp = dict(inp)
+    inp["uv"] = inp["uv"] - 4000.0
+    gin = _gpu(inp)
+    sub = dict(gin)
+    sub["uv"] = gin["uv"][:, corner.cuda()]
+    out = model(sub)
+    torch.cuda.synchronize()
+    assert model.last_stats["n_hit"] == [1, 1]            # fallback to ray 0 for both persons
+    n = int(corner.sum())
+    assert out["rgb_values"].shape == (n, 3) and torch.isfinite(out["rgb_values"]).all()
+    hit = [model._last["per"][p]["hit_index"][:1].long().cpu() for p in range(2)]
+    assert all(int(h[0]) == 0 for h in hit)
+    osub = dict(inp)
+    osub["uv"] = inp["uv"][:, corner]
+    want = oracle.forward_eval(osub, hit)
+    assert within(report("empty-hit rgb_values", out["rgb_values"], want["rgb_values"]), 0.1, 2e-3)
+    assert float(out["acc_map"].abs().max()) < 1e-3       # nothing but background
+    # ragged: 67 rays, then 1 ray
+    for cnt in (67, 1):
+        sub["uv"] = gin["uv"][:, 100:100 + cnt].contiguous()
+        out = model(sub)
+        torch.cuda.synchronize()
+        assert out["rgb_values"].shape == (cnt, 3) and out["acc_person_list"].shape == (cnt, 2)
+        osub["uv"] = inp["uv"][:, 100:100 + cnt]
+        hit = [model._last["per"][p]["hit_index"][:k].long().cpu() for p, k in zip(range(2), model.last_stats["n_hit"])]
+        want = oracle.forward_eval(osub, hit)
+        assert within(report(f"ragged {cnt} rays rgb_values", out["rgb_values"], want["rgb_values"]), 0.1, 3e-3)
+
+
+def test_canonical_pose_and_convergence_groups():
+    """canonical_pose=True re-poses SMPL to the A-pose with zero translation (multiply.py:197-202); convergence groups
+    = rendering the frame in chunks (pixel_per_batch) give exactly the chunked result."""
+    model, oracle, inp = build(H=15, W=15)        # odd size: no ray through the sphere centre (NaN quirk, see report())
+    gin = _gpu(inp)
+    R = inp["uv"].shape[1]
+    out = model(gin, canonical_pose=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out["rgb_values"]).all()
+    cin = dict(inp)
+    sp = inp["smpl_params"].clone()
+    sp[:, :, 1:4] = 0
+    sp[:, :, 4:76] = 0
+    sp[:, :, 4 + 5] = np.pi / 6
+    sp[:, :, 4 + 8] = -np.pi / 6
+    cin.update(smpl_params=sp, smpl_pose=sp[:, :, 4:76], smpl_trans=sp[:, :, 1:4])
+    hit = [model._last["per"][p]["hit_index"][:k].long().cpu() for p, k in zip(range(2), model.last_stats["n_hit"])]
+    want = oracle.forward_eval(cin, hit)
+    assert within(report("canonical pose rgb_values", out["rgb_values"], want["rgb_values"]), 0.1, 2e-3)
+    # chunked rendering == one call with convergence groups (same hit sets per chunk because groups cut the cull too)
+    model.convergence_group = 64
+    whole = model(gin)
+    torch.cuda.synchronize()
+    model.convergence_group = None
+    for c0 in (0, 64, 192):
+        part = dict(gin)
+        part["uv"] = gin["uv"][:, c0:c0 + 64].contiguous()
+        chunk = model(part)
+        torch.cuda.synchronize()
+        n = chunk["rgb_values"].shape[0]
+        d = (chunk["rgb_values"] - whole["rgb_values"][c0:c0 + n]).abs().max().item()
+        print(f"[parity] chunk {c0}: max |whole - chunk| {d:.3e}")
+        assert d < 1e-6
