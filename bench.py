@@ -5,12 +5,12 @@
 
 A "step" is one pass of the hot path (Multiply.forward, eval mode, all persons, with background) over one batch of
 synthetic input = one full 512x512 frame = 262,144 rays (BASELINE.json configs[1]: 2 persons, 128 importance
-samples/ray, bf16 MLPs).  Inputs (rays' uv, camera, SMPL parameters, weights) are resident in HBM before the timed
+samples/ray, half-precision MFMA MLPs: f16 operands, fp32 accumulate).  Inputs (rays' uv, camera, SMPL parameters, weights) are resident in HBM before the timed
 region.  N > 1: one process per GPU (torchrun), every rank renders its own frames of the sequence (rays/frames shard
 without any data-path collective -> weak scaling); time = max over ranks between barriers.
 
 The JSON line also carries
-  roofline     : the dominant kernel's algorithmic FLOP/s (HIP events inside the timed region) vs the bf16 MFMA peak
+  roofline     : the dominant kernel's algorithmic FLOP/s (HIP events inside the timed region) vs the dense 16-bit MFMA peak
   cpu_baseline : the CPU oracle (fp32 torch restatement of the reference path) timed on this host on a bounded sample
 """
 import argparse
@@ -27,7 +27,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 M_IMP, M_REN, M_BGIMP, M_BGREN = 542208, 266496, 532736, 40704      # MACs / point
-PEAK_BF16_TFLOPS = 2500.0                                           # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 2500.0                                           # MI355X dense bf16 / f16 MFMA (MI355X_MICROARCH.md)
 
 
 def build_model(n_samples, seed=0, H=512, W=512, P=2, tile=8):
@@ -307,7 +307,7 @@ def main():
             "metric": "rays/sec rendering full 512x512 frames (eval forward, all persons, with background)",
             "value": R * args.steps * world / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"2-person synthetic SMPL scene, {args.res}x{args.res} rays/frame, N_samples="
                                    f"{args.samples} (+32 extra +2 bounds = {args.samples + 33} composited samples/ray/"
                                    f"person), N_samples_eval={max(128, args.samples)}, 32 background samples, "

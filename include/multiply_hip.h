@@ -45,7 +45,7 @@ typedef struct {
 
 /* ---- weights -------------------------------------------------------------------------------
  * Packs one linear layer (optionally weight-normalised: w = g * v / ||v||_row,
- * networks.py:82-83) into the bf16 MFMA-fragment layout of csrc/mlp_core.hpp and writes its
+ * networks.py:82-83) into the half (f16) MFMA-fragment layout of csrc/mlp_core.hpp and writes its
  * fp32 bias row, with an optional hoisted contribution  bias[r] += sum_c W[r][hoist_col0+c] *
  * hoist_vec[c]  (the pose / frame conditioning that the reference concatenates to every point,
  * networks.py:164-165, 279-281, 275-276, is the same for all points of a call).
@@ -77,7 +77,7 @@ int mp_mlp_full(const MpNet* net, const void* wpack, const float* bias, const fl
  * 256 features in one pass (replaces the second forward + autograd.grad of multiply.py:643-659), then
  * normal = normalize(normalize(grad . Jinv), eps=1e-6) (multiply.py:661, :606).
  *   worklist[i] = point id; xc [*][3]; jinv [*][9] (row-major inverse of d x_d / d x_c)
- *   sdf_out[id], normal_out[id][3]; feat_frag: bf16 B-fragments, 512 B per WORK INDEX (consumed by mp_mlp_color) */
+ *   sdf_out[id], normal_out[id][3]; feat_frag: f16 B-fragments, 512 B per WORK INDEX (consumed by mp_mlp_color) */
 int mp_mlp_shade(const MpNet* net, const void* wpack, const float* bias, const float* xc, const float* jinv,
                  const int* worklist, const int* count, int max_count, float* sdf_out, float* normal_out,
                  void* feat_frag, void* stream);

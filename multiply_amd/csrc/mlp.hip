@@ -31,45 +31,45 @@ struct Lds {
     static constexpr int total = scratch + WAVES * PTS * 16;  // 4 floats per column
 };
 
-// Fourier features of a D-vector into one staging row (bf16): [x, sin(2^0 x), cos(2^0 x), ...]  (embedders.py)
+// Fourier features of a D-vector into one staging row (half): [x, sin(2^0 x), cos(2^0 x), ...]  (embedders.py)
 template <int D, int L, int KS_IN>
-__device__ __forceinline__ void stage_pe(__bf16* row, const float (&x)[D]) {
+__device__ __forceinline__ void stage_pe(op_t* row, const float (&x)[D]) {
     constexpr int NF = D + 2 * D * L;
     static_assert(NF <= KS_IN * 32, "encoding does not fit the input K steps");
 #pragma unroll
-    for (int a = 0; a < D; ++a) row[a] = (__bf16)x[a];
+    for (int a = 0; a < D; ++a) row[a] = (op_t)x[a];
 #pragma unroll
     for (int a = 0; a < D; ++a) {
         float s, c;
         sincosf(x[a], &s, &c);
 #pragma unroll
         for (int k = 0; k < L; ++k) {
-            row[D + 2 * D * k + a] = (__bf16)s;
-            row[D + 2 * D * k + D + a] = (__bf16)c;
+            row[D + 2 * D * k + a] = (op_t)s;
+            row[D + 2 * D * k + D + a] = (op_t)c;
             const float s2 = 2.0f * s * c, c2 = 1.0f - 2.0f * s * s;  // angle doubling: next octave
             s = s2;
             c = c2;
         }
     }
 #pragma unroll
-    for (int f = NF; f < KS_IN * 32; ++f) row[f] = (__bf16)0.0f;
+    for (int f = NF; f < KS_IN * 32; ++f) row[f] = (op_t)0.0f;
 }
 
 // d/dx_axis of the 3-D, L-octave Fourier features (tangent row for forward mode)
 template <int L, int KS_IN>
-__device__ __forceinline__ void stage_pe_tangent(__bf16* row, const float (&x)[3], int axis) {
+__device__ __forceinline__ void stage_pe_tangent(op_t* row, const float (&x)[3], int axis) {
     constexpr int D = 3;
 #pragma unroll
-    for (int f = 0; f < KS_IN * 32; ++f) row[f] = (__bf16)0.0f;
+    for (int f = 0; f < KS_IN * 32; ++f) row[f] = (op_t)0.0f;
     float s, c;
     const float xa = axis == 0 ? x[0] : (axis == 1 ? x[1] : x[2]);
     sincosf(xa, &s, &c);
-    row[axis] = (__bf16)1.0f;
-    float f = 1.0f;
+    row[axis] = (op_t)TANGENT_SCALE;
+    float f = TANGENT_SCALE;
 #pragma unroll
     for (int k = 0; k < L; ++k) {
-        row[D + 2 * D * k + axis] = (__bf16)(f * c);
-        row[D + 2 * D * k + D + axis] = (__bf16)(-f * s);
+        row[D + 2 * D * k + axis] = (op_t)(f * c);
+        row[D + 2 * D * k + D + axis] = (op_t)(-f * s);
         const float s2 = 2.0f * s * c, c2 = 1.0f - 2.0f * s * s;
         s = s2;
         c = c2;
@@ -78,11 +78,11 @@ __device__ __forceinline__ void stage_pe_tangent(__bf16* row, const float (&x)[3
 }
 
 template <int NB>
-__device__ __forceinline__ void zero_b(bf16x8 (&B)[KS_REG][NB]) {
+__device__ __forceinline__ void zero_b(opx8 (&B)[KS_REG][NB]) {
 #pragma unroll
     for (int k = 0; k < KS_REG; ++k)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) B[k][nb] = (bf16x8)(__bf16)0.0f;
+        for (int nb = 0; nb < NB; ++nb) B[k][nb] = (opx8)(op_t)0.0f;
 }
 
 // ------------------------------------------------------------------------------------------------ sdf only
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_sdf(const NetDesc net, const
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int count = count_p ? min(*count_p, max_count) : max_count;
     float* bias_lds = (float*)(smem + L::bias0);
-    __bf16* stage = (__bf16*)(smem + L::stage) + wave * L::PTS * in_stride(KS_IN);
+    op_t* stage = (op_t*)(smem + L::stage) + wave * L::PTS * in_stride(KS_IN);
     load_bias(net, bias, bias_lds);
     for (int t = blockIdx.x; t * L::TILE < count; t += gridDim.x) {
         const int w = t * L::TILE + wave * L::PTS + lane;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_sdf(const NetDesc net, const
             if (id >= 0) { x[0] = xc[3 * (size_t)id]; x[1] = xc[3 * (size_t)id + 1]; x[2] = xc[3 * (size_t)id + 2]; }
             stage_pe<3, 6, KS_IN>(stage + lane * in_stride(KS_IN), x);
         }
-        bf16x8 Bcur[KS_REG][NB];
+        opx8 Bcur[KS_REG][NB];
         f32x4 out[NB];
         zero_b<NB>(Bcur);
         prologue<KS_IN, WAVES>(net, wpack, smem + L::ring, wave, lane);  // barrier inside: staging rows visible
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_full(const NetDesc net, cons
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* bias_lds = (float*)(smem + L::bias0);
-    __bf16* stage = (__bf16*)(smem + L::stage) + wave * L::PTS * in_stride(KS_IN);
+    op_t* stage = (op_t*)(smem + L::stage) + wave * L::PTS * in_stride(KS_IN);
     load_bias(net, bias, bias_lds);
     for (int t = blockIdx.x; t * L::TILE < n; t += gridDim.x) {
         const int id0 = t * L::TILE + wave * L::PTS;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_full(const NetDesc net, cons
             for (int a = 0; a < D_IN; ++a) xi[a] = id >= 0 ? x[(size_t)id * D_IN + a] : 0.f;
             stage_pe<D_IN, LFREQ, KS_IN>(stage + lane * in_stride(KS_IN), xi);
         }
-        bf16x8 Bcur[KS_REG][NB];
+        opx8 Bcur[KS_REG][NB];
         f32x4 out[NB];
         zero_b<NB>(Bcur);
         prologue<KS_IN, WAVES>(net, wpack, smem + L::ring, wave, lane);
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_full(const NetDesc net, cons
 // 8 waves (2 per SIMD), each 8 points in the half-block tangent layout of mlp_core.hpp:
 //   block 0 = [values of points 0..7 | d/dx], block 1 = [d/dy | d/dz].
 // Feature fragments are written for tiles of 64 work items in the colour kernel's 16-column block layout:
-//   feat_frag[tile][ks][block = wave/2][lane' = (col + 8*(wave&1)) + 16 g][8 bf16]
+//   feat_frag[tile][ks][block = wave/2][lane' = (col + 8*(wave&1)) + 16 g][8 halves]
 __global__ __launch_bounds__(512) void k_mlp_shade(const NetDesc net, const char* __restrict__ wpack,
                                                    const float* __restrict__ bias, const float* __restrict__ xc,
                                                    const float* __restrict__ jinv, const int* __restrict__ worklist,
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(512) void k_mlp_shade(const NetDesc net, const char
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int count = count_p ? min(*count_p, max_count) : max_count;
     float* bias_lds = (float*)(smem + L::bias0);
-    __bf16* stage = (__bf16*)(smem + L::stage) + wave * L::PTS * in_stride(KS_IN);
+    op_t* stage = (op_t*)(smem + L::stage) + wave * L::PTS * in_stride(KS_IN);
     load_bias(net, bias, bias_lds);
     for (int t = blockIdx.x; t * 64 < count; t += gridDim.x) {
         // staging: lane l < 32 builds column l: block l>>4, column l&15 -> point (l&7), role 2*(l>>4) + ((l>>3)&1)
@@ -190,11 +190,11 @@ __global__ __launch_bounds__(512) void k_mlp_shade(const NetDesc net, const char
         if (lane < 32) {
             float x[3] = {0.f, 0.f, 0.f};
             if (id >= 0) { x[0] = xc[3 * (size_t)id]; x[1] = xc[3 * (size_t)id + 1]; x[2] = xc[3 * (size_t)id + 2]; }
-            __bf16* row = stage + lane * in_stride(KS_IN);
+            op_t* row = stage + lane * in_stride(KS_IN);
             if (role == 0) stage_pe<3, 6, KS_IN>(row, x);
             else stage_pe_tangent<6, KS_IN>(row, x, role - 1);
         }
-        bf16x8 Bcur[KS_REG][NB];
+        opx8 Bcur[KS_REG][NB];
         f32x4 out[NB];
         zero_b<NB>(Bcur);
         prologue<KS_IN, WAVES>(net, wpack, smem + L::ring, wave, lane);
@@ -203,12 +203,14 @@ __global__ __launch_bounds__(512) void k_mlp_shade(const NetDesc net, const char
             const int lp = ((lane & 15) + 8 * (wave & 1)) + 16 * (lane >> 4);
 #pragma unroll
             for (int ks = 0; ks < KS_REG; ++ks)
-                *(bf16x8*)(feat_frag + (((size_t)t * KS_REG + ks) * 4 + (wave >> 1)) * 1024 + lp * 16) = Bcur[ks][0];
+                *(opx8*)(feat_frag + (((size_t)t * KS_REG + ks) * 4 + (wave >> 1)) * 1024 + lp * 16) = Bcur[ks][0];
         }
         // row 0 of the last layer: lanes 0..7 hold sdf (block 0) and d/dy (block 1), lanes 8..15 d/dx and d/dz
-        const float gx = __shfl(out[0][0], (lane & 7) + 8), gz = __shfl(out[1][0], (lane & 7) + 8);
+        // (tangent columns are carried at TANGENT_SCALE; the normalisation below is scale-free but for its eps clamps)
+        constexpr float TS_INV = 1.0f / TANGENT_SCALE;
+        const float gx = TS_INV * __shfl(out[0][0], (lane & 7) + 8), gz = TS_INV * __shfl(out[1][0], (lane & 7) + 8);
         if (lane < 8 && id >= 0) {
-            const float gy = out[1][0];
+            const float gy = TS_INV * out[1][0];
             const float* Ji = jinv + 9 * (size_t)id;
             float n0 = gx * Ji[0] + gy * Ji[3] + gz * Ji[6];
             float n1 = gx * Ji[1] + gy * Ji[4] + gz * Ji[7];
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_color(const NetDesc net, con
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int count = count_p ? min(*count_p, max_count) : max_count;
     float* bias_lds = (float*)(smem + L::bias0);
-    __bf16* stage = (__bf16*)(smem + L::stage) + wave * L::PTS * in_stride(KS_IN);
+    op_t* stage = (op_t*)(smem + L::stage) + wave * L::PTS * in_stride(KS_IN);
     load_bias(net, bias, bias_lds);
     for (int t = blockIdx.x; t * L::TILE < count; t += gridDim.x) {
         const int w0 = t * L::TILE + wave * L::PTS;   // first work item of this wave
@@ -248,26 +250,26 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_color(const NetDesc net, con
         const int w = w0 + lane;
         const int id = (lane < L::PTS && w < count) ? (worklist ? worklist[w] : w) : -1;
         if (lane < L::PTS) {
-            __bf16* row = stage + lane * in_stride(KS_IN);
+            op_t* row = stage + lane * in_stride(KS_IN);
 #pragma unroll
-            for (int f = 0; f < KS_IN * 32; ++f) row[f] = (__bf16)0.0f;
+            for (int f = 0; f < KS_IN * 32; ++f) row[f] = (op_t)0.0f;
             if (id >= 0) {
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
-                    row[a] = (__bf16)xc[3 * (size_t)id + a];
-                    row[3 + a] = (__bf16)normal[3 * (size_t)id + a];
+                    row[a] = (op_t)xc[3 * (size_t)id + a];
+                    row[3 + a] = (op_t)normal[3 * (size_t)id + a];
                 }
             }
         }
-        bf16x8 Bcur[KS_REG][NB];
+        opx8 Bcur[KS_REG][NB];
         f32x4 out[NB];
         const bool live = w0 < count;
 #pragma unroll
         for (int ks = 0; ks < KS_REG; ++ks)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
-                Bcur[ks][nb] = live ? *(const bf16x8*)(feat_frag + (((size_t)tile * KS_REG + ks) * 4 + nb0 + nb) * 1024 + lane * 16)
-                                    : (bf16x8)(__bf16)0.0f;
+                Bcur[ks][nb] = live ? *(const opx8*)(feat_frag + (((size_t)tile * KS_REG + ks) * 4 + nb0 + nb) * 1024 + lane * 16)
+                                    : (opx8)(op_t)0.0f;
         prologue<KS_IN, WAVES>(net, wpack, smem + L::ring, wave, lane);
         run_net<NB, false, KS_IN, HID_RELU, WAVES>(net, wpack, bias_lds, smem + L::ring, Bcur, stage, out, wave, lane);
 #pragma unroll
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_background(const NetDesc net_imp
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* bias_lds0 = (float*)(smem + L::bias0);
     float* bias_lds1 = (float*)(smem + L::bias1);
-    __bf16* stage = (__bf16*)(smem + L::stage) + wave * L::PTS * in_stride(KS_IN);
+    op_t* stage = (op_t*)(smem + L::stage) + wave * L::PTS * in_stride(KS_IN);
     float* scr = (float*)(smem + L::scratch) + wave * L::PTS * 4;
     load_bias(net_imp, bias_imp, bias_lds0);
     load_bias(net_ren, bias_ren, bias_lds1);
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_background(const NetDesc net_imp
             const float x4[4] = {pn[0] / pnn, pn[1] / pnn, pn[2] / pnn, depth};
             stage_pe<4, 10, KS_IN>(stage + lane * in_stride(KS_IN), x4);
         }
-        bf16x8 Bcur[KS_REG][NB];
+        opx8 Bcur[KS_REG][NB];
         f32x4 out[NB];
         zero_b<NB>(Bcur);
         prologue<KS_IN, WAVES>(net_imp, wp_imp, smem + L::ring, wave, lane);

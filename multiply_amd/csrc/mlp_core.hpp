@@ -1,4 +1,5 @@
-// Register-resident fused MLP core for gfx950 (CDNA4), bf16 MFMA 16x16x32, fp32 accumulate.
+// Register-resident fused MLP core for gfx950 (CDNA4), f16 MFMA 16x16x32 (same rate as bf16, 10-bit mantissa), fp32
+// accumulate.
 //
 // Replaces the per-layer torch.nn.Linear + Softplus/ReLU chain of the reference's
 // ImplicitNet.forward (code/lib/model/networks.py:160-181) and RenderingNet.forward
@@ -15,7 +16,7 @@
 // k-slots 8g..8g+7 of every 32-slot K step of the next layer, the host packs the
 // weights with the K permutation
 //     slot(ks, g, e) <-> feature 32*ks + (e<4 ? 4g+e : 16+4g+(e-4))
-// (see pack_weights.py / mp_pack_weights), so that bf16(act(D)) of output blocks
+// (see pack_weights.py / mp_pack_weights), so that half(act(D)) of output blocks
 // (2ks, 2ks+1) IS the B fragment of K step ks: no LDS round trip, no cross-lane moves.
 //
 // A wave owns NB column blocks of 16 columns.  Plain mode: 16*NB different points (NB = 2 with 8 waves per workgroup
@@ -29,12 +30,19 @@
 
 namespace mp {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// MFMA operand element: IEEE half.  Same matrix-core rate as bf16 on gfx950, 3 more mantissa bits, and -- the reason it is
+// used -- the activation code can run on PACKED pairs (v_pk_*_f16: two rows per instruction): this kernel family is bound
+// by the number of VALU issue slots between MFMAs.  Range: hidden values carry the factor K = 100 log2(e) = 144 (scaled
+// units, below), so |z| < 65504 / 144 = 454; tangent columns carry K * TANGENT_SCALE.
+typedef _Float16 op_t;
+typedef op_t opx8 __attribute__((ext_vector_type(8)));
+typedef op_t h2 __attribute__((ext_vector_type(2)));
+constexpr float TANGENT_SCALE = 0.0625f;   // forward-mode tangent columns are carried at 1/16 (undone on output)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int KS_REG = 8;   // K steps (32 slots each) fed from registers = previous layer output (<=256 feats)
 // KS_IN (template parameter, 2 or 3): K steps fed from the encoded network input (<=64 / 96 feats: PE, normals ...)
-constexpr int TILE_BYTES = 1024;                  // one 16x32 bf16 A tile, fragment order: [lane][8]
+constexpr int TILE_BYTES = 1024;                  // one 16x32 half A tile, fragment order: [lane][8]
 constexpr int CHUNK_MB = 2;                       // 32 output rows = one K step of the next layer
 constexpr int MAX_CHUNKS = 9;                     // 8 chunks = 256 rows, +1 "extra output" chunk
 constexpr int MAX_LAYERS = 10;
@@ -42,7 +50,7 @@ constexpr int BIAS_STRIDE = MAX_CHUNKS * 32;      // 288 floats per layer
 __host__ __device__ constexpr int mb_bytes(int ks_in) { return (KS_REG + ks_in) * TILE_BYTES; }  // all K steps of 16 rows
 __host__ __device__ constexpr int chunk_bytes(int ks_in) { return CHUNK_MB * mb_bytes(ks_in); }  // 20 / 22 KiB
 constexpr int RING_SLOTS = 3;   // weight chunks are loaded two chunks ahead of their use
-__host__ __device__ constexpr int in_stride(int ks_in) { return ks_in * 32 + 8; }  // bf16 per staging row (+pad)
+__host__ __device__ constexpr int in_stride(int ks_in) { return ks_in * 32 + 8; }  // halves per staging row (+pad)
 
 enum Act : int { ACT_NONE = 0, ACT_SOFTPLUS = 1, ACT_RELU = 2 };
 
@@ -106,13 +114,10 @@ __device__ __forceinline__ void issue_chunk(const char* __restrict__ wpack, char
     }
 }
 
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-    const bf16x2 p = {(__bf16)a, (__bf16)b};
-    return __builtin_bit_cast(unsigned, p);
-}
+__device__ __forceinline__ h2 to_h2(float a, float b) { return (h2){(op_t)a, (op_t)b}; }   // one v_cvt_pk_f16_f32 (RTNE)
+__device__ __forceinline__ unsigned bits(h2 v) { return __builtin_bit_cast(unsigned, v); }
 
 // Next-layer K operand under construction.  With NB = 4 the live state (Bcur 128 + Bnext 128 + input 32 + accumulators)
 // exceeds the 256 architectural VGPRs; left to itself hipcc parks arbitrary pieces in AGPRs and pays a
@@ -121,14 +126,13 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 template <int NB, bool IN_AGPR>
 struct NextB {
     unsigned r[KS_REG][NB][4];
-    __device__ __forceinline__ void put(int c, int nb, int half, const f32x4& v) {
-        const unsigned lo = pack_bf16(v[0], v[1]), hi = pack_bf16(v[2], v[3]);
+    // rows (2 j, 2 j + 1) of half-block `half` of K step c, already packed
+    __device__ __forceinline__ void put(int c, int nb, int half, int j, h2 v) {
+        const unsigned u = bits(v);
         if constexpr (IN_AGPR) {
-            asm("v_accvgpr_write_b32 %0, %1" : "=a"(r[c][nb][2 * half]) : "v"(lo));
-            asm("v_accvgpr_write_b32 %0, %1" : "=a"(r[c][nb][2 * half + 1]) : "v"(hi));
+            asm("v_accvgpr_write_b32 %0, %1" : "=a"(r[c][nb][2 * half + j]) : "v"(u));
         } else {
-            r[c][nb][2 * half] = lo;
-            r[c][nb][2 * half + 1] = hi;
+            r[c][nb][2 * half + j] = u;
         }
     }
     __device__ __forceinline__ void zero() {
@@ -142,7 +146,7 @@ struct NextB {
                     else r[c][nb][i] = 0u;
                 }
     }
-    __device__ __forceinline__ bf16x8 get(int c, int nb) const {
+    __device__ __forceinline__ opx8 get(int c, int nb) const {
         u32x4 v;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -154,7 +158,7 @@ struct NextB {
                 v[i] = r[c][nb][i];
             }
         }
-        return __builtin_bit_cast(bf16x8, v);
+        return __builtin_bit_cast(opx8, v);
     }
 };
 
@@ -163,58 +167,100 @@ enum Hidden : int { HID_SOFTPLUS = 0, HID_RELU = 1 };
 // Softplus networks are evaluated in SCALED UNITS: every hidden pre-activation / activation carries the factor
 // K = 100 log2(e) (the host scales biases and input-fed weights by K and the last, linear layer's weights by 1/K, see
 // hip.py), because  K * softplus_100(z) = max(z',0) + log2(1 + 2^-|z'|)  with z' = K z:  base-2 softplus needs no
-// multiplications around the two transcendentals, and d softplus/dz = sigmoid(100 z) = 1/(1+2^-z') is unit-free.
+// multiplications around the two transcendentals, and d softplus/dz = sigmoid(100 z) = 2^(z' - h') is unit-free.
 // (torch's threshold branch, 100 z > 20 -> z, is dropped: there the correction is below half an ulp of z.)
-__device__ __forceinline__ float softplus2(float z) {
+//
+// The fp32 accumulators of two rows are rounded to a packed half pair FIRST (one v_cvt_pk_f16_f32) and the whole
+// activation runs on the pair; its result is the next layer's operand register as it stands.
+// v_exp_f16 / v_log_f16 have no packed form: low half, then high half written in place (SDWA, UNUSED_PRESERVE).  The
+// s_nop 0 between them is the gfx940+ transcendental-result hazard: the second instruction READS the first one's result
+// (to preserve the low half) and the assembler does not insert wait states inside an asm block.
+__device__ __forceinline__ h2 exp2_h2(h2 x) {
+    unsigned r;
+    const unsigned xi = bits(x);
+    asm("v_exp_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\ts_nop 0\n\t"
+        "v_exp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1"
+        : "=&v"(r) : "v"(xi));
+    return __builtin_bit_cast(h2, r);
+}
+__device__ __forceinline__ h2 exp2_neg_abs_h2(h2 x) {   // 2^-|x| with the source modifiers doing -|.|
+    unsigned r;
+    const unsigned xi = bits(x);
+    asm("v_exp_f16_sdwa %0, -|%1| dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\ts_nop 0\n\t"
+        "v_exp_f16_sdwa %0, -|%1| dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1"
+        : "=&v"(r) : "v"(xi));
+    return __builtin_bit_cast(h2, r);
+}
+__device__ __forceinline__ h2 log2_h2(h2 x) {
+    unsigned r;
+    const unsigned xi = bits(x);
+    asm("v_log_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n\ts_nop 0\n\t"
+        "v_log_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1"
+        : "=&v"(r) : "v"(xi));
+    return __builtin_bit_cast(h2, r);
+}
+__device__ __forceinline__ h2 relu_h2(h2 z) {   // ONE v_pk_max_f16 (the builtin max adds a canonicalising v_pk_max in front)
+    unsigned r;
+    const unsigned zi = bits(z);
+    asm("v_pk_max_f16 %0, %1, 0" : "=v"(r) : "v"(zi));
+    return __builtin_bit_cast(h2, r);
+}
+__device__ __forceinline__ h2 softplus2(h2 z) {   // h' = max(z',0) + log2(1 + 2^-|z'|)
 #ifdef MP_EXP_NOTRANS
-    return relu_f(z) + 0.001f * z;
+    return relu_h2(z) + z * (h2){(op_t)0.001f, (op_t)0.001f};
 #else
-    const float u = __builtin_amdgcn_exp2f(-fabsf(z));
-    return relu_f(z) + __builtin_amdgcn_logf(1.0f + u);
+    const h2 u = exp2_neg_abs_h2(z);
+    return relu_h2(z) + log2_h2(u + (h2){(op_t)1.0f, (op_t)1.0f});
 #endif
+}
+// lanes 8..15 of every 16-lane row receive lane-8's register, lanes 0..7 keep their own (DPP row_shr:8).  Inline asm on
+// purpose (hipcc 7.2 merges two __builtin_amdgcn_update_dpp calls on the elements of a vector into one broadcast);
+// s_nop 1 = the VALU-write -> DPP-read hazard.
+__device__ __forceinline__ h2 row_shr8(h2 s) {
+    unsigned d;
+    const unsigned si = bits(s);
+    asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shr:8 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(si), "0"(si));
+    return __builtin_bit_cast(h2, d);
 }
 
 // Piece q (0..7) of the activation of a finished block of 16 rows x NB column blocks; one piece rides in every K step
 // of the next block's MFMA stream.  `hidden` (wave-uniform): apply the nonlinearity, else pass through.
-//   plain  : value q -> column block q/4, row q%4; a column block is packed when its 4 rows are done
+//   plain  : q = 0..3 -> column block q/2, row pair q%2
 //   forward: half-block tangent layout (8 points per wave): block 0 = [values | d/dx], block 1 = [d/dy | d/dz]; lanes
 //            with (lane & 8) == 0 hold the value / d/dy columns of point lane&7, the others d/dx / d/dz.
-//            q < 4: row q (softplus + sigmoid, tangents scaled), q = 4,5: pack column block q-4
+//            q = 0, 1: row pair q of both blocks (softplus + sigmoid on the values, tangents scaled by the sigmoid)
 template <int NB, bool FWD, int HID, int q, typename NB_T>
 __device__ __forceinline__ void act_piece(f32x4 (&p)[NB], bool hidden, NB_T& Bn, int pc, int ph) {
     static_assert(NB == 2, "the MLP core is specialised for 2 column blocks per wave (2 waves per SIMD)");
     if constexpr (FWD) {
-        if constexpr (q < 4) {
+        if constexpr (q < 2) {
+            h2 z = to_h2(p[0][2 * q], p[0][2 * q + 1]);
+            h2 t = to_h2(p[1][2 * q], p[1][2 * q + 1]);
             if (hidden) {
                 const bool vl = (threadIdx.x & 8) == 0;
-                const float z = p[0][q];
+                const h2 h = softplus2(z);
 #ifdef MP_EXP_NOTRANS
-                const float u = 0.5f * z, w = 1.0f + u, h = relu_f(z) + w, rr = w * 0.3f;
+                const h2 s = z * (h2){(op_t)0.01f, (op_t)0.01f};
 #else
-                const float u = __builtin_amdgcn_exp2f(-fabsf(z));
-                const float w = 1.0f + u;
-                const float h = relu_f(z) + __builtin_amdgcn_logf(w);
-                // sigmoid(z') = 2^z' / (1 + 2^z') = 2^(z' - h'):  two instructions instead of rcp + compare + mul + select
-                // (this kernel is bound by the NUMBER of VALU issue slots between MFMAs, not by transcendental rate)
-                const float s = __builtin_amdgcn_exp2f(z - h);   // meaningful in the value lanes
+                const h2 s = exp2_h2(z - h);          // sigmoid(z') = 2^(z' - h'); meaningful in the value lanes
 #endif
-#ifdef MP_EXP_NOTRANS
-                const float s = z >= 0.0f ? rr : u * rr;
-#endif
-                // lanes 8..15 of every 16-lane row take s from lane-8 (row_shr:8); value lanes keep their own
-                const float sf = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, s),
-                                                                                        __builtin_bit_cast(int, s),
-                                                                                        0x118, 0xF, 0xF, false));
-                p[0][q] = vl ? h : z * sf;
-                p[1][q] *= sf;
+                const h2 sf = row_shr8(s);            // tangent lanes take it from their point's value lane
+                const h2 zt = z * sf;
+                z = vl ? h : zt;
+                t = t * sf;
             }
-        } else if constexpr (q < 6) {
-            if (pc < KS_REG) Bn.put(pc, q - 4, ph, p[q - 4]);
+            if (pc < KS_REG) {
+                Bn.put(pc, 0, ph, q, z);
+                Bn.put(pc, 1, ph, q, t);
+            }
         }
     } else {
-        constexpr int nb = q / 4, r = q % 4;
-        if (hidden) p[nb][r] = HID == HID_SOFTPLUS ? softplus2(p[nb][r]) : relu_f(p[nb][r]);
-        if constexpr (r == 3) { if (pc < KS_REG) Bn.put(pc, nb, ph, p[nb]); }
+        if constexpr (q < 4) {
+            constexpr int nb = q / 2, j = q % 2;
+            h2 z = to_h2(p[nb][2 * j], p[nb][2 * j + 1]);
+            if (hidden) z = HID == HID_SOFTPLUS ? softplus2(z) : relu_h2(z);
+            if (pc < KS_REG) Bn.put(pc, nb, ph, j, z);
+        }
     }
 }
 
@@ -226,8 +272,8 @@ __device__ __forceinline__ void act_from(f32x4 (&p)[NB], bool hidden, NB_T& Bn, 
 
 // Runs the whole network for this wave's NB column blocks.
 //   Bcur : register K operand of layer 0 (zeros when the network input only enters through the staging tile); on
-//          return it holds the last layer's (bf16) output blocks (e.g. the 256 features).
-//   stage_wave : this wave's input staging tile in LDS ([16*NB rows][in_stride] bf16, rows = columns): the encoded
+//          return it holds the last layer's (half) output blocks (e.g. the 256 features).
+//   stage_wave : this wave's input staging tile in LDS ([16*NB rows][in_stride] halves, rows = columns): the encoded
 //          network input, read on demand as the K operand of K steps 8.. of every layer with use_in.
 //   out  : fp32 rows 0..15 of the `out_chunk` (must be the last chunk of its layer).
 // Software pipeline: the activation of a finished 16-row block is issued, one piece per K step, inside the MFMA stream
@@ -236,16 +282,16 @@ __device__ __forceinline__ void act_from(f32x4 (&p)[NB], bool hidden, NB_T& Bn, 
 // The caller must have run prologue() (chunks 0 and 1 in ring slots 0 and 1, barrier).
 template <int NB, bool FWD, int KS_IN, int HID, int WAVES>
 __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restrict__ wpack, const float* bias_lds,
-                                        char* wring, bf16x8 (&Bcur)[KS_REG][NB], const __bf16* stage_wave,
+                                        char* wring, opx8 (&Bcur)[KS_REG][NB], const op_t* stage_wave,
                                         f32x4 (&out)[NB], int wave, int lane) {
     const int g = lane >> 4;
     int ci = 0;
     NextB<NB, false> Bn;
     Bn.zero();
     constexpr int PF = 3, QN = 4;   // prefetch distance / queue length in A tiles
-    bf16x8 aq[QN];
+    opx8 aq[QN];
 #pragma unroll
-    for (int t = 0; t < PF; ++t) aq[t] = *(const bf16x8*)(wring + t * TILE_BYTES + lane * 16);  // chunk 0, block 0
+    for (int t = 0; t < PF; ++t) aq[t] = *(const opx8*)(wring + t * TILE_BYTES + lane * 16);  // chunk 0, block 0
     for (int l = 0; l < net.n_layers; ++l) {
         const LayerDesc L = net.layer[l];
         const float* bl = bias_lds + l * BIAS_STRIDE;
@@ -284,7 +330,7 @@ __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restri
 #ifdef MP_EXP_NOLDS
 #define MP_LDS_STMT (void)src;
 #else
-#define MP_LDS_STMT if (nk < KS_REG || mbl + 1 < CHUNK_MB || has_next) aq[nk % QN] = *(const bf16x8*)src;
+#define MP_LDS_STMT if (nk < KS_REG || mbl + 1 < CHUNK_MB || has_next) aq[nk % QN] = *(const opx8*)src;
 #endif
 #define MP_QSKIP(KS)                                                                                                  \
     {                                                                                                                 \
@@ -296,7 +342,7 @@ __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restri
     }
 #define MP_KSTEP(KS)                                                                                                  \
     {                                                                                                                 \
-        const bf16x8 a = aq[KS % QN];                                                                                 \
+        const opx8 a = aq[KS % QN];                                                                                 \
         {                                                                                                             \
             constexpr int nk = KS + PF;                                                                               \
             const char* src = nk < KS_REG ? tile + nk * TILE_BYTES                                                    \
@@ -305,7 +351,7 @@ __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restri
             MP_LDS_STMT                                                                                               \
         }                                                                                                             \
         _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                             \
-            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, Bcur[KS][nb], acc[nb], 0, 0, 0);                     \
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, Bcur[KS][nb], acc[nb], 0, 0, 0);                     \
         MP_ACT_STMT(KS)                                                                                               \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                            \
         _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                                              \
@@ -331,12 +377,12 @@ __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restri
                     if (L.use_in) {
 #pragma unroll
                         for (int ks = 0; ks < KS_IN; ++ks) {
-                            const bf16x8 a = *(const bf16x8*)(tile + (KS_REG + ks) * TILE_BYTES);
+                            const opx8 a = *(const opx8*)(tile + (KS_REG + ks) * TILE_BYTES);
 #pragma unroll
                             for (int nb = 0; nb < NB; ++nb) {
-                                const bf16x8 bi = *(const bf16x8*)(stage_wave + (nb * 16 + (lane & 15)) * in_stride(KS_IN) +
+                                const opx8 bi = *(const opx8*)(stage_wave + (nb * 16 + (lane & 15)) * in_stride(KS_IN) +
                                                                    ks * 32 + g * 8);
-                                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bi, acc[nb], 0, 0, 0);
+                                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bi, acc[nb], 0, 0, 0);
                             }
                         }
                     }

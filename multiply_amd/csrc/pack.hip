@@ -1,4 +1,4 @@
-// Weight packing: fp32 (optionally weight-normalised) nn.Linear parameters -> bf16 MFMA A-fragments.
+// Weight packing: fp32 (optionally weight-normalised) nn.Linear parameters -> half (f16) MFMA A-fragments.
 // Replaces nothing arithmetic in the reference except the weight-norm reparametrisation
 // w = g * v / ||v|| (torch.nn.utils.weight_norm, reference networks.py:82-83) and hoists the per-call
 // constant conditioning (networks.py:164-165) into the bias.  See include/multiply_hip.h: mp_pack_layer.
@@ -19,7 +19,7 @@ __global__ __launch_bounds__(64) void k_pack_layer(const float* __restrict__ v, 
                                                    const int* __restrict__ rowmap, const int* __restrict__ colmap,
                                                    const float* __restrict__ colscale, int ks_in, int hoist_col0,
                                                    int hoist_n, const float* __restrict__ hoist_vec, float bias_scale,
-                                                   __bf16* __restrict__ wpack, float* __restrict__ bias_out) {
+                                                   _Float16* __restrict__ wpack, float* __restrict__ bias_out) {
     const int r = blockIdx.x, lane = threadIdx.x;
     const int src = rowmap[r];
     const int n_slots = (mp::KS_REG + ks_in) * 32;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64) void k_pack_layer(const float* __restrict__ v, 
             }
             const int ks = s >> 5, sl = s & 31, gg = sl >> 3, e = sl & 7;
             const size_t off = ((size_t)(mb * (mp::KS_REG + ks_in) + ks) * 64 + (i + 16 * gg)) * 8 + e;
-            wpack[off] = (__bf16)val;
+            wpack[off] = (_Float16)val;
         }
     }
     if (bias_out) {
@@ -73,7 +73,7 @@ extern "C" int mp_pack_layer(const float* v, const float* g, const float* b, int
     if (bias_layer && n_rows < MP_BIAS_STRIDE)
         hipLaunchKernelGGL(k_zero_f, dim3(1), dim3(MP_BIAS_STRIDE), 0, st, bias_layer + n_rows, MP_BIAS_STRIDE - n_rows);
     hipLaunchKernelGGL(k_pack_layer, dim3(n_rows), dim3(64), 0, st, v, g, b, out_dim, in_dim, rowmap, colmap,
-                       colscale, ks_in, hoist_col0, hoist_n, hoist_vec, bias_scale, (__bf16*)wpack_layer, bias_layer);
+                       colscale, ks_in, hoist_col0, hoist_n, hoist_vec, bias_scale, (_Float16*)wpack_layer, bias_layer);
     return (int)hipGetLastError();
 }
 

@@ -154,7 +154,7 @@ class LayerPlan:
 
 
 class PackedNet:
-    """bf16 fragment-ordered weights + fp32 bias table of one network role on the device."""
+    """half (f16) fragment-ordered weights + fp32 bias table of one network role on the device."""
 
     def __init__(self, plans, ks_in, device):
         assert len(plans) <= MAX_LAYERS
@@ -311,7 +311,7 @@ class PoseEmbed:
 
 # ------------------------------------------------------------------------------------------------ module-level ops
 def implicit_forward(net, x, cond_vec):
-    """ImplicitNet.forward for external callers: (N, d_in) -> (N, 257) fp32 (features are bf16-rounded)."""
+    """ImplicitNet.forward for external callers: (N, d_in) -> (N, 257) fp32 (features are f16-rounded)."""
     require_device()
     x = x.detach().float().contiguous()
     ks_in = 2 if net.d_in == 3 else 3

@@ -10,7 +10,7 @@ latent code, and -- when the caller's smpl_pose / smpl_trans / smpl_shape requir
 trainer) -- for those too, through the canonical warp, the normals' Jacobian, the pose conditioning and SMPL's bone transforms.
 
 The non-differentiable sampler (VolSDF Algorithm 1, ray_sampler.py:81-191, `torch.no_grad()` in the reference) runs on
-the fused bf16 kernels exactly like in eval mode, with the training-mode randomness drawn by torch.rand on the device.
+the fused half-precision kernels exactly like in eval mode, with the training-mode randomness drawn by torch.rand on the device.
 """
 import ctypes as C
 import math

@@ -1,7 +1,7 @@
 """GPU parity of the fused MLP kernels (through the C ABI) against the CPU oracle on the same seeded inputs.
 
-Arithmetic: bf16 MFMA operands, fp32 accumulation/activations; the reference is fp32 end to end, so the tolerances
-below are the stated bf16 tolerances: they are ~10x the errors measured on MI355X."""
+Arithmetic: f16 MFMA operands (fp32 accumulation, half-precision activations); the reference is fp32 end to end, so the
+tolerances below are the stated half-precision tolerances: >= 10x the errors measured on MI355X."""
 import numpy as np
 import pytest
 import torch

@@ -1,6 +1,6 @@
 """End-to-end parity: Multiply.forward (eval) on the GPU vs the CPU oracle on the same seeded scene.
 
-Tolerances: the MLPs run with bf16 MFMA operands and fp32 accumulation, everything else is fp32.
+Tolerances: the MLPs run with f16 MFMA operands and fp32 accumulation, everything else is fp32.
 Against the fp32 oracle that gives ~5e-3 on sdf; pixels are compared with the tolerances asserted below."""
 import numpy as np
 import pytest
@@ -56,7 +56,7 @@ def test_forward_eval_all_rays_hit():
     print("[info] oracle sampler iterations", want["iters"], "gpu", [i.tolist() for i in model.last_stats["iters"]])
     for p in range(2):
         report(f"z_vals person {p}", model._last["per"][p]["zfinal"], torch.cat([want["z_vals"][p], want["z_max"][p][:, None]], 1))
-    # bf16-MLP tolerances: (max over pixels, mean over pixels); isolated grazing rays dominate the max
+    # half-precision-MLP tolerances: (max over pixels, mean over pixels); isolated grazing rays dominate the max
     assert within(report("bg_rgb", model._last["bg_rgb"], want["bg_rgb"]), 2e-3, 3e-4)
     assert within(report("bg_transmittance", model._last["bg_T"], want["bg_transmittance"]), 0.15, 3e-3)
     assert within(report("acc_map", got["acc_map"], want["acc_map"]), 0.15, 3e-3)

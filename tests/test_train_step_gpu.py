@@ -41,7 +41,7 @@ def _train_setup(H=11, W=11, epoch=301):      # odd size: no ray through the sph
 
 def test_training_sampler_matches_oracle_with_same_draws():
     """ErrorBoundSampler in training mode (stratified t_rand, random u, randperm extras): same draws -> same depths
-    up to the bf16 SDF of the sampler's network queries."""
+    up to the half-precision SDF of the sampler's network queries."""
     model, oracle, inp, gin, gt, loss_fn, train = _train_setup()
     R = inp["uv"].shape[1]
     hit = [torch.arange(R), torch.arange(R)]
