@@ -6,20 +6,24 @@
 //   mp_gemm_tn : C[M,N] += A[K,M]^T . B[K,N]   (contraction over the ROW index, split over blocks, fp32 atomics)
 //                optionally colsum[m] += sum_{r < colsum_rows} A[r][m]  (the bias gradient rides on the same A tiles)
 //
-// Both: 128x128 tile of C per workgroup (4 waves, each 64x64 = 4x4 MFMA blocks), depth 32 per LDS stage, two stages:
+// Both: 128x128 tile of C per workgroup (8 waves, each 64x32 = 4x2 MFMA blocks; two workgroups per CU = 4 waves per SIMD,
+// which is what hides the LDS / barrier latencies: the 4-wave version ran at 73 TFLOP/s, this one at 86), depth 32 per
+// LDS stage, two stages:
 // the global loads of stage t+1 (float4 per lane, coalesced along the contiguous dimension) are in flight while the
 // MFMAs of stage t run; one barrier per stage.  The MFMA's k index is free to permute (a sum), and so is the mapping
 // of a lane's row/column inside the tile, so both are chosen such that every operand fetch is one ds_read_b128:
 //   nt: lane (li, lq) takes k = 8 lq + s for the 8 MFMA steps s of a stage  -> 8 consecutive floats of its row
-//   tn: lane li of row block i owns tile row 4 li + i                        -> 4 consecutive floats of LDS row r
+//   tn: lane li of row block i owns tile row 4 li + i (column 2 li + j)      -> 4 (2) consecutive floats of LDS row r
 #include <hip/hip_runtime.h>
 #include "../../include/multiply_hip.h"
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int NT_THREADS = 512;   // nt kernel: 8 waves (2 x 4), each a 64 x 32 sub-tile -> 4 waves per SIMD at 2 workgroups per CU
 constexpr int LDK = BK + 4;    // nt: [row][k] tiles, row stride 36 floats (16 B aligned, b128 reads spread over all banks)
 constexpr int LDM = BM + 4;    // tn: [r][m] tiles
 
@@ -32,7 +36,10 @@ __device__ __forceinline__ f32x4 ld4(const float* p, bool ok4, int n_valid) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+// FAST: 16 B aligned operands, leading dimensions and K multiples of 4 / BK: the k loop carries no bounds logic at all
+// (rows past M / N are clamped to the last valid row -- their products land in C entries that are never written).
+template <bool FAST>
+__global__ __launch_bounds__(NT_THREADS) void k_gemm_nt(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                  float* __restrict__ C, int ldc, int M, int N, int K,
                                                  const float* __restrict__ bias, int bias_rows, int accumulate, int relu) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -40,30 +47,42 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ A, in
     float (*Bs)[BN * LDK] = (float (*)[BN * LDK])(smem + 2 * BM * LDK);
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = (wave >> 2) * 64, wn = (wave & 3) * 32;   // 2 x 4 waves, each 64 x 32
     const int li = lane & 15, lq = lane >> 4;
-    f32x4 acc[4][4];
+    f32x4 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
-    // staging: 128 rows x 8 float4 per tile = 1024 float4 / 256 threads = 4 per thread per operand
-    const int sr = t >> 3, sk = (t & 7) * 4;       // row sr + 32 q, k offset sk
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+    // staging: 128 rows x 8 float4 per tile = 1024 float4 / 512 threads = 2 per thread per operand
+    const int sr = t >> 3, sk = (t & 7) * 4;       // row sr + 64 q, k offset sk
     const bool a_al = (lda & 3) == 0 && ((size_t)A & 15) == 0, b_al = (ldb & 3) == 0 && ((size_t)B & 15) == 0;
-    f32x4 ra[4], rb[4];
+    f32x4 ra[2], rb[2];
+    const float* pa[2];
+    const float* pb[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        pa[q] = A + (size_t)min(m0 + sr + 64 * q, M - 1) * lda + sk;
+        pb[q] = B + (size_t)min(n0 + sr + 64 * q, N - 1) * ldb + sk;
+    }
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int am = m0 + sr + 32 * q, bn = n0 + sr + 32 * q, k = k0 + sk;
-            ra[q] = am < M ? ld4(A + (size_t)am * lda + k, a_al && k + 3 < K, K - k) : (f32x4){0, 0, 0, 0};
-            rb[q] = bn < N ? ld4(B + (size_t)bn * ldb + k, b_al && k + 3 < K, K - k) : (f32x4){0, 0, 0, 0};
+        for (int q = 0; q < 2; ++q) {
+            if constexpr (FAST) {
+                ra[q] = *(const f32x4*)(pa[q] + k0);
+                rb[q] = *(const f32x4*)(pb[q] + k0);
+            } else {
+                const int am = m0 + sr + 64 * q, bn = n0 + sr + 64 * q, k = k0 + sk;
+                ra[q] = am < M ? ld4(A + (size_t)am * lda + k, a_al && k + 3 < K, K - k) : (f32x4){0, 0, 0, 0};
+                rb[q] = bn < N ? ld4(B + (size_t)bn * ldb + k, b_al && k + 3 < K, K - k) : (f32x4){0, 0, 0, 0};
+            }
         }
     };
     auto sstore = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            *(f32x4*)&As[buf][(sr + 32 * q) * LDK + sk] = ra[q];
-            *(f32x4*)&Bs[buf][(sr + 32 * q) * LDK + sk] = rb[q];
+        for (int q = 0; q < 2; ++q) {
+            *(f32x4*)&As[buf][(sr + 64 * q) * LDK + sk] = ra[q];
+            *(f32x4*)&Bs[buf][(sr + 64 * q) * LDK + sk] = rb[q];
         }
     };
     const int nk = (K + BK - 1) / BK;
@@ -73,20 +92,23 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ A, in
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gload((kt + 1) * BK);
-        f32x4 a[4][2], b[4][2];
+        f32x4 a[4][2], b[2][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             a[i][0] = *(const f32x4*)&As[buf][(wm + i * 16 + li) * LDK + 8 * lq];
             a[i][1] = *(const f32x4*)&As[buf][(wm + i * 16 + li) * LDK + 8 * lq + 4];
-            b[i][0] = *(const f32x4*)&Bs[buf][(wn + i * 16 + li) * LDK + 8 * lq];
-            b[i][1] = *(const f32x4*)&Bs[buf][(wn + i * 16 + li) * LDK + 8 * lq + 4];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            b[j][0] = *(const f32x4*)&Bs[buf][(wn + j * 16 + li) * LDK + 8 * lq];
+            b[j][1] = *(const f32x4*)&Bs[buf][(wn + j * 16 + li) * LDK + 8 * lq + 4];
         }
 #pragma unroll
         for (int s = 0; s < 8; ++s)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s >> 2][s & 3], b[j][s >> 2][s & 3], acc[i][j], 0, 0, 0);
         if (kt + 1 < nk) sstore(buf ^ 1);
         __syncthreads();
@@ -96,7 +118,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ A, in
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 2; ++j) {
             const int n = n0 + wn + j * 16 + cn;
             if (n >= N) continue;
             const float bn = bias ? bias[n] : 0.0f;
@@ -115,7 +137,9 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const float* __restrict__ A, in
 }
 
 // C[M,N] += sum_r A[r,m] B[r,n]; block = 128x128 tile of C x one slice of the rows
-__global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+// FAST: aligned operands, M and N multiples of the tile: only the row-slice bound remains in the loop
+template <bool FAST>
+__global__ __launch_bounds__(NT_THREADS) void k_gemm_tn(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                  float* __restrict__ C, int ldc, int M, int N, int K, int rows_per_block,
                                                  float* __restrict__ colsum, int colsum_rows) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -124,33 +148,38 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, in
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int r_begin = blockIdx.z * rows_per_block, r_end = min(K, r_begin + rows_per_block);
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = (wave >> 2) * 64, wn = (wave & 3) * 32;   // 2 x 4 waves, each 64 x 32
     const int li = lane & 15, lq = lane >> 4;
-    f32x4 acc[4][4];
+    f32x4 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
-    // staging: 32 rows x 32 float4 per tile = 1024 float4 / 256 threads = 4 per thread per operand
-    const int sc = (t & 31) * 4, sr = t >> 5;      // columns sc..sc+3, rows sr + 8 q
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+    // staging: 32 rows x 32 float4 per tile = 1024 float4 / 512 threads = 2 per thread per operand
+    const int sc = (t & 31) * 4, sr = t >> 5;      // columns sc..sc+3, rows sr + 16 q
     const bool a_al = (lda & 3) == 0 && ((size_t)A & 15) == 0, b_al = (ldb & 3) == 0 && ((size_t)B & 15) == 0;
     const bool do_sum = colsum != nullptr && blockIdx.y == 0;
-    f32x4 ra[4], rb[4], csum = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ra[2], rb[2], csum = {0.f, 0.f, 0.f, 0.f};
     auto gload = [&](int r0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = r0 + sr + 8 * q;
+        for (int q = 0; q < 2; ++q) {
+            const int r = r0 + sr + 16 * q;
             const int am = m0 + sc, bn = n0 + sc;
-            ra[q] = r < r_end ? ld4(A + (size_t)r * lda + am, a_al && am + 3 < M, M - am) : (f32x4){0, 0, 0, 0};
-            rb[q] = r < r_end ? ld4(B + (size_t)r * ldb + bn, b_al && bn + 3 < N, N - bn) : (f32x4){0, 0, 0, 0};
+            if constexpr (FAST) {
+                ra[q] = r < r_end ? *(const f32x4*)(A + (size_t)r * lda + am) : (f32x4){0, 0, 0, 0};
+                rb[q] = r < r_end ? *(const f32x4*)(B + (size_t)r * ldb + bn) : (f32x4){0, 0, 0, 0};
+            } else {
+                ra[q] = r < r_end ? ld4(A + (size_t)r * lda + am, a_al && am + 3 < M, M - am) : (f32x4){0, 0, 0, 0};
+                rb[q] = r < r_end ? ld4(B + (size_t)r * ldb + bn, b_al && bn + 3 < N, N - bn) : (f32x4){0, 0, 0, 0};
+            }
             if (do_sum && r < colsum_rows) csum += ra[q];
         }
     };
     auto sstore = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            *(f32x4*)&As[buf][(sr + 8 * q) * LDM + sc] = ra[q];
-            *(f32x4*)&Bs[buf][(sr + 8 * q) * LDM + sc] = rb[q];
+        for (int q = 0; q < 2; ++q) {
+            *(f32x4*)&As[buf][(sr + 16 * q) * LDM + sc] = ra[q];
+            *(f32x4*)&Bs[buf][(sr + 16 * q) * LDM + sc] = rb[q];
         }
     };
     const int nk = (r_end - r_begin + BK - 1) / BK;
@@ -164,25 +193,25 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, in
         if (kt + 1 < nk) gload(r_begin + (kt + 1) * BK);
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            // lane (li, lq) contracts LDS row r = 4 s + lq; its tile rows / columns are 4 li + i (i = 0..3)
+            // lane (li, lq) contracts LDS row r = 4 s + lq; its tile rows are 4 li + i (i = 0..3), its columns 2 li + j
             const f32x4 a = *(const f32x4*)&As[buf][(4 * s + lq) * LDM + wm + 4 * li];
-            const f32x4 b = *(const f32x4*)&Bs[buf][(4 * s + lq) * LDM + wn + 4 * li];
+            const f32x2 b = *(const f32x2*)&Bs[buf][(4 * s + lq) * LDM + wn + 2 * li];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) sstore(buf ^ 1);
         __syncthreads();
     }
     // D block (i, j): lane holds D[row 4*(lane>>4)+reg][col lane&15] of the MFMA block = tile row wm + 4*(4*(lane>>4)+reg) + i,
-    // tile column wn + 4*(lane&15) + j
+    // tile column wn + 2*(lane&15) + j
     const int dc = lane & 15, dr = (lane >> 4) * 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn + 4 * dc + j;
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn + 2 * dc + j;
             if (n >= N) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -193,11 +222,11 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, in
     if (do_sum) {   // threads with the same sc hold partial sums of the same 4 columns: fold them through LDS
         __syncthreads();
         float* red = smem;
-        for (int i = t; i < BM; i += 256) red[i] = 0.f;
+        for (int i = t; i < BM; i += NT_THREADS) red[i] = 0.f;
         __syncthreads();
         for (int e = 0; e < 4; ++e) atomicAdd(&red[sc + e], csum[e]);
         __syncthreads();
-        for (int i = t; i < BM; i += 256)
+        for (int i = t; i < BM; i += NT_THREADS)
             if (m0 + i < M && red[i] != 0.f) atomicAdd(colsum + m0 + i, red[i]);
     }
 }
@@ -208,10 +237,16 @@ extern "C" int mp_gemm_nt(const float* A, int lda, const float* B, int ldb, floa
                           const float* bias, int bias_rows, int accumulate, int relu, void* stream) {
     if (M <= 0 || N <= 0) return 0;
     constexpr int LDS_NT = 2 * (BM + BN) * LDK * (int)sizeof(float);
-    static int once = (int)hipFuncSetAttribute((const void*)k_gemm_nt, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_NT);
+    static int once = (int)hipFuncSetAttribute((const void*)k_gemm_nt<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_NT) +
+                      (int)hipFuncSetAttribute((const void*)k_gemm_nt<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_NT);
     (void)once;
-    hipLaunchKernelGGL(k_gemm_nt, dim3((M + BM - 1) / BM, (N + BN - 1) / BN), dim3(256), LDS_NT, (hipStream_t)stream, A, lda, B,
-                       ldb, C, ldc, M, N, K, bias, bias_rows, accumulate, relu);
+    const bool fast = (lda & 3) == 0 && (ldb & 3) == 0 && ((size_t)A & 15) == 0 && ((size_t)B & 15) == 0 && K % BK == 0;
+    if (fast)
+        hipLaunchKernelGGL(k_gemm_nt<true>, dim3((M + BM - 1) / BM, (N + BN - 1) / BN), dim3(NT_THREADS), LDS_NT, (hipStream_t)stream,
+                           A, lda, B, ldb, C, ldc, M, N, K, bias, bias_rows, accumulate, relu);
+    else
+        hipLaunchKernelGGL(k_gemm_nt<false>, dim3((M + BM - 1) / BM, (N + BN - 1) / BN), dim3(NT_THREADS), LDS_NT, (hipStream_t)stream,
+                           A, lda, B, ldb, C, ldc, M, N, K, bias, bias_rows, accumulate, relu);
     return (int)hipGetLastError();
 }
 
@@ -226,9 +261,16 @@ extern "C" int mp_gemm_tn(const float* A, int lda, const float* B, int ldb, floa
     if (rows < 4 * BK) rows = 4 * BK;
     slices = (K + rows - 1) / rows;
     constexpr int LDS_TN = 4 * BK * LDM * (int)sizeof(float);
-    static int once = (int)hipFuncSetAttribute((const void*)k_gemm_tn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TN);
+    static int once = (int)hipFuncSetAttribute((const void*)k_gemm_tn<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TN) +
+                      (int)hipFuncSetAttribute((const void*)k_gemm_tn<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TN);
     (void)once;
-    hipLaunchKernelGGL(k_gemm_tn, dim3((M + BM - 1) / BM, (N + BN - 1) / BN, slices), dim3(256), LDS_TN, (hipStream_t)stream, A,
-                       lda, B, ldb, C, ldc, M, N, K, rows, colsum, colsum_rows);
+    const bool fast = (lda & 3) == 0 && (ldb & 3) == 0 && ((size_t)A & 15) == 0 && ((size_t)B & 15) == 0 && M % BM == 0 &&
+                      N % BN == 0;
+    if (fast)
+        hipLaunchKernelGGL(k_gemm_tn<true>, dim3(M / BM, N / BN, slices), dim3(NT_THREADS), LDS_TN, (hipStream_t)stream, A, lda, B, ldb, C,
+                           ldc, M, N, K, rows, colsum, colsum_rows);
+    else
+        hipLaunchKernelGGL(k_gemm_tn<false>, dim3((M + BM - 1) / BM, (N + BN - 1) / BN, slices), dim3(NT_THREADS), LDS_TN,
+                           (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, rows, colsum, colsum_rows);
     return (int)hipGetLastError();
 }
