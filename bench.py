@@ -209,11 +209,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = world > 1
+    # one rank per GPU.  (MP_BENCH_BACKEND=gloo lets the multi-rank code path be smoke-tested on a box with fewer GPUs
+    # than ranks: ranks then share devices and collectives go through the host.)
+    backend = os.environ.get("MP_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     if dist:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            td.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            td.init_process_group(backend)
 
     # every rank renders its own frame of the synthetic sequence (seed = rank)
     model, inp, tables, sc = build_model(args.samples, seed=rank, H=args.res, W=args.res, tile=args.tile)
