@@ -157,7 +157,7 @@ class Multiply(nn.Module):
         smpl_shape = input["smpl_shape"].detach().to(dev).float()
         smpl_trans = input["smpl_trans"].detach().to(dev).float()
         P = smpl_trans.shape[1]
-        persons = list(range(P)) if id == -1 else [id]
+        persons = list(id) if isinstance(id, (list, tuple)) else (list(range(P)) if id == -1 else [id])
         rs = self.ray_sampler
         group = int(self.convergence_group or R)
         beta = (self.density.beta.detach().abs() + self.density.beta_min).reshape(1).float().contiguous()
@@ -275,7 +275,9 @@ class Multiply(nn.Module):
         pp["_sampler_keep"] = (zs, sdfs, nz, znew, sdfnew, betar, active, gflag, any_active, xc_new, work, draws)
         return zfinal, iters, wcount
 
-    def _forward_eval(self, input, id, canonical_pose):
+    def _forward_eval(self, input, id, canonical_pose, composite=True):
+        """composite=False: stop after the per-person sampling + shading and return the per-person sample arrays (in hit
+        order) -- the person-sharded multi-GPU mode composites them elsewhere (parallel.render_person_sharded)."""
         L = hip.lib()
         cx = self._setup(input, id, canonical_pose)
         dev, R, dirs, far, pose, beta = cx["dev"], cx["R"], cx["dirs"], cx["far"], cx["pose"], cx["beta"]
@@ -337,6 +339,14 @@ class Multiply(nn.Module):
             z_l.append(zfinal); sdf_l.append(sdf); rgb_l.append(rgb); nrm_l.append(nrm); inv_l.append(pp["inv_index"])
             stats["iters"].append(iters); stats["n_sdf_evals"].append(wcount)
             per[p].update(zfinal=zfinal, sdf=sdf, rgb=rgb, nrm=nrm, xc=xc, work2=work2, wc2=wc2)
+
+        if not composite:
+            stats["n_shaded"] = [per[p]["wc2"] for p in persons]
+            self.last_stats = stats
+            self._last = dict(per=per, dirs=dirs, far=far, persons=persons, cx=cx)
+            return {p: dict(z=per[p]["zfinal"], sdf=per[p]["sdf"], rgb=per[p]["rgb"], nrm=per[p]["nrm"],
+                            hit_index=per[p]["hit_index"][:max(int(n_hit[n]), 1)], n_hit=int(n_hit[n]))
+                    for n, p in enumerate(persons)}
 
         # ---- background (multiply.py:482-484, 514-539)
         bg_rgb = None

@@ -73,3 +73,99 @@ class GradientAllReduce:
             torch._foreach_copy_([p.grad for p in self.params],
                                  [v.reshape(p.shape) for p, v in zip(self.params, self.flat.split(self.sizes))])
         return self.flat
+
+
+# ======================================================================================================================
+# Person-sharded rendering (BASELINE.json configs[3]): rank g owns the networks' work of persons
+# {p : p % world == g} for ALL rays of the call, then ONE exchange step turns "all rays of my persons" into "all persons
+# of my rays", and compositing + background are ray-partitioned.
+# ======================================================================================================================
+def _exchange_by_rays(dense, world, backend_alltoall):
+    """dense [world * n_slice, ...] (rows = rays of the whole call, slice-major) -> [world, n_slice, ...]: block g holds
+    rank g's rows for MY ray slice.  all_to_all over RCCL; all_gather + select where the backend has no all_to_all."""
+    n_slice = dense.shape[0] // world
+    if backend_alltoall:
+        out = torch.empty_like(dense)
+        dist.all_to_all_single(out, dense.contiguous())
+        return out.reshape(world, n_slice, *dense.shape[1:])
+    rank = dist.get_rank()
+    bufs = [torch.empty_like(dense) for _ in range(world)]
+    dist.all_gather(bufs, dense.contiguous())
+    return torch.stack([b.reshape(world, n_slice, *dense.shape[1:])[rank] for b in bufs], 0)
+
+
+def render_person_sharded(model, input, canonical_pose=False):
+    """Eval-mode Multiply.forward with the persons sharded over the ranks.  Every rank returns the output dict for ITS ray
+    slice [rank * ceil(R / world), ...) (use gather_rays to assemble the image).  Identical results to the single-process
+    call with convergence groups that do not straddle a slice (the sampler's vote is per person and per group)."""
+    import ctypes as C
+    from . import hip
+    world, rank = dist.get_world_size(), dist.get_rank()
+    L = hip.lib()
+    st = hip.stream()
+    P = input["smpl_trans"].shape[1]
+    mine = [p for p in range(P) if p % world == rank]
+    n_local = (P + world - 1) // world                       # persons per rank, padded
+    with torch.no_grad():
+        parts = model._forward_eval(input, mine, canonical_pose, composite=False) if mine else {}
+    last = model._last if mine else None
+    dev = model.density.beta.device
+    R = input["uv"].shape[1]
+    n_slice = (R + world - 1) // world
+    Rpad = n_slice * world
+    rs = model.ray_sampler
+    NZ = rs.N_samples + rs.N_samples_extra + 2
+    S = NZ - 1
+    width = NZ + S * 7 + 1                                    # z, sdf, rgb3, nrm3 per sample, + hit flag
+    f32 = dict(dtype=torch.float32, device=dev)
+    recv = []
+    for j in range(n_local):                                  # one exchange per local person slot
+        dense = torch.zeros(Rpad, width, **f32)
+        if j < len(mine):
+            d = parts[mine[j]]
+            n, rows = d["n_hit"], d["hit_index"][:d["n_hit"]].long()
+            dense[rows, :NZ] = d["z"][:n]
+            dense[rows, NZ:NZ + S] = d["sdf"][:n * S].reshape(n, S)
+            dense[rows, NZ + S:NZ + 4 * S] = d["rgb"][:n * S].reshape(n, 3 * S)
+            dense[rows, NZ + 4 * S:NZ + 7 * S] = d["nrm"][:n * S].reshape(n, 3 * S)
+            dense[rows, -1] = 1.0
+        recv.append(_exchange_by_rays(dense, world, dist.get_backend() == "nccl"))      # [world, n_slice, width]
+    # my ray slice, all persons: person p = j * world + g
+    s0 = rank * n_slice
+    n_my = max(0, min(R, s0 + n_slice) - s0)
+    persons = list(range(P))
+    z_l, sdf_l, rgb_l, nrm_l, inv_l = [], [], [], [], []
+    for p in persons:
+        blk = recv[p // world][p % world][:n_my]
+        hit = blk[:, -1] > 0.5
+        inv = torch.where(hit, torch.arange(n_my, device=dev, dtype=torch.int32), torch.full((n_my,), -1, dtype=torch.int32, device=dev))
+        z_l.append(blk[:, :NZ].contiguous()); sdf_l.append(blk[:, NZ:NZ + S].contiguous())
+        rgb_l.append(blk[:, NZ + S:NZ + 4 * S].contiguous()); nrm_l.append(blk[:, NZ + 4 * S:NZ + 7 * S].contiguous())
+        inv_l.append(inv.contiguous())
+    table = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device=dev)
+    tabs = [table(t) for t in (inv_l, z_l, sdf_l, rgb_l, nrm_l)]
+    beta = (model.density.beta.detach().abs() + model.density.beta_min).reshape(1).float().contiguous()
+    # rays of my slice + background for them
+    uv = input["uv"].to(dev).float().reshape(-1, 2)[s0:s0 + n_my].contiguous()
+    K = input["intrinsics"].to(dev).float().reshape(16).contiguous()
+    pose = input["pose"].to(dev).float().reshape(16).contiguous()
+    dirs = torch.empty(n_my, 3, **f32); far = torch.empty(n_my, **f32)
+    hip.check(L.mp_ray_setup(hip.ptr(uv), hip.ptr(K), hip.ptr(pose), n_my, C.c_float(model.sdf_bounding_sphere),
+                             hip.ptr(dirs), hip.ptr(far), st), "mp_ray_setup")
+    bg_rgb = None
+    if input.get("idx", None) is not None:
+        key = "image_id" if "image_id" in input else "idx"
+        code = model.frame_latent_encoder.weight.detach()[int(torch.as_tensor(input[key]).reshape(-1)[0])]
+        t = torch.linspace(0.0, 1.0, rs.N_samples_inverse_sphere, device=dev)
+        z_bg = torch.flip(t * (1.0 / rs.scene_bounding_sphere), dims=[0]).contiguous()
+        bg_rgb = hip.background(model.bg_implicit_network, model.bg_rendering_network, dirs,
+                                pose.reshape(4, 4)[:3, 3].contiguous(), z_bg, code, radius=model.sdf_bounding_sphere)
+    out = {k: torch.empty(n_my, 3, **f32) for k in ("rgb_values", "fg_rgb_values", "normal_values")}
+    acc_map = torch.empty(n_my, **f32); acc_person = torch.empty(n_my, P, **f32); bg_T = torch.empty(n_my, **f32)
+    hip.check(L.mp_composite(n_my, P, NZ, *[hip.ptr(t) for t in tabs], hip.ptr(beta),
+                             hip.ptr(bg_rgb) if bg_rgb is not None else None, hip.ptr(out["rgb_values"]),
+                             hip.ptr(out["fg_rgb_values"]), hip.ptr(out["normal_values"]), hip.ptr(acc_map),
+                             hip.ptr(acc_person), hip.ptr(bg_T), st), "mp_composite")
+    torch.cuda.synchronize()                                  # the pointer tables / blocks above must outlive the launch
+    out.update(acc_map=acc_map, acc_person_list=acc_person)
+    return out, (s0, s0 + n_my)
