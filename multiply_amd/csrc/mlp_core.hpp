@@ -8,22 +8,23 @@
 //
 // Orientation: D[out_feature][point] = W[out][k] * X^T[k][point].
 //   A operand = 16x32 weight tile (rows = output features), streamed global -> LDS
-//               (global_load_lds, 16 B / lane) in MFMA fragment order, shared by the
-//               4 waves of the workgroup.
+//               (global_load_lds, 16 B / lane) in MFMA fragment order, shared by all
+//               waves of the workgroup.
 //   B operand = activations, 32 k-slots x 16 points per (ks, nb); lives in VGPRs.
 //   D         = col = lane&15 (point), row = 4*(lane>>4)+reg (output feature).
 // Because lane (j,g) receives output rows 4g..4g+3 of every 16-row block and needs
 // k-slots 8g..8g+7 of every 32-slot K step of the next layer, the host packs the
 // weights with the K permutation
 //     slot(ks, g, e) <-> feature 32*ks + (e<4 ? 4g+e : 16+4g+(e-4))
-// (see pack_weights.py / mp_pack_weights), so that half(act(D)) of output blocks
+// (hip.py reg_slot_feature / csrc/pack.hip mp_pack_layer), so that half(act(D)) of output blocks
 // (2ks, 2ks+1) IS the B fragment of K step ks: no LDS round trip, no cross-lane moves.
 //
 // A wave owns NB column blocks of 16 columns.  Plain mode: 16*NB different points (NB = 2 with 8 waves per workgroup
 // = 2 waves per SIMD, so that one wave's activation VALU work overlaps the other wave's MFMAs).
-// Forward-mode (FWD, NB=4): block 0 = values of 16 points, blocks 1..3 = d/dx, d/dy,
-// d/dz tangents of the same 16 points, so sdf and its spatial gradient (the normals of
-// multiply.py:620-661) come out of one pass: t' = softplus'(z) * (W t).
+// Forward mode (FWD): value and d/dx, d/dy, d/dz tangent columns of the same points ride through the network together,
+// t' = softplus'(z) * (W t), so sdf and its spatial gradient (the normals of multiply.py:620-661) come out of one pass.
+// Default layout (NB = 2): 8 points per wave in half blocks, block 0 = [values | d/dx], block 1 = [d/dy | d/dz];
+// alternative (NB = 4, one wave per SIMD, MP_SHADE_LAYOUT=4): 16 points, one block per role.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -67,36 +68,6 @@ struct NetDesc {
     int total_chunks;
     LayerDesc layer[MAX_LAYERS];
 };
-
-// max as ONE v_max_f32 (fmaxf on an MFMA result makes hipcc add a canonicalising v_max in front)
-__device__ __forceinline__ float relu_f(float x) {
-    float r;
-    asm("v_max_f32 %0, %1, 0" : "=v"(r) : "v"(x));
-    return r;
-}
-__device__ __forceinline__ float max_f(float x, float y) {
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
-    return r;
-}
-// softplus(beta=100, threshold=20) of torch.nn.Softplus (networks.py:85):  log1p(exp(100 z))/100
-//   = max(z,0) + (ln2/100) * log2(1 + 2^(-100*log2(e)*|z|)).  The threshold branch (100 z > 20 -> z) is dropped: there the
-//   correction term is < 2.1e-11, below half an ulp of z >= 0.2, so the fp32 result is identical.
-// Raw v_exp_f32 / v_log_f32 (no denormal fix-up code: the log argument lies in [1,2], the exp result in [0,1]).
-constexpr float SP_K = 144.26950408889634f;      // 100 * log2(e)
-constexpr float SP_C = 0.0069314718055994531f;   // ln(2) / 100
-__device__ __forceinline__ float softplus100(float z) {
-    const float u = __builtin_amdgcn_exp2f(-SP_K * fabsf(z));
-    return fmaf(SP_C, __builtin_amdgcn_logf(1.0f + u), relu_f(z));
-}
-// softplus and its derivative sigmoid(100 z) sharing one exponential
-__device__ __forceinline__ void softplus100_vg(float z, float& h, float& s) {
-    const float u = __builtin_amdgcn_exp2f(-SP_K * fabsf(z));
-    const float w = 1.0f + u;
-    h = fmaf(SP_C, __builtin_amdgcn_logf(w), relu_f(z));
-    const float r = __builtin_amdgcn_rcpf(w);
-    s = z >= 0.0f ? r : u * r;
-}
 
 template <int KS_IN, int WAVES>
 __device__ __forceinline__ void issue_chunk(const char* __restrict__ wpack, char* wring, int ci, int wave, int lane) {
