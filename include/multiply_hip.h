@@ -27,7 +27,7 @@ extern "C" {
 #define MP_KNN_CLUSTER 64   /* vertices per nearest-neighbour cluster */
 #define MP_KNN_NC 108       /* clusters (108*64 = 6912 >= 6890, padded) */
 
-enum { MP_ACT_NONE = 0, MP_ACT_SOFTPLUS = 1, MP_ACT_RELU = 2 };
+enum { MP_ACT_NONE = 0, MP_ACT_SOFTPLUS = 1, MP_ACT_RELU = 2, MP_ACT_SIGMUL = 3 };
 
 typedef struct {
     int n_chunk;   /* chunks of 32 output rows */
@@ -35,6 +35,7 @@ typedef struct {
     int use_in;    /* layer consumes the 64/96 input-fed K slots (encoded network input) */
     int act;       /* MP_ACT_* */
     int out_chunk; /* chunk returned in fp32 instead of feeding the next layer, -1 = none */
+    int aux;       /* reverse sweep only (MP_ACT_SIGMUL): bits 0..7 = 1 + stored-sigmoid layer, bits 8..15 = capture id */
 } MpLayer;
 
 typedef struct {
@@ -81,6 +82,16 @@ int mp_mlp_full(const MpNet* net, const void* wpack, const float* bias, const fl
 int mp_mlp_shade(const MpNet* net, const void* wpack, const float* bias, const float* xc, const float* jinv,
                  const int* worklist, const int* count, int max_count, float* sdf_out, float* normal_out,
                  void* feat_frag, void* stream);
+
+/* mp_mlp_shade_rev: same outputs as mp_mlp_shade, computed in reverse mode, segment by segment of the worklist:
+ * a plain forward sweep that writes sigmoid(100 z) of every hidden unit (4096 B per work index) into `sig`
+ * (seg_points * 4096 B, seg_points a multiple of 256, ZERO-INITIALISED once by the caller), then a reverse sweep through
+ * the TRANSPOSED layers (gnet / gpack: the 'grad' plan of multiply_amd/hip.py; w8_slots: the sdf row of the last layer,
+ * 256 halves in K-slot order).  Two network columns per point instead of the four of the forward-mode kernel. */
+int mp_mlp_shade_rev(const MpNet* net, const void* wpack, const float* bias, const MpNet* gnet, const void* gpack,
+                     const void* w8_slots, const float* xc, const float* jinv, const int* worklist, const int* count,
+                     int max_count, float* sdf_out, float* normal_out, void* feat_frag, void* sig, int seg_points,
+                     void* stream);
 
 /* mp_mlp_color: RenderingNet.forward mode 'pose_no_view' (networks.py:277-281, 305-311):
  * sigmoid(MLP([x_c, n, lin_pose(pose) (hoisted), feat])) -> rgb_out[id][3]. */

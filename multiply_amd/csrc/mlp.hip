@@ -282,6 +282,181 @@ __global__ __launch_bounds__(256) void k_mlp_shade4(const NetDesc net, const cha
     }
 }
 
+// ------------------------------------------------------------------------------------------------ shading: reverse mode
+// sdf, features and d sdf / d x_c in TWO sweeps of one network column each (the forward-mode kernel above pushes four
+// columns -- value and three tangents -- through the network):
+//   sweep 1  (k_mlp_fwdsave) plain forward pass (32 points per wave); sigmoid(100 z) of every hidden unit is written out,
+//            4 KiB per point (f16, operand-fragment layout), for a SEGMENT of the worklist at a time (bounded buffer).
+//            [One fused kernel doing both sweeps per tile out of a cache-resident 1 MiB block was tried and is slower:
+//            the two unrolled sweeps do not fit the instruction cache together.]
+//   sweep 2  (k_mlp_grad) reverse sweep through the TRANSPOSED layers (hip.py implicit_grad_plans):
+//            V_7 = sigma'_7 (.) W_8[sdf row];  V_{l-1} = sigma'_{l-1} (.) (W_l^T V_l);  the "activation" of the shared core is the
+//            multiplication by the stored sigmoid.  The rows of W_4^T and W_0^T that belong to the Fourier-feature inputs
+//            are contracted on the fly with d PE / d x (two small per-wave LDS tables) and give the gradient;
+//            normal = normalize(normalize(grad . Jinv))  (multiply.py:606, 661).
+struct GradCapture {
+    const op_t* tab_a;   // this wave's [32 points][48]: d PE_f / d x for the rows 0..47 of the last reverse layer (f = row)
+    const op_t* tab_b;   // ... for rows 208..255 of the skip layer's transpose (f = row - 217, 0 where row < 217)
+    float (&g)[2][3];
+    template <int NB>
+    __device__ __forceinline__ void operator()(int cid, int bi, const f32x4 (&acc)[NB]) const {
+        const int lane = threadIdx.x & 63, j = lane & 15, gq = lane >> 4;
+        const op_t* tab = cid == 1 ? tab_a : tab_b;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const op_t* tp = tab + (16 * nb + j) * 48 + 16 * bi + 4 * gq;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = max(16 * bi + 4 * gq + r - (cid == 1 ? 0 : 9), 0);
+                const int axis = f < 3 ? f : ((f - 3) % 6) % 3;
+                const float v = acc[nb][r] * (float)tp[r];
+                g[nb][0] += axis == 0 ? v : 0.0f;
+                g[nb][1] += axis == 1 ? v : 0.0f;
+                g[nb][2] += axis == 2 ? v : 0.0f;
+            }
+        }
+    }
+};
+
+
+// ---- sweep 1: work indices [offset, offset + seg) of the worklist.  sig block of (tile t, wave w) of the segment:
+//      sig + ((t * 8 + w) * 8 layers) * 16 KiB;  inside: [layer][K step][block][lane][16 B]
+template <int NB, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_mlp_fwdsave(const NetDesc net, const char* __restrict__ wpack,
+                                                            const float* __restrict__ bias, const float* __restrict__ xc,
+                                                            const int* __restrict__ worklist,
+                                                            const int* __restrict__ count_p, int max_count, int offset,
+                                                            int seg, float* __restrict__ sdf_out,
+                                                            char* __restrict__ feat_frag, char* __restrict__ sigbuf) {
+    constexpr int KS_IN = 2;
+    using L = Lds<KS_IN, NB, WAVES>;
+    static_assert(L::PTS == 32 && WAVES == 8, "feature / sigmoid block addressing assumes 8 waves x 32 points");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int count = min(count_p ? min(*count_p, max_count) : max_count, offset + seg);
+    if (offset >= count) return;
+    float* bias_lds = (float*)(smem + L::bias0);
+    op_t* stage = (op_t*)(smem + L::stage) + wave * L::PTS * in_stride(KS_IN);
+    load_bias(net, bias, bias_lds);
+    constexpr int SIG_LAYER = KS_REG * NB * 1024;
+    for (int t = blockIdx.x; offset + t * L::TILE < count; t += gridDim.x) {
+        const int w = offset + t * L::TILE + wave * L::PTS + lane;
+        const int id = (lane < L::PTS && w < count) ? (worklist ? worklist[w] : w) : -1;
+        if (lane < L::PTS) {
+            float x[3] = {0.f, 0.f, 0.f};
+            if (id >= 0) { x[0] = xc[3 * (size_t)id]; x[1] = xc[3 * (size_t)id + 1]; x[2] = xc[3 * (size_t)id + 2]; }
+            stage_pe<3, 6, KS_IN>(stage + lane * in_stride(KS_IN), x);
+        }
+        opx8 Bcur[KS_REG][NB];
+        f32x4 out[NB];
+        zero_b<NB>(Bcur);
+        prologue<KS_IN, WAVES>(net, wpack, smem + L::ring, wave, lane);
+        const SigIO sio = {sigbuf + ((size_t)t * WAVES + wave) * (size_t)(8 * SIG_LAYER), SIG_LAYER};
+        run_net<NB, false, KS_IN, HID_SOFTPLUS_SAVE, WAVES>(net, wpack, bias_lds, smem + L::ring, Bcur, stage, out, wave, lane,
+                                                            sio);
+        // features in the colour kernel's layout: tiles of 64 work items (offset is a multiple of 256), 4 blocks of 16 columns
+        const size_t tile = (size_t)(offset / 64) + (size_t)t * 4 + (wave >> 1);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+            for (int ks = 0; ks < KS_REG; ++ks)
+                *(opx8*)(feat_frag + ((tile * KS_REG + ks) * 4 + (wave & 1) * 2 + nb) * 1024 + lane * 16) = Bcur[ks][nb];
+            const int pid = __shfl(id, nb * 16 + (lane & 15));
+            if (lane < 16 && pid >= 0) sdf_out[pid] = out[nb][0];
+        }
+    }
+}
+
+// ---- sweep 2
+template <int NB, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_mlp_grad(const NetDesc net, const char* __restrict__ wpack,
+                                                         const op_t* __restrict__ w8_slots, const float* __restrict__ xc,
+                                                         const float* __restrict__ jinv, const int* __restrict__ worklist,
+                                                         const int* __restrict__ count_p, int max_count, int offset, int seg,
+                                                         const char* __restrict__ sigbuf, float* __restrict__ normal_out) {
+    constexpr int KS_IN = 2, PTS = 16 * NB, TILE = PTS * WAVES;
+    static_assert(NB == 2 && WAVES == 8, "matches k_mlp_fwdsave's tile / wave / point addressing");
+    constexpr int RING = RING_SLOTS * chunk_bytes(KS_IN);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, gq = lane >> 4;
+    const int count = min(count_p ? min(*count_p, max_count) : max_count, offset + seg);
+    if (offset >= count) return;
+    float* zero_bias = (float*)(smem + RING);                         // MAX_LAYERS * BIAS_STRIDE zeros (the sweep has no bias)
+    op_t* w8 = (op_t*)(smem + RING + BIAS_BYTES);                     // [256] sdf-row weights in K-slot order
+    op_t* tabs = w8 + 256 + wave * (2 * PTS * 48);
+    for (int i = threadIdx.x; i < MAX_LAYERS * BIAS_STRIDE; i += blockDim.x) zero_bias[i] = 0.0f;
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) w8[i] = w8_slots[i];
+    constexpr int SIG_LAYER = KS_REG * NB * 1024;
+    for (int t = blockIdx.x; offset + t * TILE < count; t += gridDim.x) {
+        const int w = offset + t * TILE + wave * PTS + (lane & (PTS - 1));
+        const int id = w < count ? (worklist ? worklist[w] : w) : -1;     // lanes l and l+32 both know point l's id
+        if (lane < PTS) {   // d PE_f / d x_axis(f), f = 0..38 (embedders.py layout: x, then per octave sin(3), cos(3))
+            float x[3] = {0.f, 0.f, 0.f};
+            if (id >= 0) { x[0] = xc[3 * (size_t)id]; x[1] = xc[3 * (size_t)id + 1]; x[2] = xc[3 * (size_t)id + 2]; }
+            op_t* ta = tabs + lane * 48;
+            op_t* tb = tabs + PTS * 48 + lane * 48;
+#pragma unroll
+            for (int f = 0; f < 48; ++f) { ta[f] = (op_t)0.0f; tb[f] = (op_t)0.0f; }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                ta[a] = (op_t)1.0f;
+                float sn, cs, fr = 1.0f;
+                sincosf(x[a], &sn, &cs);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    ta[3 + 6 * k + a] = (op_t)(fr * cs);
+                    ta[3 + 6 * k + 3 + a] = (op_t)(-fr * sn);
+                    const float s2 = 2.0f * sn * cs, c2 = 1.0f - 2.0f * sn * sn;
+                    sn = s2; cs = c2; fr *= 2.0f;
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < 39; ++f) tb[9 + f] = ta[f];
+        }
+        const SigIO sio = {const_cast<char*>(sigbuf) + ((size_t)t * WAVES + wave) * (size_t)(8 * SIG_LAYER), SIG_LAYER};
+        // V_7 = sigma'_7 (.) W_8[sdf row]
+        opx8 Bcur[KS_REG][NB];
+        __syncthreads();   // w8 / zero_bias visible
+#pragma unroll
+        for (int ks = 0; ks < KS_REG; ++ks) {
+            const opx8 wv = *(const opx8*)(w8 + ks * 32 + 8 * gq);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                Bcur[ks][nb] = *(const opx8*)(sio.base + (size_t)7 * SIG_LAYER + (ks * NB + nb) * 1024 + lane * 16) * wv;
+        }
+        float g[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+        f32x4 out[NB];
+        prologue<KS_IN, WAVES>(net, wpack, smem, wave, lane);   // barrier inside: tables visible
+        run_net<NB, false, KS_IN, HID_SIGMUL, WAVES, GradCapture>(net, wpack, zero_bias, smem, Bcur, nullptr, out, wave, lane, sio,
+                                                                   GradCapture{tabs, tabs + PTS * 48, g});
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                g[nb][a] += __shfl_xor(g[nb][a], 16);
+                g[nb][a] += __shfl_xor(g[nb][a], 32);
+            }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int pid = __shfl(id, nb * 16 + (lane & 15));
+            if (lane < 16 && pid >= 0) {
+                const float gx = g[nb][0], gy = g[nb][1], gz = g[nb][2];
+                const float* Ji = jinv + 9 * (size_t)pid;
+                float n0 = gx * Ji[0] + gy * Ji[3] + gz * Ji[6];
+                float n1 = gx * Ji[1] + gy * Ji[4] + gz * Ji[7];
+                float n2 = gx * Ji[2] + gy * Ji[5] + gz * Ji[8];
+                float inv = 1.0f / fmaxf(sqrtf(n0 * n0 + n1 * n1 + n2 * n2), 1e-12f);  // F.normalize default eps
+                n0 *= inv; n1 *= inv; n2 *= inv;
+                inv = 1.0f / fmaxf(sqrtf(n0 * n0 + n1 * n1 + n2 * n2), 1e-6f);         // multiply.py:606
+                normal_out[3 * (size_t)pid] = n0 * inv;
+                normal_out[3 * (size_t)pid + 1] = n1 * inv;
+                normal_out[3 * (size_t)pid + 2] = n2 * inv;
+            }
+        }
+        __syncthreads();   // the tables are rebuilt by the next tile
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ colour
 template <int NB, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_mlp_color(const NetDesc net, const char* __restrict__ wpack,
@@ -492,6 +667,31 @@ extern "C" int mp_mlp_full(const MpNet* net, const void* wpack, const float* bia
                            dim3(PWAVES * 64), L::total, st, d, (const char*)wpack, bias, x, n, out);
     } else {
         return -1;
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_mlp_shade_rev(const MpNet* net, const void* wpack, const float* bias, const MpNet* gnet, const void* gpack,
+                                const void* w8_slots, const float* xc, const float* jinv, const int* worklist,
+                                const int* count, int max_count, float* sdf_out, float* normal_out, void* feat_frag,
+                                void* sig, int seg_points, void* stream) {
+    if (max_count <= 0) return 0;
+    if (seg_points < 256 || seg_points % 256) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    using L = Lds<2, PNB, PWAVES>;
+    constexpr int TILE = 16 * PNB * PWAVES;
+    constexpr int LDS_G = RING_SLOTS * chunk_bytes(2) + BIAS_BYTES + 512 + PWAVES * 2 * 16 * PNB * 48 * 2;
+    static int once = set_lds(k_mlp_fwdsave<PNB, PWAVES>, L::total) + set_lds(k_mlp_grad<PNB, PWAVES>, LDS_G);
+    (void)once;
+    const NetDesc d = as_desc(net), gd = as_desc(gnet);
+    for (int off = 0; off < max_count; off += seg_points) {   // segments past the device-side count return at once
+        const int n = max_count - off < seg_points ? max_count - off : seg_points;
+        const int grid = grid_for((n + TILE - 1) / TILE, 1);
+        hipLaunchKernelGGL((k_mlp_fwdsave<PNB, PWAVES>), dim3(grid), dim3(PWAVES * 64), L::total, st, d, (const char*)wpack, bias,
+                           xc, worklist, count, max_count, off, seg_points, sdf_out, (char*)feat_frag, (char*)sig);
+        hipLaunchKernelGGL((k_mlp_grad<PNB, PWAVES>), dim3(grid), dim3(PWAVES * 64), LDS_G, st, gd, (const char*)gpack,
+                           (const op_t*)w8_slots, xc, jinv, worklist, count, max_count, off, seg_points, (const char*)sig,
+                           normal_out);
     }
     return (int)hipGetLastError();
 }

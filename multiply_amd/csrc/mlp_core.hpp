@@ -53,7 +53,7 @@ __host__ __device__ constexpr int chunk_bytes(int ks_in) { return CHUNK_MB * mb_
 constexpr int RING_SLOTS = 3;   // weight chunks are loaded two chunks ahead of their use
 __host__ __device__ constexpr int in_stride(int ks_in) { return ks_in * 32 + 8; }  // halves per staging row (+pad)
 
-enum Act : int { ACT_NONE = 0, ACT_SOFTPLUS = 1, ACT_RELU = 2 };
+enum Act : int { ACT_NONE = 0, ACT_SOFTPLUS = 1, ACT_RELU = 2, ACT_SIGMUL = 3 };
 
 struct LayerDesc {
     int n_chunk;    // chunks of 32 output rows (1..9)
@@ -61,6 +61,8 @@ struct LayerDesc {
     int use_in;     // consume the 2 input K steps
     int act;        // Act
     int out_chunk;  // chunk whose first 16 rows are returned in fp32 `out` instead of feeding the next layer (-1: none)
+    int aux;        // bits 0..7: 1 + index of the stored-sigmoid layer this layer's outputs are multiplied by (ACT_SIGMUL);
+                    // bits 8..15: capture id (reverse sweep: which 48 output rows are the input-encoding gradient), 0 = none
 };
 
 struct NetDesc {
@@ -133,7 +135,15 @@ struct NextB {
     }
 };
 
-enum Hidden : int { HID_SOFTPLUS = 0, HID_RELU = 1 };
+// HID_SOFTPLUS_SAVE: softplus, and the sigmoid of every hidden unit is written out in the operand-fragment layout
+//   [layer][K step][column block][lane][8 halves]  (one 16 B store per lane when a K step's operand is complete)
+// HID_SIGMUL: the "activation" is a multiplication by such a stored sigmoid: the reverse sweep of reverse-mode
+//   differentiation runs through the same core with the transposed weights.
+enum Hidden : int { HID_SOFTPLUS = 0, HID_RELU = 1, HID_SOFTPLUS_SAVE = 2, HID_SIGMUL = 3 };
+struct SigIO {
+    char* base;       // this wave's sigmoid block of the current tile
+    int layer_bytes;  // bytes per layer in it (= 8 * NB * 1024)
+};
 
 // Softplus networks are evaluated in SCALED UNITS: every hidden pre-activation / activation carries the factor
 // K = 100 log2(e) (the host scales biases and input-fed weights by K and the last, linear layer's weights by 1/K, see
@@ -201,7 +211,8 @@ __device__ __forceinline__ h2 row_shr8(h2 s) {
 //            with (lane & 8) == 0 hold the value / d/dy columns of point lane&7, the others d/dx / d/dz.
 //            q = 0, 1: row pair q of both blocks (softplus + sigmoid on the values, tangents scaled by the sigmoid)
 template <int NB, bool FWD, int HID, int q, typename NB_T>
-__device__ __forceinline__ void act_piece(f32x4 (&p)[NB], bool hidden, NB_T& Bn, int pc, int ph) {
+__device__ __forceinline__ void act_piece(f32x4 (&p)[NB], bool hidden, NB_T& Bn, int pc, int ph, u32x4 (&sg)[NB],
+                                          const SigIO& sig, int sig_layer) {
     static_assert(NB == 2 || (NB == 4 && FWD), "2 column blocks per wave (2 waves per SIMD), or the 4-block forward layout");
     if constexpr (FWD && NB == 4) {
         // full-block tangent layout (16 points per wave, one wave per SIMD): block 0 = values, blocks 1..3 = d/dx, d/dy,
@@ -253,16 +264,34 @@ __device__ __forceinline__ void act_piece(f32x4 (&p)[NB], bool hidden, NB_T& Bn,
         if constexpr (q < 4) {
             constexpr int nb = q / 2, j = q % 2;
             h2 z = to_h2(p[nb][2 * j], p[nb][2 * j + 1]);
-            if (hidden) z = HID == HID_SOFTPLUS ? softplus2(z) : relu_h2(z);
+            if constexpr (HID == HID_SOFTPLUS_SAVE) {
+                if (hidden) {
+                    const h2 h = softplus2(z);
+                    const unsigned sv = bits(exp2_h2(z - h));   // sigmoid(z') = 2^(z' - h')
+                    if (ph == 0) { if (j == 0) sg[nb][0] = sv; else sg[nb][1] = sv; }
+                    else { if (j == 0) sg[nb][2] = sv; else sg[nb][3] = sv; }
+                    z = h;
+                    if (ph == 1 && j == 1 && pc < KS_REG)
+                        *(u32x4*)(sig.base + (size_t)sig_layer * sig.layer_bytes + (pc * NB + nb) * 1024 + (threadIdx.x & 63) * 16) = sg[nb];
+                }
+            } else if constexpr (HID == HID_SIGMUL) {
+                if (hidden) {
+                    const unsigned sv = ph == 0 ? (j == 0 ? sg[nb][0] : sg[nb][1]) : (j == 0 ? sg[nb][2] : sg[nb][3]);
+                    z = z * __builtin_bit_cast(h2, sv);
+                }
+            } else {
+                if (hidden) z = HID == HID_SOFTPLUS ? softplus2(z) : relu_h2(z);
+            }
             if (pc < KS_REG) Bn.put(pc, nb, ph, j, z);
         }
     }
 }
 
 template <int NB, bool FWD, int HID, int q, typename NB_T>
-__device__ __forceinline__ void act_from(f32x4 (&p)[NB], bool hidden, NB_T& Bn, int pc, int ph) {
-    act_piece<NB, FWD, HID, q>(p, hidden, Bn, pc, ph);
-    if constexpr (q + 1 < 8) act_from<NB, FWD, HID, q + 1>(p, hidden, Bn, pc, ph);
+__device__ __forceinline__ void act_from(f32x4 (&p)[NB], bool hidden, NB_T& Bn, int pc, int ph, u32x4 (&sg)[NB],
+                                         const SigIO& sig, int sig_layer) {
+    act_piece<NB, FWD, HID, q>(p, hidden, Bn, pc, ph, sg, sig, sig_layer);
+    if constexpr (q + 1 < 8) act_from<NB, FWD, HID, q + 1>(p, hidden, Bn, pc, ph, sg, sig, sig_layer);
 }
 
 // Runs the whole network for this wave's NB column blocks.
@@ -275,12 +304,23 @@ __device__ __forceinline__ void act_from(f32x4 (&p)[NB], bool hidden, NB_T& Bn, 
 // of the next block; A tiles run PF tiles ahead in a rotating register queue across block and chunk boundaries;
 // weight chunks are loaded two chunks ahead into a 3-slot LDS ring (one barrier per chunk).
 // The caller must have run prologue() (chunks 0 and 1 in ring slots 0 and 1, barrier).
-template <int NB, bool FWD, int KS_IN, int HID, int WAVES>
+struct NoCapture {
+    template <int NB>
+    __device__ __forceinline__ void operator()(int, int, const f32x4 (&)[NB]) const {}
+};
+
+template <int NB, bool FWD, int KS_IN, int HID, int WAVES, typename Cap = NoCapture>
 __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restrict__ wpack, const float* bias_lds,
                                         char* wring, opx8 (&Bcur)[KS_REG][NB], const op_t* stage_wave,
-                                        f32x4 (&out)[NB], int wave, int lane) {
+                                        f32x4 (&out)[NB], int wave, int lane, SigIO sig = SigIO{nullptr, 0},
+                                        Cap cap = Cap()) {
     const int g = lane >> 4;
     int ci = 0;
+    // sigmoid fragments of the K steps under construction (HID_SOFTPLUS_SAVE / HID_SIGMUL), double-buffered by chunk
+    // parity: chunk c's group is live from block (c,1) to block (c+1,0), the next one is loaded at chunk c+1's start
+    u32x4 sgb[2][NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) sgb[0][nb] = sgb[1][nb] = (u32x4){0u, 0u, 0u, 0u};
     NextB<NB, (NB > 2)> Bn;   // 4 blocks: the operand under construction lives in the accumulator file
     Bn.zero();
     constexpr int PF = 3, QN = 4;   // prefetch distance / queue length in A tiles
@@ -291,6 +331,8 @@ __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restri
         const LayerDesc L = net.layer[l];
         const float* bl = bias_lds + l * BIAS_STRIDE;
         const bool hidden = L.act != ACT_NONE;
+        const int sig_layer = HID == HID_SIGMUL ? (L.aux & 0xff) - 1 : l;
+        const int cap_id = (L.aux >> 8) & 0xff;
         f32x4 pend[NB];  // finished block whose activation is still pending
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) pend[nb] = (f32x4){0, 0, 0, 0};
@@ -304,6 +346,14 @@ __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restri
                 // chunk ci+1 landed before the previous barrier: its first A tiles are prefetched from this chunk
                 const char* slot_next = wring + ((ci + 1) % RING_SLOTS) * chunk_bytes(KS_IN) + lane * 16;
                 const bool has_next = ci + 1 < net.total_chunks;
+                if constexpr (HID == HID_SIGMUL) {
+                    if (hidden) {
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            sgb[c & 1][nb] = *(const u32x4*)(sig.base + (size_t)sig_layer * sig.layer_bytes + (c * NB + nb) * 1024 +
+                                                             lane * 16);
+                    }
+                }
 #pragma unroll
                 for (int mbl = 0; mbl < CHUNK_MB; ++mbl) {
                     f32x4 acc[NB];
@@ -320,7 +370,7 @@ __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restri
 #ifdef MP_EXP_NOACT
 #define MP_ACT_STMT(KS)
 #else
-#define MP_ACT_STMT(KS) if (has_pend) act_piece<NB, FWD, HID, KS>(pend, hidden, Bn, pc, ph);
+#define MP_ACT_STMT(KS) if (has_pend) act_piece<NB, FWD, HID, KS>(pend, hidden, Bn, pc, ph, sgb[pc & 1], sig, sig_layer);
 #endif
 #ifdef MP_EXP_NOLDS
 #define MP_LDS_STMT (void)src;
@@ -362,7 +412,7 @@ __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restri
                         // in step with the tile stream and finish the pending block's activation
                         MP_QSKIP(0) MP_QSKIP(1) MP_QSKIP(2) MP_QSKIP(3) MP_QSKIP(4) MP_QSKIP(5) MP_QSKIP(6) MP_QSKIP(7)
 #ifndef MP_EXP_NOACT
-                        if (has_pend) act_from<NB, FWD, HID, 0>(pend, hidden, Bn, pc, ph);
+                        if (has_pend) act_from<NB, FWD, HID, 0>(pend, hidden, Bn, pc, ph, sgb[pc & 1], sig, sig_layer);
 #endif
                     }
 #undef MP_KSTEP
@@ -383,6 +433,13 @@ __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restri
                     }
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) pend[nb] = acc[nb];
+                    if (cap_id == 1) {          // rows 0..47: blocks (0,0), (0,1), (1,0)
+                        if (c == 0) cap(1, mbl, acc);
+                        else if (c == 1 && mbl == 0) cap(1, 2, acc);
+                    } else if (cap_id == 2) {   // rows 208..255: blocks (6,1), (7,0), (7,1)
+                        if (c == 6 && mbl == 1) cap(2, 0, acc);
+                        else if (c == 7) cap(2, 1 + mbl, acc);
+                    }
                     if ((c == 0 || c == MAX_CHUNKS - 1) && mbl == 0) {
                         if (c == L.out_chunk) {  // fp32 rows 0..15 of the out chunk (its layer is linear)
 #pragma unroll
@@ -391,7 +448,7 @@ __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restri
                     }
                 }
                 if (c == L.n_chunk - 1) {  // layer ends: drain the pipeline (block (c, 1))
-                    act_from<NB, FWD, HID, 0>(pend, hidden, Bn, c, 1);
+                    act_from<NB, FWD, HID, 0>(pend, hidden, Bn, c, 1, sgb[c & 1], sig, sig_layer);
                 }
 #ifndef MP_EXP_NOBARRIER
                 __syncthreads();  // every wave is done with chunk ci; chunk ci+2's loads have had a whole chunk to land

@@ -15,13 +15,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MP_LIB_PATH", os.path.join(_HERE, "libmultiply_hip.so"))  # override: experiments only
 
 MAX_LAYERS, MAX_CHUNKS, BIAS_STRIDE = 10, 9, 288
-ACT_NONE, ACT_SOFTPLUS, ACT_RELU = 0, 1, 2
+ACT_NONE, ACT_SOFTPLUS, ACT_RELU, ACT_SIGMUL = 0, 1, 2, 3
 KNN_CLUSTER, KNN_NC = 64, 108
 
 
 class MpLayer(C.Structure):
     _fields_ = [("n_chunk", C.c_int), ("use_reg", C.c_int), ("use_in", C.c_int), ("act", C.c_int),
-                ("out_chunk", C.c_int)]
+                ("out_chunk", C.c_int), ("aux", C.c_int)]
 
 
 class MpNet(C.Structure):
@@ -127,8 +127,11 @@ class LayerPlan:
     """How one nn.Linear maps onto the packed layout."""
 
     def __init__(self, lin, rowmap, reg_cols=None, in_cols=None, scale=1.0, hoist=None, act=ACT_NONE, out_chunk=-1,
-                 in_scale=None, bias_scale=1.0):
+                 in_scale=None, bias_scale=1.0, transpose=False, row_scale=None, aux=0):
+        """transpose: pack W^T (rows = the layer's INPUT features, K = its outputs; reverse sweep); row_scale: optional
+        per-row factors of the transposed matrix (the input-side scales of the forward plan); aux: see MpLayer.aux."""
         self.lin, self.act, self.out_chunk = lin, act, out_chunk
+        self.transpose, self.row_scale, self.aux = transpose, row_scale, aux
         self.in_scale = float(scale if in_scale is None else in_scale)   # factor on the input-fed K slots
         self.bias_scale = float(bias_scale)
         rowmap = list(rowmap)
@@ -168,7 +171,7 @@ class PackedNet:
             assert 1 <= nch <= MAX_CHUNKS
             L = self.net.layer[i]
             L.n_chunk, L.use_reg, L.use_in = nch, int(p.reg_cols is not None), int(p.in_cols is not None)
-            L.act, L.out_chunk = p.act, p.out_chunk
+            L.act, L.out_chunk, L.aux = p.act, p.out_chunk, p.aux
             self.offsets.append(off)
             off += nch
         self.net.total_chunks = off
@@ -191,6 +194,14 @@ class PackedNet:
     def _pack_layer(self, i, weights, hoist_vec):
         p = self.plans[i]
         v, g, b = self._params(p.lin)
+        if p.transpose:      # reverse sweep: effective weight (weight norm resolved), transposed, input-side scales on the rows
+            w = v.detach().float()
+            if g is not None:
+                w = w * (g.detach().reshape(-1, 1) / w.norm(dim=1, keepdim=True))
+            w = w.t()
+            if p.row_scale is not None:
+                w = w * torch.as_tensor(p.row_scale, dtype=torch.float32, device=w.device).reshape(-1, 1)
+            v, g, b = w.contiguous(), None, torch.zeros(w.shape[0], dtype=torch.float32, device=w.device)
         v, b = v.detach().contiguous(), b.detach().contiguous()
         g = None if g is None else g.detach().reshape(-1).contiguous()
         h0, hn = p.hoist if (p.hoist is not None and hoist_vec is not None) else (0, 0)
@@ -255,6 +266,43 @@ def implicit_plans(net, variant):
     return plans
 
 
+def implicit_grad_plans(net):
+    """Reverse sweep of the foreground ImplicitNet for d sdf / d x (csrc/mlp.hip k_mlp_shade_rev, sweep 2): layers 7..1 transposed
+    (rows = that layer's inputs, K = its outputs in K-slot order, outputs multiplied by the stored sigmoid of the layer
+    below), then the input-fed part of layer 0 transposed.  The skip layer's transpose also carries the 39 rows of the
+    re-injected encoding (captured as gradient rows, capture id 2); layer 0's rows are captured with id 1."""
+    assert net.d_in == 3 and net.multires == 6 and list(net.skip_in) == [4] and net.num_layers - 1 == 9
+    E, K = net.embed_dim, SOFTPLUS_K
+    lins = list(net.layers())
+    r2 = 1.0 / math.sqrt(2.0)
+    plans = []
+    for l in range(7, 0, -1):
+        lin = lins[l]
+        wv = lin.weight_v if hasattr(lin, "weight_v") else lin.weight
+        out_dim, in_dim = wv.shape
+        row_scale, aux = None, (l - 1) + 1           # outputs (= h_{l-1} adjoint) x sigma'_{l-1}
+        if l in net.skip_in:
+            prev = in_dim - E
+            row_scale = np.concatenate([np.full(prev, r2), np.full(E, r2 * K)])
+            aux |= 2 << 8
+        plans.append(LayerPlan(lin, range(in_dim), reg_cols=np.arange(out_dim), act=ACT_SIGMUL, transpose=True,
+                               row_scale=row_scale, aux=aux))
+    lin0 = lins[0]
+    plans.append(LayerPlan(lin0, range(E), reg_cols=np.arange(lin0.bias.shape[0]), act=ACT_NONE, transpose=True,
+                           row_scale=np.concatenate([np.full(E, K), np.zeros(net.cond_dim)]), aux=1 << 8))
+    return plans
+
+
+def sdf_row_slots(net):
+    """the sdf row of the last layer (effective weights) as 256 halves in K-slot order: V_8 of the reverse sweep"""
+    lin = list(net.layers())[-1]
+    w = (lin.weight_v if hasattr(lin, "weight_v") else lin.weight).detach().float()
+    if hasattr(lin, "weight_g"):
+        w = w * (lin.weight_g.detach().reshape(-1, 1) / w.norm(dim=1, keepdim=True))
+    idx = torch.as_tensor(_REG_FEATURE, device=w.device)
+    return w[0][idx].to(torch.float16).contiguous()
+
+
 def rendering_plans(net):
     """LayerPlans of a RenderingNet: 'pose_no_view' = [x_c3, n3 | pose8 hoisted | feat256]; 'nerf_frame_encoding' =
     [PE4(view) 27 | frame32 hoisted | feat256]."""
@@ -283,7 +331,10 @@ def packed(module, role, ks_in):
     key = (role, ks_in, str(dev))
     if key not in cache:
         from .networks import ImplicitNet
-        plans = implicit_plans(module, role) if isinstance(module, ImplicitNet) else rendering_plans(module)
+        if isinstance(module, ImplicitNet):
+            plans = implicit_grad_plans(module) if role == "grad" else implicit_plans(module, role)
+        else:
+            plans = rendering_plans(module)
         cache[key] = PackedNet(plans, ks_in, dev)
     return cache[key]
 
@@ -335,8 +386,58 @@ def implicit_sdf(net, x_c, cond_vec):
     return out
 
 
-def shade_points(imp, ren, x_c, jinv, cond_vec):
-    """sdf, normals, rgb at canonical points (forward-mode ImplicitNet + RenderingNet 'pose_no_view')."""
+SHADE_MODE = os.environ.get("MP_SHADE_MODE", "reverse")   # "reverse" (2 sweeps, 2 network columns per point) | "forward"
+
+
+class GradNet:
+    """packed reverse-sweep network + the sdf row in K-slot order of one foreground ImplicitNet (cached on the module)"""
+
+    def __init__(self, imp):
+        self.imp = imp
+        self.pk = packed(imp, "grad", 2)
+        self.w8 = None
+        self.version = None
+
+    def refresh(self):
+        self.pk.refresh(None)
+        if self.version != self.pk.version:
+            self.w8 = sdf_row_slots(self.imp)
+            self.version = self.pk.version
+        return self
+
+
+def grad_net(imp):
+    g = imp.__dict__.get("_mp_gradnet")
+    if g is None:
+        g = imp.__dict__["_mp_gradnet"] = GradNet(imp)
+    return g.refresh()
+
+
+SEG_POINTS = 1 << 21          # work items per segment of the reverse-mode shading: 8 GiB of stored sigmoids
+
+
+def sig_scratch(device):
+    """per-device buffer for the stored sigmoids of the reverse-mode shading kernels.  Zero-initialised once: the K steps
+    a narrower layer never writes (layer 3 has 217 outputs) must read as finite numbers in the reverse sweep."""
+    key = str(device)
+    buf = _SCRATCH.get(key)
+    if buf is None:
+        buf = _SCRATCH[key] = torch.zeros(SEG_POINTS * 4096, dtype=torch.uint8, device=device)
+    return buf
+
+
+_SCRATCH = {}
+
+
+def shade_rev_launch(pki, gn, x_c, jinv, worklist, count, n, sdf, nrm, feat):
+    check(lib().mp_mlp_shade_rev(C.byref(pki.net), ptr(pki.wpack), ptr(pki.bias), C.byref(gn.pk.net), ptr(gn.pk.wpack),
+                                 ptr(gn.w8), ptr(x_c), ptr(jinv), ptr(worklist), ptr(count), n, ptr(sdf), ptr(nrm),
+                                 ptr(feat), ptr(sig_scratch(x_c.device)), SEG_POINTS, stream()), "mp_mlp_shade_rev")
+
+
+def shade_points(imp, ren, x_c, jinv, cond_vec, mode=None):
+    """sdf, normals, rgb at canonical points (ImplicitNet value + input gradient, RenderingNet 'pose_no_view').
+    mode 'reverse': mp_mlp_shade_rev (two sweeps); 'forward': the forward-mode kernel mp_mlp_shade."""
     require_device()
     n = x_c.shape[0]
     x_c = x_c.detach().float().contiguous()
@@ -354,8 +455,11 @@ def shade_points(imp, ren, x_c, jinv, cond_vec):
     rgb = torch.empty(n, 3, dtype=torch.float32, device=dev)
     tiles = (n + 255) // 256 * 4
     feat = torch.empty(tiles * 8 * 4 * 1024, dtype=torch.uint8, device=dev)
-    check(lib().mp_mlp_shade(C.byref(pki.net), ptr(pki.wpack), ptr(pki.bias), ptr(x_c), ptr(jinv), None, None, n,
-                             ptr(sdf), ptr(nrm), ptr(feat), stream()), "mp_mlp_shade")
+    if (mode or SHADE_MODE) == "reverse":
+        shade_rev_launch(pki, grad_net(imp), x_c, jinv, None, None, n, sdf, nrm, feat)
+    else:
+        check(lib().mp_mlp_shade(C.byref(pki.net), ptr(pki.wpack), ptr(pki.bias), ptr(x_c), ptr(jinv), None, None, n,
+                                 ptr(sdf), ptr(nrm), ptr(feat), stream()), "mp_mlp_shade")
     check(lib().mp_mlp_color(C.byref(pkr.net), ptr(pkr.wpack), ptr(pkr.bias), ptr(x_c), ptr(nrm), ptr(feat), None,
                              None, n, ptr(rgb), stream()), "mp_mlp_color")
     return sdf, nrm, rgb

@@ -85,6 +85,7 @@ class Multiply(nn.Module):
 
         self.sdf_bounding_sphere = 3.0
         self.threshold = 0.05
+        self.shade_mode = hip.SHADE_MODE      # 'reverse' | 'forward' (csrc/mlp.hip: k_mlp_shade_rev | k_mlp_shade)
         self.density = LaplaceDensity(**opt.density)
         self.bg_density = AbsDensity()
         self.ray_sampler = ErrorBoundSampler(self.sdf_bounding_sphere, inverse_sphere_bg=True, **opt.ray_sampler)
@@ -328,10 +329,14 @@ class Multiply(nn.Module):
             ren.__dict__["_mp_pose_embed"] = pe
             pk_col.refresh(pe(pp["cond"]))
             feat = torch.empty(((npts + 255) // 256) * 4 * 8 * 4 * 1024, dtype=torch.uint8, device=dev)
-            with self._ph("mlp_shade"):
-                hip.check(L.mp_mlp_shade(C.byref(pk_full.net), hip.ptr(pk_full.wpack), hip.ptr(pk_full.bias), hip.ptr(xc),
-                                         hip.ptr(jinv), hip.ptr(work2), hip.ptr(wc2), npts, hip.ptr(sdf), hip.ptr(nrm),
-                                         hip.ptr(feat), st), "mp_mlp_shade")
+            if self.shade_mode == "reverse":     # value sweep (parks the sigmoids) + reverse sweep for the normals
+                with self._ph("mlp_shade"):
+                    hip.shade_rev_launch(pk_full, hip.grad_net(imp), xc, jinv, work2, wc2, npts, sdf, nrm, feat)
+            else:
+                with self._ph("mlp_shade"):
+                    hip.check(L.mp_mlp_shade(C.byref(pk_full.net), hip.ptr(pk_full.wpack), hip.ptr(pk_full.bias), hip.ptr(xc),
+                                             hip.ptr(jinv), hip.ptr(work2), hip.ptr(wc2), npts, hip.ptr(sdf), hip.ptr(nrm),
+                                             hip.ptr(feat), st), "mp_mlp_shade")
             with self._ph("mlp_color"):
                 hip.check(L.mp_mlp_color(C.byref(pk_col.net), hip.ptr(pk_col.wpack), hip.ptr(pk_col.bias), hip.ptr(xc),
                                          hip.ptr(nrm), hip.ptr(feat), hip.ptr(work2), hip.ptr(wc2), npts, hip.ptr(rgb),

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(lib_path):
 
 def test_struct_layouts_match_header():
     from multiply_amd import hip
-    assert ctypes.sizeof(hip.MpLayer) == 20 and ctypes.sizeof(hip.MpNet) == 8 + 20 * hip.MAX_LAYERS
+    assert ctypes.sizeof(hip.MpLayer) == 24 and ctypes.sizeof(hip.MpNet) == 8 + 24 * hip.MAX_LAYERS
     assert ctypes.sizeof(hip.MpSamplerCfg) == 32
     assert ctypes.sizeof(hip.MpSamplerState) == 11 * ctypes.sizeof(ctypes.c_void_p)
 

@@ -37,3 +37,6 @@ if which in ("all", "shade"):
 if which in ("all", "sdf"):
     t = timeit(lambda: hip.implicit_sdf(imp, x, cond))
     print(f"sdf only   : {n / t / 1e6:.1f} Mpts/s, algorithmic {2 * M_IMP * n / t / 1e12:.0f} TFLOP/s  ({t * 1e3:.1f} ms)")
+if which in ("all", "shade_forward"):
+    t = timeit(lambda: hip.shade_points(imp, ren, x, jinv, cond, mode="forward"))
+    print(f"shade+color (forward-mode kernel): {n / t / 1e6:.1f} Mpts/s  ({t * 1e3:.1f} ms)")
