@@ -298,15 +298,20 @@ def main():
     # separate runs, gfx950 half-count correction on reads) are kept under profiles/; the counters cannot be read from
     # inside the process, so the committed measurement is attached when it was taken on this workload.
     traffic = None
-    kern = {"mlp_shade": "k_mlp_shade", "mlp_color": "k_mlp_color", "background": "k_background",
-            "sampler_mlp_sdf": "k_mlp_sdf"}[dom]
+    kernels = {"mlp_shade": ["k_mlp_fwdsave", "k_mlp_grad"] if model.shade_mode == "reverse" else ["k_mlp_shade"],
+               "mlp_color": ["k_mlp_color"], "background": ["k_background"], "sampler_mlp_sdf": ["k_mlp_sdf"]}[dom]
     pmc_file = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(pmc_file) and args.res == 512 and args.samples == 128:
         with open(pmc_file) as f:
-            e = json.load(f).get(kern)
-        if e:
-            traffic = {"bytes_per_launch": e["hbm_read_bytes_corrected"] + e["hbm_write_bytes_uncalibrated"],
-                       "read": e["hbm_read_bytes_corrected"], "write": e["hbm_write_bytes_uncalibrated"],
+            pmc = json.load(f)                      # per-dispatch averages of ONE frame (bench.py --steps 1 --warmup 0)
+        rd = wr = 0.0
+        for name, e in pmc.items():
+            if any(k in name for k in kernels):
+                rd += e["hbm_read_bytes_corrected"] * e["dispatches"]
+                wr += e["hbm_write_bytes_uncalibrated"] * e["dispatches"]
+        if rd + wr > 0:
+            traffic = {"bytes_per_launch": (rd + wr) / launches_per_frame, "read": rd / launches_per_frame,
+                       "write": wr / launches_per_frame,
                        "source": "profiles/r01_pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
 
     if rank == 0:
@@ -320,7 +325,7 @@ def main():
                                    f"person), N_samples_eval={max(128, args.samples)}, 32 background samples, "
                                    f"convergence groups of 512 rays (reference pixel_per_batch), geometric-init weights",
                        "rays_per_step": R, "frames_per_rank": args.steps, "parallelism": f"frame-sharded dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": dom + " = " + " + ".join(kernels), "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "avg_launch_ms": 1e3 * per_launch_s, "launches_per_step": launches_per_frame,
                          "algorithmic_flop_per_launch": flops[dom] / launches_per_frame},
