@@ -62,12 +62,19 @@ def test_shade_points(nets_gpu):
     g = torch.autograd.grad(out[:, :1], xg, torch.ones(n, 1))[0]
     nrm = torch.nn.functional.normalize(torch.einsum("bi,bij->bj", g, jinv), dim=1)
     rgb = O.rendering_forward_pose_no_view(sd, "foreground_rendering_network_list.0.", x, nrm, cond, out[:, 1:].detach())
-    sdf_g, nrm_g, rgb_g = hip.shade_points(m.foreground_implicit_network_list[0], m.foreground_rendering_network_list[0],
-                                           x.cuda(), jinv.cuda(), cond.cuda())
-    torch.cuda.synchronize()
-    assert report("shade sdf", sdf_g, out[:, 0].detach()) < 2e-2
-    assert report("shade normal", nrm_g, nrm) < 5e-2
-    assert report("shade rgb", rgb_g, rgb.detach()) < 3e-2
+    # both implementations of the value + input-gradient pass: reverse mode (default: forward sweep + transposed reverse
+    # sweep) and forward mode (value + three tangent columns); tolerances = 5-10x the errors measured with f16 operands
+    res = {}
+    for mode in ("reverse", "forward"):
+        sdf_g, nrm_g, rgb_g = hip.shade_points(m.foreground_implicit_network_list[0], m.foreground_rendering_network_list[0],
+                                               x.cuda(), jinv.cuda(), cond.cuda(), mode=mode)
+        torch.cuda.synchronize()
+        assert report(f"shade sdf ({mode})", sdf_g, out[:, 0].detach()) < 5e-3
+        assert report(f"shade normal ({mode})", nrm_g, nrm) < 2e-2
+        assert report(f"shade rgb ({mode})", rgb_g, rgb.detach()) < 1e-3
+        res[mode] = (sdf_g, nrm_g, rgb_g)
+    assert torch.equal(res["reverse"][0], res["forward"][0])          # the value column is the same arithmetic
+    assert report("normals reverse vs forward", res["reverse"][1], res["forward"][1].cpu()) < 2e-2
 
 
 def test_background(nets_gpu, smpl_tables):
