@@ -374,7 +374,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_grad(const NetDesc net, cons
                                                          const float* __restrict__ jinv, const int* __restrict__ worklist,
                                                          const int* __restrict__ count_p, int max_count, int offset, int seg,
                                                          const char* __restrict__ sigbuf, float* __restrict__ normal_out) {
-    constexpr int KS_IN = 2, PTS = 16 * NB, TILE = PTS * WAVES;
+    constexpr int KS_IN = 0, PTS = 16 * NB, TILE = PTS * WAVES;   // no input-fed K steps: 16 KiB weight chunks
     static_assert(NB == 2 && WAVES == 8, "matches k_mlp_fwdsave's tile / wave / point addressing");
     constexpr int RING = RING_SLOTS * chunk_bytes(KS_IN);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -680,7 +680,7 @@ extern "C" int mp_mlp_shade_rev(const MpNet* net, const void* wpack, const float
     hipStream_t st = (hipStream_t)stream;
     using L = Lds<2, PNB, PWAVES>;
     constexpr int TILE = 16 * PNB * PWAVES;
-    constexpr int LDS_G = RING_SLOTS * chunk_bytes(2) + BIAS_BYTES + 512 + PWAVES * 2 * 16 * PNB * 48 * 2;
+    constexpr int LDS_G = RING_SLOTS * chunk_bytes(0) + BIAS_BYTES + 512 + PWAVES * 2 * 16 * PNB * 48 * 2;
     static int once = set_lds(k_mlp_fwdsave<PNB, PWAVES>, L::total) + set_lds(k_mlp_grad<PNB, PWAVES>, LDS_G);
     (void)once;
     const NetDesc d = as_desc(net), gd = as_desc(gnet);

@@ -68,7 +68,7 @@ extern "C" int mp_pack_layer(const float* v, const float* g, const float* b, int
                              const int* rowmap, int n_rows, const int* colmap, const float* colscale, int ks_in,
                              int hoist_col0, int hoist_n, const float* hoist_vec, float bias_scale,
                              void* wpack_layer, float* bias_layer, void* stream) {
-    if (n_rows <= 0 || n_rows % 32 || n_rows > MP_BIAS_STRIDE || (ks_in != 2 && ks_in != 3)) return -1;
+    if (n_rows <= 0 || n_rows % 32 || n_rows > MP_BIAS_STRIDE || (ks_in != 0 && ks_in != 2 && ks_in != 3)) return -1;
     hipStream_t st = (hipStream_t)stream;
     if (bias_layer && n_rows < MP_BIAS_STRIDE)
         hipLaunchKernelGGL(k_zero_f, dim3(1), dim3(MP_BIAS_STRIDE), 0, st, bias_layer + n_rows, MP_BIAS_STRIDE - n_rows);

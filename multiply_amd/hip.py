@@ -394,7 +394,7 @@ class GradNet:
 
     def __init__(self, imp):
         self.imp = imp
-        self.pk = packed(imp, "grad", 2)
+        self.pk = packed(imp, "grad", 0)      # no input-fed K steps in the reverse sweep
         self.w8 = None
         self.version = None
 
