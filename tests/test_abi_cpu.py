@@ -64,6 +64,33 @@ def test_layer_plans_cover_every_weight_exactly_once():
             assert rows == list(range(out_dim))
 
 
+def test_reverse_sweep_plans_transpose_every_hidden_layer():
+    """implicit_grad_plans: layers 7..1 transposed (rows = the layer's inputs, K slots = its outputs, each exactly once),
+    then the Fourier-feature part of layer 0; sigmoid / capture wiring in MpLayer.aux."""
+    from multiply_amd import hip
+    from tests.util import seeded_networks
+    m, _ = seeded_networks(1, 0)
+    net = m.foreground_implicit_network_list[0]
+    plans = hip.implicit_grad_plans(net)
+    lins = list(net.layers())
+    assert [p.lin for p in plans] == [lins[l] for l in (7, 6, 5, 4, 3, 2, 1, 0)]
+    for p, l in zip(plans, (7, 6, 5, 4, 3, 2, 1, 0)):
+        w = p.lin.weight_v if hasattr(p.lin, "weight_v") else p.lin.weight
+        out_dim, in_dim = w.shape
+        assert p.transpose
+        cm = p.colmap(0)
+        assert sorted(c for c in cm if c >= 0) == list(range(out_dim)), "K slots = the layer's outputs, each once"
+        rows = [r for r in p.rowmap if r >= 0]
+        if l > 0:
+            assert rows == list(range(in_dim)) and p.act == hip.ACT_SIGMUL and (p.aux & 0xff) == l      # sigma'_{l-1}
+            assert (p.aux >> 8) == (2 if l == 4 else 0)
+        else:
+            assert rows == list(range(net.embed_dim)) and p.act == hip.ACT_NONE and (p.aux >> 8) == 1
+    # the skip layer's transpose scales its rows like the forward plan scales the matching input columns
+    rs = plans[3].row_scale
+    assert len(rs) == 256 and np.allclose(rs[:217], 2 ** -0.5) and np.allclose(rs[217:], 2 ** -0.5 * hip.SOFTPLUS_K)
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from multiply_amd import hip
     monkeypatch.setattr(hip, "_lib", None)
