@@ -7,7 +7,6 @@
 // Geometry: plain kernels run 8 waves x (2 column blocks of 16 points) = 2 waves per SIMD; the forward-mode kernel needs
 // value and its three tangents in one wave: 8 waves x 8 points in a half-block layout, also 2 waves per SIMD.
 #include <hip/hip_runtime.h>
-#include <stdlib.h>
 #include "../../include/multiply_hip.h"
 #include "mlp_core.hpp"
 
@@ -212,61 +211,6 @@ __global__ __launch_bounds__(512) void k_mlp_shade(const NetDesc net, const char
         const float gx = TS_INV * __shfl(out[0][0], (lane & 7) + 8), gz = TS_INV * __shfl(out[1][0], (lane & 7) + 8);
         if (lane < 8 && id >= 0) {
             const float gy = TS_INV * out[1][0];
-            const float* Ji = jinv + 9 * (size_t)id;
-            float n0 = gx * Ji[0] + gy * Ji[3] + gz * Ji[6];
-            float n1 = gx * Ji[1] + gy * Ji[4] + gz * Ji[7];
-            float n2 = gx * Ji[2] + gy * Ji[5] + gz * Ji[8];
-            float inv = 1.0f / fmaxf(sqrtf(n0 * n0 + n1 * n1 + n2 * n2), 1e-12f);  // F.normalize default eps
-            n0 *= inv; n1 *= inv; n2 *= inv;
-            inv = 1.0f / fmaxf(sqrtf(n0 * n0 + n1 * n1 + n2 * n2), 1e-6f);         // multiply.py:606
-            sdf_out[id] = out[0][0];
-            normal_out[3 * (size_t)id] = n0 * inv;
-            normal_out[3 * (size_t)id + 1] = n1 * inv;
-            normal_out[3 * (size_t)id + 2] = n2 * inv;
-        }
-    }
-}
-
-// Variant with the full-block tangent layout: 4 waves (ONE per SIMD), each 16 points x {value, d/dx, d/dy, d/dz} = 4
-// column blocks.  Per MFMA it needs half the LDS weight reads and about half the activation instructions of the
-// half-block kernel above, but a wave has to hide every latency by itself.  Selected with MP_SHADE_LAYOUT (hip.py).
-__global__ __launch_bounds__(256) void k_mlp_shade4(const NetDesc net, const char* __restrict__ wpack,
-                                                    const float* __restrict__ bias, const float* __restrict__ xc,
-                                                    const float* __restrict__ jinv, const int* __restrict__ worklist,
-                                                    const int* __restrict__ count_p, int max_count,
-                                                    float* __restrict__ sdf_out, float* __restrict__ normal_out,
-                                                    char* __restrict__ feat_frag) {
-    constexpr int KS_IN = 2, NB = 4, WAVES = 4;
-    using L = Lds<KS_IN, NB, WAVES>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int count = count_p ? min(*count_p, max_count) : max_count;
-    float* bias_lds = (float*)(smem + L::bias0);
-    op_t* stage = (op_t*)(smem + L::stage) + wave * L::PTS * in_stride(KS_IN);
-    load_bias(net, bias, bias_lds);
-    for (int t = blockIdx.x; t * 64 < count; t += gridDim.x) {
-        // staging: lane l builds column l: block (role) l>>4, point l&15
-        const int pt = lane & 15, role = lane >> 4;
-        const int w = t * 64 + wave * 16 + pt;
-        const int id = w < count ? (worklist ? worklist[w] : w) : -1;   // every lane knows the id of point lane&15
-        {
-            float x[3] = {0.f, 0.f, 0.f};
-            if (id >= 0) { x[0] = xc[3 * (size_t)id]; x[1] = xc[3 * (size_t)id + 1]; x[2] = xc[3 * (size_t)id + 2]; }
-            op_t* row = stage + lane * in_stride(KS_IN);
-            if (role == 0) stage_pe<3, 6, KS_IN>(row, x);
-            else stage_pe_tangent<6, KS_IN>(row, x, role - 1);
-        }
-        opx8 Bcur[KS_REG][NB];
-        f32x4 out[NB];
-        zero_b<NB>(Bcur);
-        prologue<KS_IN, WAVES>(net, wpack, smem + L::ring, wave, lane);
-        run_net<NB, true, KS_IN, HID_SOFTPLUS, WAVES>(net, wpack, bias_lds, smem + L::ring, Bcur, stage, out, wave, lane);
-#pragma unroll
-        for (int ks = 0; ks < KS_REG; ++ks)   // features of point lane&15: block = wave of the 64-item tile
-            *(opx8*)(feat_frag + (((size_t)t * KS_REG + ks) * 4 + wave) * 1024 + lane * 16) = Bcur[ks][0];
-        if (lane < 16 && id >= 0) {   // row 0 of the last layer: sdf (block 0) and its three derivatives (blocks 1..3)
-            constexpr float TS_INV = 1.0f / TANGENT_SCALE;
-            const float gx = TS_INV * out[1][0], gy = TS_INV * out[2][0], gz = TS_INV * out[3][0];
             const float* Ji = jinv + 9 * (size_t)id;
             float n0 = gx * Ji[0] + gy * Ji[3] + gz * Ji[6];
             float n1 = gx * Ji[1] + gy * Ji[4] + gz * Ji[7];
@@ -702,16 +646,6 @@ extern "C" int mp_mlp_shade(const MpNet* net, const void* wpack, const float* bi
     if (max_count <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const NetDesc d = as_desc(net);
-    static const int layout = [] { const char* e = getenv("MP_SHADE_LAYOUT"); return e ? atoi(e) : 2; }();
-    if (layout == 4) {
-        using L4 = Lds<2, 4, 4>;
-        static int once4 = set_lds(k_mlp_shade4, L4::total);
-        (void)once4;
-        hipLaunchKernelGGL(k_mlp_shade4, dim3(grid_for((max_count + 63) / 64, 1)), dim3(256), L4::total, st, d,
-                           (const char*)wpack, bias, xc, jinv, worklist, count, max_count, sdf_out, normal_out,
-                           (char*)feat_frag);
-        return (int)hipGetLastError();
-    }
     using L = Lds<2, 2, 8>;
     static int once = set_lds(k_mlp_shade, L::total);
     (void)once;

@@ -23,8 +23,10 @@
 // = 2 waves per SIMD, so that one wave's activation VALU work overlaps the other wave's MFMAs).
 // Forward mode (FWD): value and d/dx, d/dy, d/dz tangent columns of the same points ride through the network together,
 // t' = softplus'(z) * (W t), so sdf and its spatial gradient (the normals of multiply.py:620-661) come out of one pass.
-// Default layout (NB = 2): 8 points per wave in half blocks, block 0 = [values | d/dx], block 1 = [d/dy | d/dz];
-// alternative (NB = 4, one wave per SIMD, MP_SHADE_LAYOUT=4): 16 points, one block per role.
+// Layout: 8 points per wave in half blocks, block 0 = [values | d/dx], block 1 = [d/dy | d/dz].  (A 4-block layout, 16
+// points per wave at one wave per SIMD, needs half the LDS reads and activation instructions per MFMA but was slower:
+// 26.5 vs 24.0 ms per 4 M points -- a single wave cannot hide the latencies.)  The default shading path is reverse mode
+// (mlp.hip: k_mlp_fwdsave + k_mlp_grad), which needs no tangent columns at all.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -213,32 +215,8 @@ __device__ __forceinline__ h2 row_shr8(h2 s) {
 template <int NB, bool FWD, int HID, int q, typename NB_T>
 __device__ __forceinline__ void act_piece(f32x4 (&p)[NB], bool hidden, NB_T& Bn, int pc, int ph, u32x4 (&sg)[NB],
                                           const SigIO& sig, int sig_layer) {
-    static_assert(NB == 2 || (NB == 4 && FWD), "2 column blocks per wave (2 waves per SIMD), or the 4-block forward layout");
-    if constexpr (FWD && NB == 4) {
-        // full-block tangent layout (16 points per wave, one wave per SIMD): block 0 = values, blocks 1..3 = d/dx, d/dy,
-        // d/dz of the same 16 points -> the sigmoid a tangent needs sits in its own lane (no DPP, no select), every
-        // lane's transcendental work is useful, and an A tile feeds 4 MFMAs instead of 2.
-        if constexpr (q < 2) {
-            h2 z = to_h2(p[0][2 * q], p[0][2 * q + 1]);
-            h2 t1 = to_h2(p[1][2 * q], p[1][2 * q + 1]);
-            h2 t2 = to_h2(p[2][2 * q], p[2][2 * q + 1]);
-            h2 t3 = to_h2(p[3][2 * q], p[3][2 * q + 1]);
-            if (hidden) {
-                const h2 h = softplus2(z);
-                const h2 sg = exp2_h2(z - h);
-                z = h;
-                t1 = t1 * sg;
-                t2 = t2 * sg;
-                t3 = t3 * sg;
-            }
-            if (pc < KS_REG) {
-                Bn.put(pc, 0, ph, q, z);
-                Bn.put(pc, 1, ph, q, t1);
-                Bn.put(pc, 2, ph, q, t2);
-                Bn.put(pc, 3, ph, q, t3);
-            }
-        }
-    } else if constexpr (FWD) {
+    static_assert(NB == 2, "the MLP core is specialised for 2 column blocks per wave (2 waves per SIMD)");
+    if constexpr (FWD) {
         if constexpr (q < 2) {
             h2 z = to_h2(p[0][2 * q], p[0][2 * q + 1]);
             h2 t = to_h2(p[1][2 * q], p[1][2 * q + 1]);
@@ -321,7 +299,7 @@ __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restri
     u32x4 sgb[2][NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) sgb[0][nb] = sgb[1][nb] = (u32x4){0u, 0u, 0u, 0u};
-    NextB<NB, (NB > 2)> Bn;   // 4 blocks: the operand under construction lives in the accumulator file
+    NextB<NB, false> Bn;
     Bn.zero();
     constexpr int PF = 3, QN = 4;   // prefetch distance / queue length in A tiles
     opx8 aq[QN];
@@ -360,7 +338,7 @@ __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restri
                     const f32x4 bv = *(const f32x4*)(bl + c * 32 + mbl * 16 + g * 4);
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) acc[nb] = (FWD && nb > 0) ? (f32x4){0, 0, 0, 0} : bv;
-                    if constexpr (FWD && NB == 2) {  // half-block layout: only the value half of block 0 carries the bias
+                    if constexpr (FWD) {  // half-block layout: only the value half of block 0 carries the bias
                         if (threadIdx.x & 8) acc[0] = (f32x4){0, 0, 0, 0};
                     }
                     const char* tile = slot + mbl * mb_bytes(KS_IN);
