@@ -235,14 +235,15 @@ int mp_tr_softplus_bwd(const float* Z, int ldz, int rows, int C, int P, float sc
                        float* dZ, int lddz, void* stream);
 int mp_tr_relu_bwd(const float* H, int ldh, int rows, int C, const float* dH, int lddh, float* dZ, int lddz, void* stream);
 /* last ImplicitNet layer Z8 [4P][257] -> sdf, normals (multiply.py:606,661) and the colour-net input XA [n][6] = [x_c, n];
- * the adjoint writes column 0 of a zero-initialised dZ8 (d sdf on value rows, d grad on tangent rows) */
+ * the adjoint writes column 0 of a zero-initialised dZ8 (d sdf on value rows, d grad on tangent rows).
+ * grad / dgrad (optional, [P][3]): d sdf / d x given separately instead of as tangent rows (reverse-over-reverse net) */
 int mp_tr_shade_in_fwd(const float* Z8, int P, int n_pts, const float* xc, const float* jinv, float* XR, float* nrm,
-                       float* sdf, void* stream);
+                       float* sdf, const float* grad, void* stream);
 int mp_tr_shade_in_bwd(const float* Z8, int P, int n_pts, const float* jinv, const float* dXR, const float* dsdf,
-                       const float* dnrm_extra, float* dZ8, float* djinv, void* stream);
+                       const float* dnrm_extra, float* dZ8, float* djinv, const float* grad, float* dgrad, void* stream);
 /* eikonal samples (multiply.py:322-331): grad_theta [E][3] = d sdf/dx of points e0..e0+E of the batch */
-int mp_tr_eik_fwd(const float* Z8, int P, int e0, int E, float* grad_theta, void* stream);
-int mp_tr_eik_bwd(int P, int e0, int E, const float* dgrad, float* dZ8, void* stream);
+int mp_tr_eik_fwd(const float* Z8, int P, int e0, int E, float* grad_theta, const float* grad, void* stream);
+int mp_tr_eik_bwd(int P, int e0, int E, const float* dgrad_theta, float* dZ8, float* dgrad, void* stream);
 int mp_tr_sigmoid_fwd(const float* Z, long long n, float* Y, void* stream);
 int mp_tr_sigmoid_bwd(const float* Y, const float* dY, long long n, float* dZ, void* stream);
 /* weight norm w = g v/|v| (networks.py:82-83): W [out][in] and its transpose WT [in][out]; adjoint dW -> dv, dg */
@@ -277,6 +278,17 @@ int mp_tr_warp_bwd(const float* xc, const float* dxc, const float* jinv, const f
                    const int* nn_cano, int n, const float* skin_w, const float* tfs, float* dtfs, void* stream);
 int mp_smpl_pose_bwd(const int* parents, const float* params, const float* tfs_c_inv, const float* rest_joints,
                      const float* j_shapedirs, const float* dtfs, float* dparams, void* stream);
+/* reverse-over-reverse SDF net (train.py ImplicitTrainRev): V = sigma'(Z) (.) U (U NULL: the row vector wrow) ;
+ * its adjoint (dU, d sigma') ; dZ = sigma' dX scale + sigma'' dS ; Fourier-feature Jacobian products (3-D points). */
+int mp_tr_sigmul(const float* Z, int ldz, long long rows, int C, const float* U, int ldu, const float* wrow, float scale,
+                 float* V, int ldv, void* stream);
+int mp_tr_rev_adj(const float* Z, int ldz, long long rows, int C, const float* U, int ldu, const float* wrow, float uscale,
+                  const float* dV, int lddv, float* dU, int lddu, float* dS, int ldds, void* stream);
+int mp_tr_dz(const float* Z, int ldz, long long rows, int C, const float* dX, int lddx, float scale, const float* dS, int ldds,
+             float* dZ, int lddz, void* stream);
+int mp_tr_pe_grad_fwd(const float* x, int P, int L, const float* G, int ldg, float* grad, void* stream);
+int mp_tr_pe_grad_bwd(const float* x, int P, int L, const float* dgrad, const float* G, int ldg, float* dG, int lddg,
+                      float* dx, void* stream);
 int mp_tr_copy_cols(const float* src, int lds, int c0s, float* dst, int ldd, int c0d, long long rows, int C, float scale,
                     int accumulate, void* stream);
 

@@ -109,11 +109,14 @@ __global__ void k_relu_bwd(const float* __restrict__ H, int ldh, long long n, in
 // n = normalize(normalize(g . Jinv), eps 1e-6)   (multiply.py:606, 661)
 __global__ void k_shade_in_fwd(const float* __restrict__ Z8, int P, int n_pts, const float* __restrict__ xc,
                                const float* __restrict__ jinv, float* __restrict__ XR, float* __restrict__ nrm_out,
-                               float* __restrict__ sdf_out) {
+                               float* __restrict__ sdf_out, const float* __restrict__ grad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pts) return;
     const int ld = 257;
-    const float g[3] = {Z8[(size_t)(P + i) * ld], Z8[(size_t)(2 * P + i) * ld], Z8[(size_t)(3 * P + i) * ld]};
+    // d sdf / d x: the tangent rows of a forward-mode batch, or a separate [P][3] array (reverse-over-reverse net)
+    const float g[3] = {grad ? grad[3 * (size_t)i] : Z8[(size_t)(P + i) * ld],
+                        grad ? grad[3 * (size_t)i + 1] : Z8[(size_t)(2 * P + i) * ld],
+                        grad ? grad[3 * (size_t)i + 2] : Z8[(size_t)(3 * P + i) * ld]};
     const float* J = jinv + 9 * (size_t)i;
     float v[3];
     for (int j = 0; j < 3; ++j) v[j] = g[0] * J[j] + g[1] * J[3 + j] + g[2] * J[6 + j];
@@ -135,11 +138,13 @@ __global__ void k_shade_in_fwd(const float* __restrict__ Z8, int P, int n_pts, c
 __global__ void k_shade_in_bwd(const float* __restrict__ Z8, int P, int n_pts, const float* __restrict__ jinv,
                                const float* __restrict__ dXR, const float* __restrict__ dsdf,
                                const float* __restrict__ dnrm_extra, float* __restrict__ dZ8,
-                               float* __restrict__ djinv) {
+                               float* __restrict__ djinv, const float* __restrict__ grad, float* __restrict__ dgrad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pts) return;
     const int ld = 257;
-    const float g[3] = {Z8[(size_t)(P + i) * ld], Z8[(size_t)(2 * P + i) * ld], Z8[(size_t)(3 * P + i) * ld]};
+    const float g[3] = {grad ? grad[3 * (size_t)i] : Z8[(size_t)(P + i) * ld],
+                        grad ? grad[3 * (size_t)i + 1] : Z8[(size_t)(2 * P + i) * ld],
+                        grad ? grad[3 * (size_t)i + 2] : Z8[(size_t)(3 * P + i) * ld]};
     const float* J = jinv + 9 * (size_t)i;
     float v[3];
     for (int j = 0; j < 3; ++j) v[j] = g[0] * J[j] + g[1] * J[3 + j] + g[2] * J[6 + j];
@@ -163,8 +168,11 @@ __global__ void k_shade_in_bwd(const float* __restrict__ Z8, int P, int n_pts, c
         const float dot = dn1[0] * n1[0] + dn1[1] * n1[1] + dn1[2] * n1[2];
         for (int j = 0; j < 3; ++j) dv[j] = na > 1e-12f ? (dn1[j] - n1[j] * dot) / a : dn1[j] / a;
     }
-    for (int k = 0; k < 3; ++k)
-        dZ8[(size_t)((k + 1) * P + i) * ld] = dv[0] * J[3 * k] + dv[1] * J[3 * k + 1] + dv[2] * J[3 * k + 2];
+    for (int k = 0; k < 3; ++k) {
+        const float dg = dv[0] * J[3 * k] + dv[1] * J[3 * k + 1] + dv[2] * J[3 * k + 2];
+        if (dgrad) dgrad[3 * (size_t)i + k] = dg;
+        else dZ8[(size_t)((k + 1) * P + i) * ld] = dg;
+    }
     dZ8[(size_t)i * ld] = dsdf[i];
     if (djinv)   // v_j = sum_k g_k Jinv[k][j]
         for (int k = 0; k < 3; ++k)
@@ -172,15 +180,21 @@ __global__ void k_shade_in_bwd(const float* __restrict__ Z8, int P, int n_pts, c
 }
 
 // eikonal points: grad_theta [E][3] = d sdf / d x (raw); rows offset e0 inside the batch of P points
-__global__ void k_eik_fwd(const float* __restrict__ Z8, int P, int e0, int E, float* __restrict__ grad_theta) {
+__global__ void k_eik_fwd(const float* __restrict__ Z8, int P, int e0, int E, float* __restrict__ grad_theta,
+                          const float* __restrict__ grad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= E) return;
-    for (int k = 0; k < 3; ++k) grad_theta[3 * (size_t)i + k] = Z8[(size_t)((k + 1) * P + e0 + i) * 257];
+    for (int k = 0; k < 3; ++k)
+        grad_theta[3 * (size_t)i + k] = grad ? grad[3 * (size_t)(e0 + i) + k] : Z8[(size_t)((k + 1) * P + e0 + i) * 257];
 }
-__global__ void k_eik_bwd(int P, int e0, int E, const float* __restrict__ dgrad, float* __restrict__ dZ8) {
+__global__ void k_eik_bwd(int P, int e0, int E, const float* __restrict__ dgrad_theta, float* __restrict__ dZ8,
+                          float* __restrict__ dgrad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= E) return;
-    for (int k = 1; k <= 3; ++k) dZ8[(size_t)(k * P + e0 + i) * 257] = dgrad[3 * (size_t)i + k - 1];
+    for (int k = 1; k <= 3; ++k) {
+        if (dgrad) dgrad[3 * (size_t)(e0 + i) + k - 1] = dgrad_theta[3 * (size_t)i + k - 1];
+        else dZ8[(size_t)(k * P + e0 + i) * 257] = dgrad_theta[3 * (size_t)i + k - 1];
+    }
 }
 
 __global__ void k_sigmoid_fwd(const float* __restrict__ Z, long long n, float* __restrict__ Y) {
@@ -679,6 +693,86 @@ __global__ void k_smpl_pose_bwd(const int* __restrict__ parents, const float* __
         }
 }
 
+
+// ---- reverse-over-reverse SDF net (multiply_amd/train.py ImplicitTrainRev): the spatial gradient of the sdf comes from a
+// reverse sweep V_l = sigma'(Z_l) (.) U_l, U_{l-1} = V_l W_l, and the training backward is the adjoint of BOTH sweeps:
+// 6 GEMMs per layer over P rows instead of 3 GEMMs over the 4P rows of the forward-mode formulation.
+//   sigmul    : V = sigma'(Z) (.) U * scale            (U == NULL: U = wrow broadcast over the rows)
+//   rev_adj   : dU = sigma'(Z) (.) dV ;  dS = U (.) dV   (adjoint of sigmul w.r.t. U and w.r.t. sigma')
+//   dz        : dZ = sigma'(Z) (.) dX * scale + sigma''(Z) (.) dS
+__global__ void k_sigmul(const float* __restrict__ Z, int ldz, long long rows, int C, const float* __restrict__ U, int ldu,
+                         const float* __restrict__ wrow, float scale, float* __restrict__ V, int ldv) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * C) return;
+    const size_t r = idx / C;
+    const int c = (int)(idx % C);
+    float h, d1, d2;
+    softplus_d012(Z[r * ldz + c], h, d1, d2);
+    V[r * ldv + c] = d1 * (U ? U[r * ldu + c] : wrow[c]) * scale;
+}
+__global__ void k_rev_adj(const float* __restrict__ Z, int ldz, long long rows, int C, const float* __restrict__ U, int ldu,
+                          const float* __restrict__ wrow, float uscale, const float* __restrict__ dV, int lddv,
+                          float* __restrict__ dU, int lddu, float* __restrict__ dS, int ldds) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * C) return;
+    const size_t r = idx / C;
+    const int c = (int)(idx % C);
+    float h, d1, d2;
+    softplus_d012(Z[r * ldz + c], h, d1, d2);
+    const float dv = dV[r * lddv + c];
+    dU[r * lddu + c] = d1 * dv;
+    dS[r * ldds + c] = (U ? U[r * ldu + c] : wrow[c]) * uscale * dv;
+}
+__global__ void k_dz(const float* __restrict__ Z, int ldz, long long rows, int C, const float* __restrict__ dX, int lddx,
+                     float scale, const float* __restrict__ dS, int ldds, float* __restrict__ dZ, int lddz) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * C) return;
+    const size_t r = idx / C;
+    const int c = (int)(idx % C);
+    float h, d1, d2;
+    softplus_d012(Z[r * ldz + c], h, d1, d2);
+    dZ[r * lddz + c] = d1 * dX[r * lddx + c] * scale + d2 * dS[r * ldds + c];
+}
+// Fourier-feature Jacobian (3-D points, L octaves; embedders.py layout): grad[a] = sum_f G[f] dPE_f/dx_a ;
+// adjoint: dG[f] = dgrad[a(f)] dPE_f/dx_a ; dx[a] += sum_f G[f] dgrad[a] d2PE_f/dx_a^2   (optional)
+__global__ void k_pe_grad_fwd(const float* __restrict__ x, int P, int L, const float* __restrict__ G, int ldg,
+                              float* __restrict__ grad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float* g = G + (size_t)i * ldg;
+    for (int a = 0; a < 3; ++a) {
+        const float xa = x[3 * (size_t)i + a];
+        float acc = g[a];
+        for (int k = 0; k < L; ++k) {
+            const float f = (float)(1 << k);
+            float sn, cs;
+            sincosf(xa * f, &sn, &cs);
+            acc += f * (cs * g[3 + 6 * k + a] - sn * g[3 + 6 * k + 3 + a]);
+        }
+        grad[3 * (size_t)i + a] = acc;
+    }
+}
+__global__ void k_pe_grad_bwd(const float* __restrict__ x, int P, int L, const float* __restrict__ dgrad,
+                              const float* __restrict__ G, int ldg, float* __restrict__ dG, int lddg, float* __restrict__ dx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float* dg = dG + (size_t)i * lddg;
+    for (int a = 0; a < 3; ++a) {
+        const float xa = x[3 * (size_t)i + a], da = dgrad[3 * (size_t)i + a];
+        dg[a] = da;
+        float acc = 0.f;
+        for (int k = 0; k < L; ++k) {
+            const float f = (float)(1 << k);
+            float sn, cs;
+            sincosf(xa * f, &sn, &cs);
+            dg[3 + 6 * k + a] = da * f * cs;
+            dg[3 + 6 * k + 3 + a] = -da * f * sn;
+            if (dx) acc -= da * f * f * (sn * G[(size_t)i * ldg + 3 + 6 * k + a] + cs * G[(size_t)i * ldg + 3 + 6 * k + 3 + a]);
+        }
+        if (dx) dx[3 * (size_t)i + a] += acc;
+    }
+}
+
 }  // namespace
 
 #define ST (hipStream_t) stream
@@ -709,25 +803,26 @@ int mp_tr_relu_bwd(const float* H, int ldh, int rows, int C, const float* dH, in
     return (int)hipGetLastError();
 }
 int mp_tr_shade_in_fwd(const float* Z8, int P, int n_pts, const float* xc, const float* jinv, float* XR, float* nrm,
-                       float* sdf, void* stream) {
+                       float* sdf, const float* grad, void* stream) {
     if (n_pts <= 0) return 0;
-    hipLaunchKernelGGL(k_shade_in_fwd, grid1(n_pts), dim3(TB), 0, ST, Z8, P, n_pts, xc, jinv, XR, nrm, sdf);
+    hipLaunchKernelGGL(k_shade_in_fwd, grid1(n_pts), dim3(TB), 0, ST, Z8, P, n_pts, xc, jinv, XR, nrm, sdf, grad);
     return (int)hipGetLastError();
 }
 int mp_tr_shade_in_bwd(const float* Z8, int P, int n_pts, const float* jinv, const float* dXR, const float* dsdf,
-                       const float* dnrm_extra, float* dZ8, float* djinv, void* stream) {
+                       const float* dnrm_extra, float* dZ8, float* djinv, const float* grad, float* dgrad, void* stream) {
     if (n_pts <= 0) return 0;
-    hipLaunchKernelGGL(k_shade_in_bwd, grid1(n_pts), dim3(TB), 0, ST, Z8, P, n_pts, jinv, dXR, dsdf, dnrm_extra, dZ8, djinv);
+    hipLaunchKernelGGL(k_shade_in_bwd, grid1(n_pts), dim3(TB), 0, ST, Z8, P, n_pts, jinv, dXR, dsdf, dnrm_extra, dZ8, djinv,
+                       grad, dgrad);
     return (int)hipGetLastError();
 }
-int mp_tr_eik_fwd(const float* Z8, int P, int e0, int E, float* grad_theta, void* stream) {
+int mp_tr_eik_fwd(const float* Z8, int P, int e0, int E, float* grad_theta, const float* grad, void* stream) {
     if (E <= 0) return 0;
-    hipLaunchKernelGGL(k_eik_fwd, grid1(E), dim3(TB), 0, ST, Z8, P, e0, E, grad_theta);
+    hipLaunchKernelGGL(k_eik_fwd, grid1(E), dim3(TB), 0, ST, Z8, P, e0, E, grad_theta, grad);
     return (int)hipGetLastError();
 }
-int mp_tr_eik_bwd(int P, int e0, int E, const float* dgrad, float* dZ8, void* stream) {
+int mp_tr_eik_bwd(int P, int e0, int E, const float* dgrad_theta, float* dZ8, float* dgrad, void* stream) {
     if (E <= 0) return 0;
-    hipLaunchKernelGGL(k_eik_bwd, grid1(E), dim3(TB), 0, ST, P, e0, E, dgrad, dZ8);
+    hipLaunchKernelGGL(k_eik_bwd, grid1(E), dim3(TB), 0, ST, P, e0, E, dgrad_theta, dZ8, dgrad);
     return (int)hipGetLastError();
 }
 int mp_tr_sigmoid_fwd(const float* Z, long long n, float* Y, void* stream) {
@@ -801,6 +896,33 @@ int mp_smpl_pose_bwd(const int* parents, const float* params, const float* tfs_c
                      const float* j_shapedirs, const float* dtfs, float* dparams, void* stream) {
     hipLaunchKernelGGL(k_smpl_pose_bwd, dim3(1), dim3(64), 0, ST, parents, params, tfs_c_inv, rest_joints, j_shapedirs, dtfs,
                        dparams);
+    return (int)hipGetLastError();
+}
+int mp_tr_sigmul(const float* Z, int ldz, long long rows, int C, const float* U, int ldu, const float* wrow, float scale,
+                 float* V, int ldv, void* stream) {
+    hipLaunchKernelGGL(k_sigmul, grid1(rows * C), dim3(TB), 0, ST, Z, ldz, rows, C, U, ldu, wrow, scale, V, ldv);
+    return (int)hipGetLastError();
+}
+int mp_tr_rev_adj(const float* Z, int ldz, long long rows, int C, const float* U, int ldu, const float* wrow, float uscale,
+                  const float* dV, int lddv, float* dU, int lddu, float* dS, int ldds, void* stream) {
+    hipLaunchKernelGGL(k_rev_adj, grid1(rows * C), dim3(TB), 0, ST, Z, ldz, rows, C, U, ldu, wrow, uscale, dV, lddv, dU, lddu, dS,
+                       ldds);
+    return (int)hipGetLastError();
+}
+int mp_tr_dz(const float* Z, int ldz, long long rows, int C, const float* dX, int lddx, float scale, const float* dS, int ldds,
+             float* dZ, int lddz, void* stream) {
+    hipLaunchKernelGGL(k_dz, grid1(rows * C), dim3(TB), 0, ST, Z, ldz, rows, C, dX, lddx, scale, dS, ldds, dZ, lddz);
+    return (int)hipGetLastError();
+}
+int mp_tr_pe_grad_fwd(const float* x, int P, int L, const float* G, int ldg, float* grad, void* stream) {
+    if (P <= 0) return 0;
+    hipLaunchKernelGGL(k_pe_grad_fwd, grid1(P), dim3(TB), 0, ST, x, P, L, G, ldg, grad);
+    return (int)hipGetLastError();
+}
+int mp_tr_pe_grad_bwd(const float* x, int P, int L, const float* dgrad, const float* G, int ldg, float* dG, int lddg,
+                      float* dx, void* stream) {
+    if (P <= 0) return 0;
+    hipLaunchKernelGGL(k_pe_grad_bwd, grid1(P), dim3(TB), 0, ST, x, P, L, dgrad, G, ldg, dG, lddg, dx);
     return (int)hipGetLastError();
 }
 int mp_tr_copy_cols(const float* src, int lds, int c0s, float* dst, int ldd, int c0d, long long rows, int C, float scale,

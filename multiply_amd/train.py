@@ -175,6 +175,161 @@ class ImplicitTrain:
         return [g for lw in self.lins for g in lw.param_grads()]
 
 
+class ImplicitTrainRev:
+    """Foreground ImplicitNet for P points with d sdf / d x by REVERSE-over-reverse differentiation:
+
+        forward   Z_l = X_l W_l^T + b_l,  X_{l+1} = softplus(Z_l)                       (value only, P rows)
+        sweep     V_7 = s_7 (.) W_8[sdf row];  U_{l-1} = V_l W_l;  V_{l-1} = s_{l-1} (.) U_{l-1};  grad = J_PE^T (V_0 W_0in + ...)
+        backward  the adjoint of BOTH sweeps (sigma'' enters through d s_l = U_l (.) dV_l)
+
+    = what torch autograd does for the reference (multiply.py:643-659 with create_graph=True): 6 GEMMs per layer over P
+    rows, where the forward-mode class above spends 3 GEMMs over 4P rows.  Same results, same parameter gradients.
+    self.out [P][257] = last layer, self.grad [P][3] = d sdf / d x."""
+
+    def __init__(self, net, x, cond_vec):
+        L = hip.lib()
+        st = hip.stream()
+        self.net, self.x, self.cond = net, x, cond_vec
+        dev = x.device
+        self.P = P = x.shape[0]
+        self.E = E = net.embed_dim
+        assert net.d_in == 3 and len(net.skip_in) == 1
+        self.lins = lins = [LinW(l) for l in net.layers()]
+        self.nl = nl = len(lins)
+        r2 = 1.0 / math.sqrt(2.0)
+        f32 = dict(dtype=F32, device=dev)
+        self.IN = torch.empty(P, E, **f32)
+        _chk(L.mp_tr_pe(_p(x), 3, P, net.multires, 0, C.c_float(1.0), _p(self.IN), E, 0, st), "mp_tr_pe")
+        # ---- value sweep
+        self.Z, self.X = [], []
+        for l, lw in enumerate(lins):
+            out = lw.out_dim
+            Z = torch.empty(P, out, **f32)
+            if l == 0:
+                self.b0 = torch.empty(out, **f32)
+                _chk(L.mp_tr_hoist_fwd(_p(lw.W), out, lw.in_dim, _p(lw.b), E, net.cond_dim, _p(cond_vec), _p(self.b0), st),
+                     "mp_tr_hoist_fwd")
+                Xl = self.IN
+                gemm_nt(_p(Xl), E, _p(lw.W), lw.in_dim, _p(Z), out, P, out, E, _p(self.b0), P)
+            else:
+                po = lins[l - 1].out_dim
+                if l in net.skip_in:
+                    Xl = torch.empty(P, po + E, **f32)
+                    _chk(L.mp_tr_softplus_fwd(_p(self.Z[l - 1]), po, P, po, 0, C.c_float(r2), _p(Xl), po + E, 0, st), "softplus")
+                    _chk(L.mp_tr_copy_cols(_p(self.IN), E, 0, _p(Xl), po + E, po, P, E, C.c_float(r2), 0, st), "copy_cols")
+                else:
+                    Xl = torch.empty(P, po, **f32)
+                    _chk(L.mp_tr_softplus_fwd(_p(self.Z[l - 1]), po, P, po, 0, C.c_float(1.0), _p(Xl), po, 0, st), "softplus")
+                gemm_nt(_p(Xl), Xl.shape[1], _p(lw.W), lw.in_dim, _p(Z), out, P, out, lw.in_dim, _p(lw.b), P)
+            self.Z.append(Z)
+            self.X.append(Xl)
+        self.out = self.Z[-1]
+        # ---- reverse sweep for d sdf / d x
+        nh = nl - 1                                   # hidden layers 0..nh-1
+        self.w8 = lins[nh].W[0].contiguous()          # sdf row of the last layer
+        self.V = [None] * nh
+        self.T = [None] * nh                          # T[l] = V_l W_l  (U_{l-1} = scale_l * T[l][:, :out_{l-1}])
+        self.V[nh - 1] = torch.empty(P, lins[nh - 1].out_dim, **f32)
+        _chk(L.mp_tr_sigmul(_p(self.Z[nh - 1]), lins[nh - 1].out_dim, P, lins[nh - 1].out_dim, None, 0, _p(self.w8),
+                            C.c_float(1.0), _p(self.V[nh - 1]), lins[nh - 1].out_dim, st), "mp_tr_sigmul")
+        self.Gpe = torch.zeros(P, E, **f32)
+        for l in range(nh - 1, 0, -1):
+            lw, po = lins[l], lins[l - 1].out_dim
+            T = torch.empty(P, lw.in_dim, **f32)
+            gemm_nt(_p(self.V[l]), lw.out_dim, _p(lw.WT), lw.out_dim, _p(T), lw.in_dim, P, lw.in_dim, lw.out_dim)
+            sc = r2 if l in net.skip_in else 1.0
+            if l in net.skip_in:
+                _chk(L.mp_tr_copy_cols(_p(T), lw.in_dim, po, _p(self.Gpe), E, 0, P, E, C.c_float(r2), 1, st), "copy_cols")
+            self.T[l] = T
+            self.V[l - 1] = torch.empty(P, po, **f32)
+            _chk(L.mp_tr_sigmul(_p(self.Z[l - 1]), po, P, po, _p(T), lw.in_dim, None, C.c_float(sc), _p(self.V[l - 1]), po, st),
+                 "mp_tr_sigmul")
+        lw0 = lins[0]
+        gemm_nt(_p(self.V[0]), lw0.out_dim, _p(lw0.WT), lw0.out_dim, _p(self.Gpe), E, P, E, lw0.out_dim, accumulate=True)
+        self.grad = torch.empty(P, 3, **f32)
+        _chk(L.mp_tr_pe_grad_fwd(_p(x), P, net.multires, _p(self.Gpe), E, _p(self.grad), st), "mp_tr_pe_grad_fwd")
+
+    def backward(self, dZ_last, dgrad, want_dx=False):
+        """dZ_last [P][257], dgrad [P][3] -> dW/db of every layer; returns d cond; want_dx: self.dx [P][3]"""
+        L = hip.lib()
+        st = hip.stream()
+        net, P, E, lins = self.net, self.P, self.E, self.lins
+        nh = self.nl - 1
+        dev = dZ_last.device
+        f32 = dict(dtype=F32, device=dev)
+        r2 = 1.0 / math.sqrt(2.0)
+        # ---- adjoint of the reverse sweep (ascending l)
+        dGpe = torch.empty(P, E, **f32)
+        self.dx = torch.zeros(P, 3, **f32) if want_dx else None
+        _chk(L.mp_tr_pe_grad_bwd(_p(self.x), P, net.multires, _p(dgrad), _p(self.Gpe), E, _p(dGpe), E, _p(self.dx), st),
+             "mp_tr_pe_grad_bwd")
+        lw0 = lins[0]
+        dV = torch.empty(P, lw0.out_dim, **f32)
+        gemm_nt(_p(dGpe), E, _p(lw0.W), lw0.in_dim, _p(dV), lw0.out_dim, P, lw0.out_dim, E)
+        gemm_tn(_p(self.V[0]), lw0.out_dim, _p(dGpe), E, _p(lw0.dW), lw0.in_dim, lw0.out_dim, E, P)
+        dS = [None] * nh
+        for l in range(0, nh - 1):
+            lw1 = lins[l + 1]
+            out_l = lins[l].out_dim
+            sc = r2 if (l + 1) in net.skip_in else 1.0
+            dU = torch.empty(P, out_l, **f32)
+            dS[l] = torch.empty(P, out_l, **f32)
+            _chk(L.mp_tr_rev_adj(_p(self.Z[l]), out_l, P, out_l, _p(self.T[l + 1]), lw1.in_dim, None, C.c_float(sc), _p(dV), out_l,
+                                 _p(dU), out_l, _p(dS[l]), out_l, st), "mp_tr_rev_adj")
+            if (l + 1) in net.skip_in:
+                dT = torch.empty(P, lw1.in_dim, **f32)
+                _chk(L.mp_tr_copy_cols(_p(dU), out_l, 0, _p(dT), lw1.in_dim, 0, P, out_l, C.c_float(r2), 0, st), "copy_cols")
+                _chk(L.mp_tr_copy_cols(_p(dGpe), E, 0, _p(dT), lw1.in_dim, out_l, P, E, C.c_float(r2), 0, st), "copy_cols")
+            else:
+                dT = dU
+            dV = torch.empty(P, lw1.out_dim, **f32)
+            gemm_nt(_p(dT), lw1.in_dim, _p(lw1.W), lw1.in_dim, _p(dV), lw1.out_dim, P, lw1.out_dim, lw1.in_dim)
+            gemm_tn(_p(self.V[l + 1]), lw1.out_dim, _p(dT), lw1.in_dim, _p(lw1.dW), lw1.in_dim, lw1.out_dim, lw1.in_dim, P)
+        # top of the sweep: V_7 = s_7 (.) W_8[sdf row]
+        top = lins[nh - 1].out_dim
+        dU = torch.empty(P, top, **f32)
+        dS[nh - 1] = torch.empty(P, top, **f32)
+        _chk(L.mp_tr_rev_adj(_p(self.Z[nh - 1]), top, P, top, None, 0, _p(self.w8), C.c_float(1.0), _p(dV), top, _p(dU), top,
+                             _p(dS[nh - 1]), top, st), "mp_tr_rev_adj")
+        dw8 = torch.empty(top, **f32)
+        _chk(L.mp_tr_colsum(_p(dU), top, P, top, _p(dw8), st), "mp_tr_colsum")
+        lins[nh].dW[0] += dw8
+        # ---- adjoint of the value sweep (descending l)
+        dZ = dZ_last
+        dcond = None
+        dIN = torch.zeros(P, E, **f32) if want_dx else None
+        for l in range(nh, -1, -1):
+            lw, Xl = lins[l], self.X[l]
+            out = lw.out_dim
+            kin = E if l == 0 else lw.in_dim
+            gemm_tn(_p(dZ), out, _p(Xl), Xl.shape[1], _p(lw.dW), lw.in_dim, out, kin, P, _p(lw.db), P)
+            if l == 0:
+                _chk(L.mp_tr_hoist_bwd(_p(lw.db), out, lw.in_dim, E, net.cond_dim, _p(self.cond), _p(lw.dW), st), "mp_tr_hoist_bwd")
+                dcond = torch.zeros(net.cond_dim, **f32)
+                gemm_tn(_p(lw.db), 1, off(lw.W, E), lw.in_dim, _p(dcond), net.cond_dim, 1, net.cond_dim, out)
+                if want_dx:
+                    gemm_nt(_p(dZ), out, _p(lw.WT), out, _p(dIN), E, P, E, out, accumulate=True)
+                    _chk(L.mp_tr_pe_bwd(_p(self.x), 3, P, net.multires, 0, _p(dIN), E, _p(self.dx), st), "mp_tr_pe_bwd")
+                break
+            po = lins[l - 1].out_dim
+            dX = torch.empty(P, lw.in_dim, **f32)
+            gemm_nt(_p(dZ), out, _p(lw.WT), out, _p(dX), lw.in_dim, P, lw.in_dim, out)
+            sc = r2 if l in net.skip_in else 1.0
+            if want_dx and l in net.skip_in:
+                _chk(L.mp_tr_copy_cols(_p(dX), lw.in_dim, po, _p(dIN), E, 0, P, E, C.c_float(r2), 1, st), "copy_cols")
+            dZp = torch.empty(P, po, **f32)
+            _chk(L.mp_tr_dz(_p(self.Z[l - 1]), po, P, po, _p(dX), lw.in_dim, C.c_float(sc), _p(dS[l - 1]), po, _p(dZp), po, st),
+                 "mp_tr_dz")
+            dZ = dZp
+        return dcond
+
+    def params(self):
+        return [p for lw in self.lins for p in lw.params()]
+
+    def param_grads(self):
+        return [g for lw in self.lins for g in lw.param_grads()]
+
+
 class RenderTrain:
     """RenderingNet (networks.py:263-312): mode 'pose_no_view' (inputs XA = [x_c, n] (6), feat) or 'nerf_frame_encoding'
     (XA = PE_4(view) (27), feat).  feat is read in place from the SDF net's last layer (ld 257, column 1..)."""
@@ -266,6 +421,7 @@ class RenderTrain:
 # Training-mode Multiply.forward (multiply.py:174-588, `self.training` branches) as ONE autograd node
 # ======================================================================================================================
 N_EIKONAL = 512          # multiply.py:324
+SDF_TRAIN_MODE = __import__("os").environ.get("MP_SDF_TRAIN_MODE", "reverse")   # 'reverse' (ImplicitTrainRev) | 'forward' 
 
 
 def _table(ts, dev):
@@ -345,12 +501,14 @@ class TrainGraph:
             # eikonal points near the canonical surface (multiply.py:322-327, sampler.py:84-108 with global_ratio 0)
             vc = server.verts_c.reshape(-1, 3)
             X[npts:] = vc[dr["eik_idx"]] + dr["eik_noise"] * m.sampler.local_sigma
-            it = ImplicitTrain(imp, X, pp["cond"], fwd=True)
+            rev = SDF_TRAIN_MODE == "reverse"
+            it = ImplicitTrainRev(imp, X, pp["cond"]) if rev else ImplicitTrain(imp, X, pp["cond"], fwd=True)
+            gptr = _p(it.grad) if rev else None
             XA = torch.empty(npts, 6, **f32); nrm = torch.empty(npts, 3, **f32); sdf = torch.empty(npts, **f32)
-            _chk(L.mp_tr_shade_in_fwd(_p(it.out), Pt, npts, _p(X), _p(jinv), _p(XA), _p(nrm), _p(sdf), st),
+            _chk(L.mp_tr_shade_in_fwd(_p(it.out), Pt, npts, _p(X), _p(jinv), _p(XA), _p(nrm), _p(sdf), gptr, st),
                  "mp_tr_shade_in_fwd")
             gth = torch.empty(E, 3, **f32)
-            _chk(L.mp_tr_eik_fwd(_p(it.out), Pt, npts, E, _p(gth), st), "mp_tr_eik_fwd")
+            _chk(L.mp_tr_eik_fwd(_p(it.out), Pt, npts, E, _p(gth), gptr, st), "mp_tr_eik_fwd")
             rt = RenderTrain(ren, XA, off(it.out, 1), 257, npts, pp["cond"])
             self.fg[p] = dict(it=it, rt=rt, X=X, jinv=jinv, XA=XA, sdf=sdf, nrm=nrm, gth=gth, zfinal=zfinal, iters=iters,
                               wcount=wcount, npts=npts, Pt=Pt, Rp=Rp, flags=flags, nn_posed=nn_posed,
@@ -432,16 +590,18 @@ class TrainGraph:
         for n, p in enumerate(persons):
             f = self.fg[p]
             it, rt, npts, Pt = f["it"], f["rt"], f["npts"], f["Pt"]
-            dZ8 = torch.zeros(4 * Pt, 257, **f32)
+            rev = isinstance(it, ImplicitTrainRev)
+            dZ8 = torch.zeros(Pt if rev else 4 * Pt, 257, **f32)
+            dgrad = torch.zeros(Pt, 3, **f32) if rev else None
             dXA = torch.empty(npts, 6, **f32)
             rt.backward(drgb_l[n], dXA, off(dZ8, 1), 257)
             djinv = torch.empty(npts, 9, **f32) if self.pose_grad else None
             _chk(L.mp_tr_shade_in_bwd(_p(it.out), Pt, npts, _p(f["jinv"]), _p(dXA), _p(dsdf_l[n]), None, _p(dZ8),
-                                      _p(djinv), st), "mp_tr_shade_in_bwd")
+                                      _p(djinv), _p(it.grad) if rev else None, _p(dgrad), st), "mp_tr_shade_in_bwd")
             if d_grad_theta is not None:
                 dg = d_grad_theta.reshape(-1, 3)[n * N_EIKONAL:(n + 1) * N_EIKONAL].contiguous().float()
-                _chk(L.mp_tr_eik_bwd(Pt, npts, N_EIKONAL, _p(dg), _p(dZ8), st), "mp_tr_eik_bwd")
-            dcond = it.backward(dZ8, want_dx=self.pose_grad)
+                _chk(L.mp_tr_eik_bwd(Pt, npts, N_EIKONAL, _p(dg), _p(dZ8), _p(dgrad), st), "mp_tr_eik_bwd")
+            dcond = it.backward(dZ8, dgrad, want_dx=self.pose_grad) if rev else it.backward(dZ8, want_dx=self.pose_grad)
             collect(it); collect(rt)
             if self.pose_grad:
                 # x_c enters the SDF net (value + tangent rows) and the colour net (XA[:, :3]); the transforms also shape
