@@ -204,3 +204,17 @@ def test_canonical_pose_and_convergence_groups():
         d = (chunk["rgb_values"] - whole["rgb_values"][c0:c0 + n]).abs().max().item()
         print(f"[parity] chunk {c0}: max |whole - chunk| {d:.3e}")
         assert d < 1e-6
+
+
+def test_forward_mode_and_reverse_mode_shading_agree():
+    """Multiply.shade_mode: reverse (two sweeps) vs forward (tangent columns) renders of the same frame."""
+    model, oracle, inp = build(H=15, W=15)
+    gin = _gpu(inp)
+    a = model(gin)
+    model.shade_mode = "forward"
+    b = model(gin)
+    torch.cuda.synchronize()
+    for k, tol in (("rgb_values", 1e-4), ("acc_map", 1e-6), ("normal_values", 5e-3)):
+        d = (a[k] - b[k]).abs().max().item()
+        print(f"[parity] reverse vs forward shading, {k}: max {d:.3e}")
+        assert d < tol, k
