@@ -231,8 +231,8 @@ __global__ __launch_bounds__(512) void k_mlp_shade(const NetDesc net, const char
 // columns -- value and three tangents -- through the network):
 //   sweep 1  (k_mlp_fwdsave) plain forward pass (32 points per wave); sigmoid(100 z) of every hidden unit is written out,
 //            4 KiB per point (f16, operand-fragment layout), for a SEGMENT of the worklist at a time (bounded buffer).
-//            [One fused kernel doing both sweeps per tile out of a cache-resident 1 MiB block was tried and is slower:
-//            the two unrolled sweeps do not fit the instruction cache together.]
+//            [One fused kernel doing both sweeps per tile out of a cache-resident 1 MiB block was tried and is slower
+//            (96.7 vs 74.6 ms/frame).]
 //   sweep 2  (k_mlp_grad) reverse sweep through the TRANSPOSED layers (hip.py implicit_grad_plans):
 //            V_7 = sigma'_7 (.) W_8[sdf row];  V_{l-1} = sigma'_{l-1} (.) (W_l^T V_l);  the "activation" of the shared core is the
 //            multiplication by the stored sigmoid.  The rows of W_4^T and W_0^T that belong to the Fourier-feature inputs
@@ -241,6 +241,10 @@ __global__ __launch_bounds__(512) void k_mlp_shade(const NetDesc net, const char
 struct GradCapture {
     const op_t* tab_a;   // this wave's [32 points][48]: d PE_f / d x for the rows 0..47 of the last reverse layer (f = row)
     const op_t* tab_b;   // ... for rows 208..255 of the skip layer's transpose (f = row - 217, 0 where row < 217)
+    // Encoding feature f differentiates along axis f mod 3 (embedders.py layout: x, then per octave sin(3), cos(3)), and
+    // this lane's row of block bi, register r is f = 16 bi + 4 (lane >> 4) + r (- 9 in the skip layer), so its axis is
+    // (bi + r + (lane >> 4)) mod 3: accumulate by the COMPILE-TIME part k = (bi + r) mod 3 and undo the per-lane rotation
+    // once per tile (unrotate) -- no per-axis selects (their lane masks, hoisted, used to cost ~140 SGPRs).
     float (&g)[2][3];
     template <int NB>
     __device__ __forceinline__ void operator()(int cid, int bi, const f32x4 (&acc)[NB]) const {
@@ -251,13 +255,23 @@ struct GradCapture {
             const op_t* tp = tab + (16 * nb + j) * 48 + 16 * bi + 4 * gq;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int f = max(16 * bi + 4 * gq + r - (cid == 1 ? 0 : 9), 0);
-                const int axis = f < 3 ? f : ((f - 3) % 6) % 3;
                 const float v = acc[nb][r] * (float)tp[r];
-                g[nb][0] += axis == 0 ? v : 0.0f;
-                g[nb][1] += axis == 1 ? v : 0.0f;
-                g[nb][2] += axis == 2 ? v : 0.0f;
+                const int k = (bi + r) % 3;
+                g[nb][0] += k == 0 ? v : 0.0f;
+                g[nb][1] += k == 1 ? v : 0.0f;
+                g[nb][2] += k == 2 ? v : 0.0f;
             }
+        }
+    }
+    // rotated accumulator k holds axis (k + lane>>4) mod 3
+    static __device__ __forceinline__ void unrotate(float (&g)[2][3]) {
+        const int s = ((threadIdx.x & 63) >> 4) % 3;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const float a0 = g[nb][0], a1 = g[nb][1], a2 = g[nb][2];
+            g[nb][0] = s == 0 ? a0 : (s == 1 ? a2 : a1);
+            g[nb][1] = s == 0 ? a1 : (s == 1 ? a0 : a2);
+            g[nb][2] = s == 0 ? a2 : (s == 1 ? a1 : a0);
         }
     }
 };
@@ -295,7 +309,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_fwdsave(const NetDesc net, c
         f32x4 out[NB];
         zero_b<NB>(Bcur);
         prologue<KS_IN, WAVES>(net, wpack, smem + L::ring, wave, lane);
+        #ifdef MP_EXP_SIGCACHED   // ablation: every tile uses the first workgroup-slots of the buffer (cache resident)
+        const SigIO sio = {sigbuf + ((size_t)(blockIdx.x) * WAVES + wave) * (size_t)(8 * SIG_LAYER), SIG_LAYER};
+#else
         const SigIO sio = {sigbuf + ((size_t)t * WAVES + wave) * (size_t)(8 * SIG_LAYER), SIG_LAYER};
+#endif
         run_net<NB, false, KS_IN, HID_SOFTPLUS_SAVE, WAVES>(net, wpack, bias_lds, smem + L::ring, Bcur, stage, out, wave, lane,
                                                             sio);
         // features in the colour kernel's layout: tiles of 64 work items (offset is a multiple of 256), 4 blocks of 16 columns
@@ -325,10 +343,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_grad(const NetDesc net, cons
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, gq = lane >> 4;
     const int count = min(count_p ? min(*count_p, max_count) : max_count, offset + seg);
     if (offset >= count) return;
-    float* zero_bias = (float*)(smem + RING);                         // MAX_LAYERS * BIAS_STRIDE zeros (the sweep has no bias)
-    op_t* w8 = (op_t*)(smem + RING + BIAS_BYTES);                     // [256] sdf-row weights in K-slot order
+    op_t* w8 = (op_t*)(smem + RING);                                  // [256] sdf-row weights in K-slot order
     op_t* tabs = w8 + 256 + wave * (2 * PTS * 48);
-    for (int i = threadIdx.x; i < MAX_LAYERS * BIAS_STRIDE; i += blockDim.x) zero_bias[i] = 0.0f;
     for (int i = threadIdx.x; i < 256; i += blockDim.x) w8[i] = w8_slots[i];
     constexpr int SIG_LAYER = KS_REG * NB * 1024;
     for (int t = blockIdx.x; offset + t * TILE < count; t += gridDim.x) {
@@ -357,10 +373,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_grad(const NetDesc net, cons
 #pragma unroll
             for (int f = 0; f < 39; ++f) tb[9 + f] = ta[f];
         }
+        #ifdef MP_EXP_SIGCACHED
+        const SigIO sio = {const_cast<char*>(sigbuf) + ((size_t)(blockIdx.x) * WAVES + wave) * (size_t)(8 * SIG_LAYER), SIG_LAYER};
+#else
         const SigIO sio = {const_cast<char*>(sigbuf) + ((size_t)t * WAVES + wave) * (size_t)(8 * SIG_LAYER), SIG_LAYER};
+#endif
         // V_7 = sigma'_7 (.) W_8[sdf row]
         opx8 Bcur[KS_REG][NB];
-        __syncthreads();   // w8 / zero_bias visible
+        __syncthreads();   // w8 visible
 #pragma unroll
         for (int ks = 0; ks < KS_REG; ++ks) {
             const opx8 wv = *(const opx8*)(w8 + ks * 32 + 8 * gq);
@@ -371,8 +391,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_grad(const NetDesc net, cons
         float g[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
         f32x4 out[NB];
         prologue<KS_IN, WAVES>(net, wpack, smem, wave, lane);   // barrier inside: tables visible
-        run_net<NB, false, KS_IN, HID_SIGMUL, WAVES, GradCapture>(net, wpack, zero_bias, smem, Bcur, nullptr, out, wave, lane, sio,
+        run_net<NB, false, KS_IN, HID_SIGMUL, WAVES, GradCapture>(net, wpack, nullptr, smem, Bcur, nullptr, out, wave, lane, sio,
                                                                    GradCapture{tabs, tabs + PTS * 48, g});
+        GradCapture::unrotate(g);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -574,13 +595,36 @@ NetDesc as_desc(const MpNet* net) {
     return d;
 }
 
+// The core runs a network as a run of hidden (activated) layers followed by its linear output layer(s)
+// (mlp_core.hpp run_net); anything else is a malformed descriptor.
+bool net_ok(const MpNet* net) {
+    if (!net || net->n_layers < 1 || net->n_layers > MAX_LAYERS) return false;
+    bool linear_seen = false;
+    int chunks = 0;
+    for (int l = 0; l < net->n_layers; ++l) {
+        const auto& L = net->layer[l];
+        if (L.n_chunk < 1 || L.n_chunk > MAX_CHUNKS) return false;
+        if (L.act == ACT_NONE) linear_seen = true;
+        else if (linear_seen) return false;
+        chunks += L.n_chunk;
+    }
+    return chunks == net->total_chunks;
+}
+
 constexpr int PNB = 2, PWAVES = 8;   // plain-mode geometry
 
 }  // namespace
 
+#ifdef MP_EXP_STAMP
+extern "C" int mp_debug_stamps(void* dst_host) {
+    return (int)hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(mp::mp_stamps), sizeof(mp::mp_stamps));
+}
+#endif
+
 extern "C" int mp_mlp_sdf(const MpNet* net, const void* wpack, const float* bias, const float* xc,
                           const int* worklist, const int* count, int max_count, float* sdf_out, void* stream) {
     if (max_count <= 0) return 0;
+    if (!net_ok(net)) return -1;
     hipStream_t st = (hipStream_t)stream;
     using L = Lds<2, PNB, PWAVES>;
     static int once = set_lds(k_mlp_sdf<PNB, PWAVES>, L::total);
@@ -595,6 +639,7 @@ extern "C" int mp_mlp_sdf(const MpNet* net, const void* wpack, const float* bias
 extern "C" int mp_mlp_full(const MpNet* net, const void* wpack, const float* bias, const float* x, int d_in, int n,
                            float* out, void* stream) {
     if (n <= 0) return 0;
+    if (!net_ok(net)) return -1;
     hipStream_t st = (hipStream_t)stream;
     const NetDesc d = as_desc(net);
     if (d_in == 3) {
@@ -621,10 +666,11 @@ extern "C" int mp_mlp_shade_rev(const MpNet* net, const void* wpack, const float
                                 void* sig, int seg_points, void* stream) {
     if (max_count <= 0) return 0;
     if (seg_points < 256 || seg_points % 256) return -1;
+    if (!net_ok(net) || !net_ok(gnet)) return -1;
     hipStream_t st = (hipStream_t)stream;
     using L = Lds<2, PNB, PWAVES>;
     constexpr int TILE = 16 * PNB * PWAVES;
-    constexpr int LDS_G = RING_SLOTS * chunk_bytes(0) + BIAS_BYTES + 512 + PWAVES * 2 * 16 * PNB * 48 * 2;
+    constexpr int LDS_G = RING_SLOTS * chunk_bytes(0) + 512 + PWAVES * 2 * 16 * PNB * 48 * 2;
     static int once = set_lds(k_mlp_fwdsave<PNB, PWAVES>, L::total) + set_lds(k_mlp_grad<PNB, PWAVES>, LDS_G);
     (void)once;
     const NetDesc d = as_desc(net), gd = as_desc(gnet);
@@ -644,6 +690,7 @@ extern "C" int mp_mlp_shade(const MpNet* net, const void* wpack, const float* bi
                             const float* jinv, const int* worklist, const int* count, int max_count, float* sdf_out,
                             float* normal_out, void* feat_frag, void* stream) {
     if (max_count <= 0) return 0;
+    if (!net_ok(net)) return -1;
     hipStream_t st = (hipStream_t)stream;
     const NetDesc d = as_desc(net);
     using L = Lds<2, 2, 8>;
@@ -659,6 +706,7 @@ extern "C" int mp_mlp_color(const MpNet* net, const void* wpack, const float* bi
                             const float* normal, const void* feat_frag, const int* worklist, const int* count,
                             int max_count, float* rgb_out, void* stream) {
     if (max_count <= 0) return 0;
+    if (!net_ok(net)) return -1;
     hipStream_t st = (hipStream_t)stream;
     using L = Lds<2, PNB, PWAVES>;
     static int once = set_lds(k_mlp_color<PNB, PWAVES>, L::total);
@@ -674,6 +722,7 @@ extern "C" int mp_background(const MpNet* net_imp, const void* wpack_imp, const 
                              const void* wpack_ren, const float* bias_ren, const float* dirs, const float* cam,
                              const float* z_bg, int z_per_ray, int n_rays, float radius, float* bg_rgb, void* stream) {
     if (n_rays <= 0) return 0;
+    if (!net_ok(net_imp) || !net_ok(net_ren)) return -1;
     hipStream_t st = (hipStream_t)stream;
     using L = Lds<3, PNB, PWAVES>;
     static int once = set_lds(k_background<PNB, PWAVES>, L::total);

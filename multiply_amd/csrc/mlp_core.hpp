@@ -73,25 +73,59 @@ struct NetDesc {
     LayerDesc layer[MAX_LAYERS];
 };
 
-template <int KS_IN, int WAVES>
+// One LDS-DMA piece: 64 lanes x 16 B global -> 1 KiB of LDS at `lds_base` (wave-uniform byte offset), asynchronous,
+// counted in vmcnt.  Issued through inline asm ON PURPOSE: hipcc models the builtin (__builtin_amdgcn_global_load_lds)
+// as a FLAT operation touching both memory and LDS, and while one is pending every wait for an LDS read degrades to a
+// full drain (s_waitcnt lgkmcnt(0)) -- with weight chunks in flight all the time that is every wait of the K-step
+// stream, and it defeats the A-tile prefetch queue.  The price: the compiler does not know these loads, so the code
+// that consumes a chunk must order itself: dma_wait_all() before the barrier that publishes the chunk.
+// Addressing: scalar 64-bit base (wave-uniform) + one 32-bit lane offset register shared by every piece.
+__device__ __forceinline__ void lds_dma_16(const void* gsrc_uniform, unsigned lane_off, unsigned lds_base) {
+    // (M0 is a reserved register for hipcc: it writes M0 itself right before every instruction of its own that reads it
+    // and keeps nothing there across statements, so the asm may overwrite it without declaring a clobber)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_base), "v"(lane_off), "s"(gsrc_uniform)
+                 : "memory");
+}
+// s_waitcnt vmcnt(0) (gfx9 encoding: expcnt 7 and lgkmcnt 15 = "do not wait").  The builtin, not asm text: hipcc's wait
+// insertion pass reads it and learns that ITS OWN global loads (inputs, stored sigmoids) are complete as well, so it
+// does not re-wait for them (with vmcnt(0), i.e. also for the weight stream) inside the next chunk.
+__device__ __forceinline__ void dma_wait_all() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+__device__ __forceinline__ unsigned lds_offset(const void* p) { return (unsigned)(size_t)p; }   // low half of the flat address
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+    const size_t v = (size_t)p;
+    return (const char*)(((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                         (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+}
+
+// Pieces [P0, P1) of this wave's share of weight chunk ci (a chunk = NP 1 KiB pieces dealt round-robin to the waves).
+template <int KS_IN, int WAVES, int P0 = 0, int P1 = 99>
 __device__ __forceinline__ void issue_chunk(const char* __restrict__ wpack, char* wring, int ci, int wave, int lane) {
     constexpr int CB = chunk_bytes(KS_IN);
-    constexpr int NP = CB / TILE_BYTES;   // 1 KiB pieces, dealt round-robin to the workgroup's waves
-    const char* src = wpack + (size_t)ci * CB;
-    char* dst = wring + (ci % RING_SLOTS) * CB;
+    constexpr int NP = CB / TILE_BYTES;
+    constexpr int NI = (NP + WAVES - 1) / WAVES;
+    // everything the asm takes in scalar registers is made uniform explicitly ("s" does not enforce it)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave), ci_u = __builtin_amdgcn_readfirstlane(ci);
+    const char* src = uniform_ptr(wpack) + (size_t)ci_u * CB + wave_u * TILE_BYTES;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_offset(wring)) + (ci_u % RING_SLOTS) * CB + wave_u * TILE_BYTES;
 #pragma unroll
-    for (int i = 0; i < (NP + WAVES - 1) / WAVES; ++i) {
-        const int piece = wave + WAVES * i;
-        if (piece < NP)
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(src + piece * TILE_BYTES + lane * 16),
-            (__attribute__((address_space(3))) void*)(dst + piece * TILE_BYTES), 16, 0, 0);
+    for (int i = P0; i < (P1 < NI ? P1 : NI); ++i) {
+        if (wave_u + WAVES * i < NP) lds_dma_16(src + WAVES * i * TILE_BYTES, lane * 16, dst + WAVES * i * TILE_BYTES);
     }
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ h2 to_h2(float a, float b) { return (h2){(op_t)a, (op_t)b}; }   // one v_cvt_pk_f16_f32 (RTNE)
+#ifdef MP_EXP_STAMP   // ablation tooling: shader-clock stamps of workgroup 0 at every chunk boundary (mp_debug_stamps)
+__device__ unsigned long long mp_stamps[8 * 128 * 4];
+#define MP_STAMP(ev) do { if (blockIdx.x == 0 && lane == 0 && ci < 128) mp_stamps[((wave) * 128 + ci) * 4 + (ev)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MP_STAMP(ev)
+#endif
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h2 to_h2(float a, float b) {   // ONE v_cvt_pk_f16_f32 (RTNE): a vector conversion, so that it
+    return __builtin_convertvector((f32x2){a, b}, h2);    // stays packed whatever consumes the result
+}
 __device__ __forceinline__ unsigned bits(h2 v) { return __builtin_bit_cast(unsigned, v); }
 
 // Next-layer K operand under construction.  With NB = 4 the live state (Bcur 128 + Bnext 128 + input 32 + accumulators)
@@ -109,6 +143,13 @@ struct NextB {
         } else {
             r[c][nb][2 * half + j] = u;
         }
+    }
+    // same with a RUN-TIME K step (the layer's last block): a chain of selects, never a dynamically indexed array
+    __device__ __forceinline__ void put_sel(int c_rt, int nb, int half, int j, h2 v) {
+        static_assert(!IN_AGPR, "put_sel: VGPR-resident only");
+        const unsigned u = bits(v);
+#pragma unroll
+        for (int c = 0; c < KS_REG; ++c) r[c][nb][2 * half + j] = c == c_rt ? u : r[c][nb][2 * half + j];
     }
     __device__ __forceinline__ void zero() {
 #pragma unroll
@@ -182,11 +223,12 @@ __device__ __forceinline__ h2 log2_h2(h2 x) {
         : "=&v"(r) : "v"(xi));
     return __builtin_bit_cast(h2, r);
 }
-__device__ __forceinline__ h2 relu_h2(h2 z) {   // ONE v_pk_max_f16 (the builtin max adds a canonicalising v_pk_max in front)
-    unsigned r;
-    const unsigned zi = bits(z);
-    asm("v_pk_max_f16 %0, %1, 0" : "=v"(r) : "v"(zi));
-    return __builtin_bit_cast(h2, r);
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+// ReLU on the BIT PATTERN: a negative half is a negative int16, so one v_pk_max_i16 against 0 does it (-0 -> +0), without
+// the canonicalising extra v_pk_max the float max builtin carries and without inline asm (which the scheduler cannot
+// move).
+__device__ __forceinline__ h2 relu_h2(h2 z) {
+    return __builtin_bit_cast(h2, __builtin_elementwise_max(__builtin_bit_cast(s16x2, z), (s16x2){0, 0}));
 }
 __device__ __forceinline__ h2 softplus2(h2 z) {   // h' = max(z',0) + log2(1 + 2^-|z'|)
 #ifdef MP_EXP_NOTRANS
@@ -207,20 +249,21 @@ __device__ __forceinline__ h2 row_shr8(h2 s) {
 }
 
 // Piece q (0..7) of the activation of a finished block of 16 rows x NB column blocks; one piece rides in every K step
-// of the next block's MFMA stream.  `hidden` (wave-uniform): apply the nonlinearity, else pass through.
+// of the next block's MFMA stream.  HIDDEN (compile time: the layer loop dispatches on it, so that the K-step stream
+// is straight-line code): apply the nonlinearity, else pass through.
 //   plain  : q = 0..3 -> column block q/2, row pair q%2
 //   forward: half-block tangent layout (8 points per wave): block 0 = [values | d/dx], block 1 = [d/dy | d/dz]; lanes
 //            with (lane & 8) == 0 hold the value / d/dy columns of point lane&7, the others d/dx / d/dz.
 //            q = 0, 1: row pair q of both blocks (softplus + sigmoid on the values, tangents scaled by the sigmoid)
-template <int NB, bool FWD, int HID, int q, typename NB_T>
-__device__ __forceinline__ void act_piece(f32x4 (&p)[NB], bool hidden, NB_T& Bn, int pc, int ph, u32x4 (&sg)[NB],
+template <int NB, bool FWD, int HID, bool HIDDEN, int q, typename NB_T>
+__device__ __forceinline__ void act_piece(const f32x4 (&p)[NB], NB_T& Bn, int pc, int ph, u32x4 (&sg)[NB],
                                           const SigIO& sig, int sig_layer) {
     static_assert(NB == 2, "the MLP core is specialised for 2 column blocks per wave (2 waves per SIMD)");
     if constexpr (FWD) {
         if constexpr (q < 2) {
             h2 z = to_h2(p[0][2 * q], p[0][2 * q + 1]);
             h2 t = to_h2(p[1][2 * q], p[1][2 * q + 1]);
-            if (hidden) {
+            if constexpr (HIDDEN) {
                 const bool vl = (threadIdx.x & 8) == 0;
                 const h2 h = softplus2(z);
 #ifdef MP_EXP_NOTRANS
@@ -242,8 +285,8 @@ __device__ __forceinline__ void act_piece(f32x4 (&p)[NB], bool hidden, NB_T& Bn,
         if constexpr (q < 4) {
             constexpr int nb = q / 2, j = q % 2;
             h2 z = to_h2(p[nb][2 * j], p[nb][2 * j + 1]);
-            if constexpr (HID == HID_SOFTPLUS_SAVE) {
-                if (hidden) {
+            if constexpr (HIDDEN) {
+                if constexpr (HID == HID_SOFTPLUS_SAVE) {
                     const h2 h = softplus2(z);
                     const unsigned sv = bits(exp2_h2(z - h));   // sigmoid(z') = 2^(z' - h')
                     if (ph == 0) { if (j == 0) sg[nb][0] = sv; else sg[nb][1] = sv; }
@@ -251,109 +294,177 @@ __device__ __forceinline__ void act_piece(f32x4 (&p)[NB], bool hidden, NB_T& Bn,
                     z = h;
                     if (ph == 1 && j == 1 && pc < KS_REG)
                         *(u32x4*)(sig.base + (size_t)sig_layer * sig.layer_bytes + (pc * NB + nb) * 1024 + (threadIdx.x & 63) * 16) = sg[nb];
-                }
-            } else if constexpr (HID == HID_SIGMUL) {
-                if (hidden) {
+                } else if constexpr (HID == HID_SIGMUL) {
                     const unsigned sv = ph == 0 ? (j == 0 ? sg[nb][0] : sg[nb][1]) : (j == 0 ? sg[nb][2] : sg[nb][3]);
                     z = z * __builtin_bit_cast(h2, sv);
+                } else {
+                    z = HID == HID_SOFTPLUS ? softplus2(z) : relu_h2(z);
                 }
-            } else {
-                if (hidden) z = HID == HID_SOFTPLUS ? softplus2(z) : relu_h2(z);
             }
             if (pc < KS_REG) Bn.put(pc, nb, ph, j, z);
         }
     }
 }
 
-template <int NB, bool FWD, int HID, int q, typename NB_T>
-__device__ __forceinline__ void act_from(f32x4 (&p)[NB], bool hidden, NB_T& Bn, int pc, int ph, u32x4 (&sg)[NB],
+template <int NB, bool FWD, int HID, bool HIDDEN, int q, typename NB_T>
+__device__ __forceinline__ void act_from(const f32x4 (&p)[NB], NB_T& Bn, int pc, int ph, u32x4 (&sg)[NB],
                                          const SigIO& sig, int sig_layer) {
-    act_piece<NB, FWD, HID, q>(p, hidden, Bn, pc, ph, sg, sig, sig_layer);
-    if constexpr (q + 1 < 8) act_from<NB, FWD, HID, q + 1>(p, hidden, Bn, pc, ph, sg, sig, sig_layer);
+    act_piece<NB, FWD, HID, HIDDEN, q>(p, Bn, pc, ph, sg, sig, sig_layer);
+    if constexpr (q + 1 < 8) act_from<NB, FWD, HID, HIDDEN, q + 1>(p, Bn, pc, ph, sg, sig, sig_layer);
 }
 
-// Runs the whole network for this wave's NB column blocks.
-//   Bcur : register K operand of layer 0 (zeros when the network input only enters through the staging tile); on
-//          return it holds the last layer's (half) output blocks (e.g. the 256 features).
-//   stage_wave : this wave's input staging tile in LDS ([16*NB rows][in_stride] halves, rows = columns): the encoded
-//          network input, read on demand as the K operand of K steps 8.. of every layer with use_in.
-//   out  : fp32 rows 0..15 of the `out_chunk` (must be the last chunk of its layer).
-// Software pipeline: the activation of a finished 16-row block is issued, one piece per K step, inside the MFMA stream
-// of the next block; A tiles run PF tiles ahead in a rotating register queue across block and chunk boundaries;
-// weight chunks are loaded two chunks ahead into a 3-slot LDS ring (one barrier per chunk).
-// The caller must have run prologue() (chunks 0 and 1 in ring slots 0 and 1, barrier).
+// Sigmoid fragment buffers: chunk pc's four dwords per column block live in sgb[pc & 1]: written (HID_SOFTPLUS_SAVE) or
+// read (HID_SIGMUL, loaded at the chunk's start) from block (pc,1) to block (pc+1,0).  [Loading the reverse sweep's
+// fragments one chunk ahead into a third buffer, with or without letting them stay in flight across the chunk
+// barrier (s_waitcnt vmcnt(4) instead of 0), was measured 5-7 % SLOWER: the sweep is not waiting for HBM.]
+constexpr int SIG_BUFS = 2;
+template <int HID>
+__device__ __forceinline__ constexpr int sig_slot(int pc) { return pc & 1; }
+
+// Activation of a layer's LAST block (chunk pc_rt = n_chunk - 1, known only at run time, second half block): the one
+// piece of the pipeline that has no next block to ride in.  Written with selects on pc_rt -- when it was a copy of
+// act_from per unrolled chunk, hipcc merged the copies into one block that indexes the operand array dynamically and
+// moved the array to scratch memory.
+template <int NB, bool FWD, int HID, bool HIDDEN, typename NB_T>
+__device__ __forceinline__ void act_drain(const f32x4 (&p)[NB], NB_T& Bn, int pc_rt, u32x4 (&sgb)[SIG_BUFS][NB],
+                                          const SigIO& sig, int sig_layer) {
+    const bool odd = pc_rt & 1;
+#define MP_SG(nb, i) (odd ? sgb[1][nb][i] : sgb[0][nb][i])
+    if constexpr (FWD) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            h2 z = to_h2(p[0][2 * q], p[0][2 * q + 1]);
+            h2 t = to_h2(p[1][2 * q], p[1][2 * q + 1]);
+            if constexpr (HIDDEN) {
+                const bool vl = (threadIdx.x & 8) == 0;
+                const h2 h = softplus2(z);
+                const h2 s = exp2_h2(z - h);
+                const h2 sf = row_shr8(s);
+                const h2 zt = z * sf;
+                z = vl ? h : zt;
+                t = t * sf;
+            }
+            Bn.put_sel(pc_rt, 0, 1, q, z);
+            Bn.put_sel(pc_rt, 1, 1, q, t);
+        }
+    } else {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            // the four dwords of this chunk's sigmoid fragment, selected by buffer one by one (explicit scalars: with
+            // a u32x4 temporary indexed by the unrolled row-pair counter, hipcc 7.2 multiplied both row pairs by dword 0)
+            const unsigned s0 = MP_SG(nb, 0), s1 = MP_SG(nb, 1);
+            unsigned s2 = MP_SG(nb, 2), s3 = MP_SG(nb, 3);
+            h2 z0 = to_h2(p[nb][0], p[nb][1]), z1 = to_h2(p[nb][2], p[nb][3]);
+            if constexpr (HIDDEN) {
+                if constexpr (HID == HID_SOFTPLUS_SAVE) {
+                    const h2 h0 = softplus2(z0), h1 = softplus2(z1);
+                    s2 = bits(exp2_h2(z0 - h0));
+                    s3 = bits(exp2_h2(z1 - h1));
+                    z0 = h0;
+                    z1 = h1;
+                } else if constexpr (HID == HID_SIGMUL) {
+                    z0 = z0 * __builtin_bit_cast(h2, s2);
+                    z1 = z1 * __builtin_bit_cast(h2, s3);
+                } else {
+                    z0 = HID == HID_SOFTPLUS ? softplus2(z0) : relu_h2(z0);
+                    z1 = HID == HID_SOFTPLUS ? softplus2(z1) : relu_h2(z1);
+                }
+            }
+            Bn.put_sel(pc_rt, nb, 1, 0, z0);
+            Bn.put_sel(pc_rt, nb, 1, 1, z1);
+            if constexpr (HIDDEN && HID == HID_SOFTPLUS_SAVE) {
+                if (pc_rt < KS_REG)
+                    *(u32x4*)(sig.base + (size_t)sig_layer * sig.layer_bytes + (pc_rt * NB + nb) * 1024 + (threadIdx.x & 63) * 16) =
+                        (u32x4){s0, s1, s2, s3};
+            }
+        }
+    }
+#undef MP_SG
+}
+
 struct NoCapture {
     template <int NB>
     __device__ __forceinline__ void operator()(int, int, const f32x4 (&)[NB]) const {}
 };
 
-template <int NB, bool FWD, int KS_IN, int HID, int WAVES, typename Cap = NoCapture>
-__device__ __forceinline__ void run_net(const NetDesc& net, const char* __restrict__ wpack, const float* bias_lds,
-                                        char* wring, opx8 (&Bcur)[KS_REG][NB], const op_t* stage_wave,
-                                        f32x4 (&out)[NB], int wave, int lane, SigIO sig = SigIO{nullptr, 0},
-                                        Cap cap = Cap()) {
+constexpr int A_PF = 3, A_QN = 4;   // A-tile prefetch distance / rotating queue length (tiles)
+
+// One layer.  Software pipeline: the activation of a finished 16-row block is issued, one piece per K step, inside the
+// MFMA stream of the next block (the two blocks of a chunk accumulate in two register sets, so nothing is copied);
+// A tiles run A_PF tiles ahead in a rotating register queue across block and chunk boundaries; the bias of the next
+// block is fetched one block ahead; weight chunks are loaded two chunks ahead into a 3-slot LDS ring (one barrier per
+// chunk).  Everything inside a block is straight-line code: a wave-uniform branch per K step costs issue slots AND
+// makes hipcc drain the LDS queue (s_waitcnt lgkmcnt(0)) where a partial wait would do.
+template <int NB, bool FWD, int KS_IN, int HID, int WAVES, bool HIDDEN, typename Cap, typename NB_T>
+__device__ __forceinline__ void run_layer(const NetDesc& net, const LayerDesc L, int l, const char* __restrict__ wpack,
+                                          const float* bias_lds, char* wring, opx8 (&Bcur)[KS_REG][NB], NB_T& Bn,
+                                          opx8 (&aq)[A_QN], u32x4 (&sgb)[SIG_BUFS][NB], const op_t* stage_wave,
+                                          f32x4 (&out)[NB], int wave, int lane, const SigIO& sig, Cap& cap, int& ci) {
+    constexpr int PF = A_PF, QN = A_QN;
+    constexpr bool BIAS = HID != HID_SIGMUL;   // the reverse sweep has no bias
     const int g = lane >> 4;
-    int ci = 0;
-    // sigmoid fragments of the K steps under construction (HID_SOFTPLUS_SAVE / HID_SIGMUL), double-buffered by chunk
-    // parity: chunk c's group is live from block (c,1) to block (c+1,0), the next one is loaded at chunk c+1's start
-    u32x4 sgb[2][NB];
+    const float* bl = BIAS ? bias_lds + l * BIAS_STRIDE + g * 4 : nullptr;
+    const int sig_layer = HID == HID_SIGMUL ? (L.aux & 0xff) - 1 : l;
+    const int cap_id = (L.aux >> 8) & 0xff;
+    f32x4 accs[2][NB];   // block (c, mbl) accumulates in accs[mbl] while the activation of accs[mbl ^ 1] is issued
+    f32x4 bv_next = (f32x4){0, 0, 0, 0};
+    if constexpr (BIAS) bv_next = *(const f32x4*)bl;
+    auto load_sig = [&](int cc) {   // stored sigmoids of chunk cc (compile-time after unrolling) -> their buffer
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) sgb[0][nb] = sgb[1][nb] = (u32x4){0u, 0u, 0u, 0u};
-    NextB<NB, false> Bn;
-    Bn.zero();
-    constexpr int PF = 3, QN = 4;   // prefetch distance / queue length in A tiles
-    opx8 aq[QN];
+        for (int nb = 0; nb < NB; ++nb)
+            sgb[sig_slot<HID>(cc)][nb] = *(const u32x4*)(sig.base + (size_t)sig_layer * sig.layer_bytes + (cc * NB + nb) * 1024 +
+                                                         lane * 16);
+    };
 #pragma unroll
-    for (int t = 0; t < PF; ++t) aq[t] = *(const opx8*)(wring + t * TILE_BYTES + lane * 16);  // chunk 0, block 0
-    for (int l = 0; l < net.n_layers; ++l) {
-        const LayerDesc L = net.layer[l];
-        const float* bl = bias_lds + l * BIAS_STRIDE;
-        const bool hidden = L.act != ACT_NONE;
-        const int sig_layer = HID == HID_SIGMUL ? (L.aux & 0xff) - 1 : l;
-        const int cap_id = (L.aux >> 8) & 0xff;
-        f32x4 pend[NB];  // finished block whose activation is still pending
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) pend[nb] = (f32x4){0, 0, 0, 0};
-#pragma unroll
-        for (int c = 0; c < MAX_CHUNKS; ++c) {
-            if (c < L.n_chunk) {
-#ifndef MP_EXP_NOLOAD
-                if (ci + 2 < net.total_chunks) issue_chunk<KS_IN, WAVES>(wpack, wring, ci + 2, wave, lane);
+    for (int c = 0; c < MAX_CHUNKS; ++c) {
+        if (c < L.n_chunk) {
+            MP_STAMP(0);
+#ifndef MP_EXP_DMA_FIRST
+            if constexpr (HID == HID_SIGMUL && HIDDEN) load_sig(c);   // HBM stream first, then the (L2-resident) weight stream
 #endif
-                const char* slot = wring + (ci % RING_SLOTS) * chunk_bytes(KS_IN) + lane * 16;
-                // chunk ci+1 landed before the previous barrier: its first A tiles are prefetched from this chunk
-                const char* slot_next = wring + ((ci + 1) % RING_SLOTS) * chunk_bytes(KS_IN) + lane * 16;
-                const bool has_next = ci + 1 < net.total_chunks;
-                if constexpr (HID == HID_SIGMUL) {
-                    if (hidden) {
+#if !defined(MP_EXP_NOLOAD) && !defined(MP_EXP_SPREAD_DMA)
+            if (ci + 2 < net.total_chunks) issue_chunk<KS_IN, WAVES>(wpack, wring, ci + 2, wave, lane);
+#endif
+#ifdef MP_EXP_DMA_FIRST
+            if constexpr (HID == HID_SIGMUL && HIDDEN) load_sig(c);
+#endif
+            const char* slot = wring + (ci % RING_SLOTS) * chunk_bytes(KS_IN) + lane * 16;
+            // chunk ci+1 landed before the previous barrier: its first A tiles are prefetched from this chunk (after the
+            // network's last chunk the read hits a stale ring slot and is never used)
+            const char* slot_next = wring + ((ci + 1) % RING_SLOTS) * chunk_bytes(KS_IN) + lane * 16;
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
-                            sgb[c & 1][nb] = *(const u32x4*)(sig.base + (size_t)sig_layer * sig.layer_bytes + (c * NB + nb) * 1024 +
-                                                             lane * 16);
-                    }
+            for (int mbl = 0; mbl < CHUNK_MB; ++mbl) {
+#ifdef MP_EXP_PRIO   // ablation: alternate the issue priority of the two waves of a SIMD block by block
+                if (((wave >> 2) ^ mbl) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef MP_EXP_SPREAD_DMA   // ablation: one piece per wave at the start of each block instead of all after the barrier
+                if (ci + 2 < net.total_chunks) {
+                    if (mbl == 0) issue_chunk<KS_IN, WAVES, 0, 1>(wpack, wring, ci + 2, wave, lane);
+                    else issue_chunk<KS_IN, WAVES, 1, 99>(wpack, wring, ci + 2, wave, lane);
                 }
+#endif
+                f32x4 (&acc)[NB] = accs[mbl];
+                const f32x4 (&pend)[NB] = accs[mbl ^ 1];   // finished block whose activation is still pending
+                const f32x4 bv = bv_next;
+                if constexpr (BIAS) bv_next = *(const f32x4*)(bl + (2 * c + mbl + 1) * 16);   // may run 16 floats past the table
 #pragma unroll
-                for (int mbl = 0; mbl < CHUNK_MB; ++mbl) {
-                    f32x4 acc[NB];
-                    const f32x4 bv = *(const f32x4*)(bl + c * 32 + mbl * 16 + g * 4);
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) acc[nb] = (FWD && nb > 0) ? (f32x4){0, 0, 0, 0} : bv;
-                    if constexpr (FWD) {  // half-block layout: only the value half of block 0 carries the bias
-                        if (threadIdx.x & 8) acc[0] = (f32x4){0, 0, 0, 0};
-                    }
-                    const char* tile = slot + mbl * mb_bytes(KS_IN);
-                    // pending block = (c, 0) when mbl == 1, (c-1, 1) when mbl == 0
-                    const bool has_pend = mbl == 1 || c > 0;
-                    const int pc = mbl == 1 ? c : c - 1, ph = mbl == 1 ? 0 : 1;
+                for (int nb = 0; nb < NB; ++nb) acc[nb] = (FWD && nb > 0) ? (f32x4){0, 0, 0, 0} : bv;
+                if constexpr (FWD) {  // half-block layout: only the value half of block 0 carries the bias
+                    if (threadIdx.x & 8) acc[0] = (f32x4){0, 0, 0, 0};
+                }
+                const char* tile = slot + mbl * mb_bytes(KS_IN);
+                // pending block = (c, 0) when mbl == 1, (c-1, 1) when mbl == 0
+                const bool has_pend = mbl == 1 || c > 0;
+                const int pc = mbl == 1 ? c : c - 1, ph = mbl == 1 ? 0 : 1;
 #ifdef MP_EXP_NOACT
 #define MP_ACT_STMT(KS)
 #else
-#define MP_ACT_STMT(KS) if (has_pend) act_piece<NB, FWD, HID, KS>(pend, hidden, Bn, pc, ph, sgb[pc & 1], sig, sig_layer);
+#define MP_ACT_STMT(KS) if (has_pend) act_piece<NB, FWD, HID, HIDDEN, KS>(pend, Bn, pc, ph, sgb[sig_slot<HID>(pc)], sig, sig_layer);
 #endif
 #ifdef MP_EXP_NOLDS
 #define MP_LDS_STMT (void)src;
 #else
-#define MP_LDS_STMT if (nk < KS_REG || mbl + 1 < CHUNK_MB || has_next) aq[nk % QN] = *(const opx8*)src;
+#define MP_LDS_STMT aq[nk % QN] = *(const opx8*)src;
 #endif
 #define MP_QSKIP(KS)                                                                                                  \
     {                                                                                                                 \
@@ -383,62 +494,97 @@ __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restri
         }                                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
     }
-                    if (L.use_reg) {
-                        MP_KSTEP(0) MP_KSTEP(1) MP_KSTEP(2) MP_KSTEP(3) MP_KSTEP(4) MP_KSTEP(5) MP_KSTEP(6) MP_KSTEP(7)
-                    } else {
-                        // layer fed only by the encoded input (layer 0): no register K steps; keep the A-tile queue
-                        // in step with the tile stream and finish the pending block's activation
-                        MP_QSKIP(0) MP_QSKIP(1) MP_QSKIP(2) MP_QSKIP(3) MP_QSKIP(4) MP_QSKIP(5) MP_QSKIP(6) MP_QSKIP(7)
+                if (L.use_reg) {
+                    MP_KSTEP(0) MP_KSTEP(1) MP_KSTEP(2) MP_KSTEP(3) MP_KSTEP(4) MP_KSTEP(5) MP_KSTEP(6) MP_KSTEP(7)
+                } else {
+                    // layer fed only by the encoded input (layer 0): no register K steps; keep the A-tile queue
+                    // in step with the tile stream and finish the pending block's activation
+                    MP_QSKIP(0) MP_QSKIP(1) MP_QSKIP(2) MP_QSKIP(3) MP_QSKIP(4) MP_QSKIP(5) MP_QSKIP(6) MP_QSKIP(7)
 #ifndef MP_EXP_NOACT
-                        if (has_pend) act_from<NB, FWD, HID, 0>(pend, hidden, Bn, pc, ph, sgb[pc & 1], sig, sig_layer);
+                    if (has_pend) act_from<NB, FWD, HID, HIDDEN, 0>(pend, Bn, pc, ph, sgb[sig_slot<HID>(pc)], sig, sig_layer);
 #endif
-                    }
+                }
 #undef MP_KSTEP
 #undef MP_QSKIP
 #undef MP_ACT_STMT
 #undef MP_LDS_STMT
-                    if (L.use_in) {
+                if (L.use_in) {
 #pragma unroll
-                        for (int ks = 0; ks < KS_IN; ++ks) {
-                            const opx8 a = *(const opx8*)(tile + (KS_REG + ks) * TILE_BYTES);
+                    for (int ks = 0; ks < KS_IN; ++ks) {
+                        const opx8 a = *(const opx8*)(tile + (KS_REG + ks) * TILE_BYTES);
 #pragma unroll
-                            for (int nb = 0; nb < NB; ++nb) {
-                                const opx8 bi = *(const opx8*)(stage_wave + (nb * 16 + (lane & 15)) * in_stride(KS_IN) +
-                                                                   ks * 32 + g * 8);
-                                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bi, acc[nb], 0, 0, 0);
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) pend[nb] = acc[nb];
-                    if (cap_id == 1) {          // rows 0..47: blocks (0,0), (0,1), (1,0)
-                        if (c == 0) cap(1, mbl, acc);
-                        else if (c == 1 && mbl == 0) cap(1, 2, acc);
-                    } else if (cap_id == 2) {   // rows 208..255: blocks (6,1), (7,0), (7,1)
-                        if (c == 6 && mbl == 1) cap(2, 0, acc);
-                        else if (c == 7) cap(2, 1 + mbl, acc);
-                    }
-                    if ((c == 0 || c == MAX_CHUNKS - 1) && mbl == 0) {
-                        if (c == L.out_chunk) {  // fp32 rows 0..15 of the out chunk (its layer is linear)
-#pragma unroll
-                            for (int nb = 0; nb < NB; ++nb) out[nb] = acc[nb];
+                        for (int nb = 0; nb < NB; ++nb) {
+                            const opx8 bi = *(const opx8*)(stage_wave + (nb * 16 + (lane & 15)) * in_stride(KS_IN) +
+                                                               ks * 32 + g * 8);
+                            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bi, acc[nb], 0, 0, 0);
                         }
                     }
                 }
-                if (c == L.n_chunk - 1) {  // layer ends: drain the pipeline (block (c, 1))
-                    act_from<NB, FWD, HID, 0>(pend, hidden, Bn, c, 1, sgb[c & 1], sig, sig_layer);
+                if (cap_id == 1) {          // rows 0..47: blocks (0,0), (0,1), (1,0)
+                    if (c == 0) cap(1, mbl, acc);
+                    else if (c == 1 && mbl == 0) cap(1, 2, acc);
+                } else if (cap_id == 2) {   // rows 208..255: blocks (6,1), (7,0), (7,1)
+                    if (c == 6 && mbl == 1) cap(2, 0, acc);
+                    else if (c == 7) cap(2, 1 + mbl, acc);
                 }
-#ifndef MP_EXP_NOBARRIER
-                __syncthreads();  // every wave is done with chunk ci; chunk ci+2's loads have had a whole chunk to land
-#endif
-                ++ci;
+                if ((c == 0 || c == MAX_CHUNKS - 1) && mbl == 0) {
+                    if (c == L.out_chunk) {  // fp32 rows 0..15 of the out chunk (its layer is linear)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) out[nb] = acc[nb];
+                    }
+                }
             }
+            MP_STAMP(1);
+#ifndef MP_EXP_NOBARRIER
+            dma_wait_all();   // this wave's pieces of chunk ci+2 (issued a whole chunk ago) and of every earlier chunk
+            MP_STAMP(2);
+            __syncthreads();  // every wave is done with chunk ci; chunk ci+1 is complete in the ring
+            MP_STAMP(3);
+#endif
+            ++ci;
         }
-#pragma unroll
-        for (int k = 0; k < KS_REG; ++k)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) Bcur[k][nb] = Bn.get(k, nb);
     }
+    // layer ends: drain the pipeline (block (n_chunk - 1, 1); after the chunk's barrier, it touches registers only)
+    act_drain<NB, FWD, HID, HIDDEN>(accs[1], Bn, L.n_chunk - 1, sgb, sig, sig_layer);
+#pragma unroll
+    for (int k = 0; k < KS_REG; ++k)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) Bcur[k][nb] = Bn.get(k, nb);
+}
+
+// Runs the whole network for this wave's NB column blocks.
+//   Bcur : register K operand of layer 0 (zeros when the network input only enters through the staging tile); on
+//          return it holds the last layer's (half) output blocks (e.g. the 256 features).
+//   stage_wave : this wave's input staging tile in LDS ([16*NB rows][in_stride] halves, rows = columns): the encoded
+//          network input, read on demand as the K operand of K steps 8.. of every layer with use_in.
+//   out  : fp32 rows 0..15 of the `out_chunk` (must be the last chunk of its layer).
+// The caller must have run prologue() (chunks 0 and 1 in ring slots 0 and 1, barrier).
+template <int NB, bool FWD, int KS_IN, int HID, int WAVES, typename Cap = NoCapture>
+__device__ __forceinline__ void run_net(const NetDesc& net, const char* __restrict__ wpack, const float* bias_lds,
+                                        char* wring, opx8 (&Bcur)[KS_REG][NB], const op_t* stage_wave,
+                                        f32x4 (&out)[NB], int wave, int lane, SigIO sig = SigIO{nullptr, 0},
+                                        Cap cap = Cap()) {
+    int ci = 0;
+    // sigmoid fragments of the K steps under construction (HID_SOFTPLUS_SAVE) / about to be applied (HID_SIGMUL): sig_slot
+    u32x4 sgb[SIG_BUFS][NB];
+#pragma unroll
+    for (int b = 0; b < SIG_BUFS; ++b)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) sgb[b][nb] = (u32x4){0u, 0u, 0u, 0u};
+    NextB<NB, false> Bn;
+    Bn.zero();
+    opx8 aq[A_QN];
+#pragma unroll
+    for (int t = 0; t < A_PF; ++t) aq[t] = *(const opx8*)(wring + t * TILE_BYTES + lane * 16);  // chunk 0, block 0
+    // every network on this path is a run of hidden layers followed by its linear output layer(s): two loops instead of
+    // a per-layer dispatch keep the two instantiations of the layer body out of each other's register allocation
+    int l = 0;
+    for (; l < net.n_layers && net.layer[l].act != ACT_NONE; ++l)
+        run_layer<NB, FWD, KS_IN, HID, WAVES, true>(net, net.layer[l], l, wpack, bias_lds, wring, Bcur, Bn, aq, sgb, stage_wave,
+                                                    out, wave, lane, sig, cap, ci);
+    for (; l < net.n_layers; ++l)
+        run_layer<NB, FWD, KS_IN, HID, WAVES, false>(net, net.layer[l], l, wpack, bias_lds, wring, Bcur, Bn, aq, sgb, stage_wave,
+                                                     out, wave, lane, sig, cap, ci);
 }
 
 // Issues the first two weight chunks into ring slots 0 and 1 and synchronises (also publishes the staging rows).
@@ -447,6 +593,7 @@ __device__ __forceinline__ void prologue(const NetDesc& net, const char* __restr
                                          int lane) {
     issue_chunk<KS_IN, WAVES>(wpack, wring, 0, wave, lane);
     if (net.total_chunks > 1) issue_chunk<KS_IN, WAVES>(wpack, wring, 1, wave, lane);
+    dma_wait_all();
     __syncthreads();
 }
 __device__ __forceinline__ void load_bias(const NetDesc& net, const float* __restrict__ bias, float* bias_lds) {

@@ -175,6 +175,8 @@ class PackedNet:
             self.offsets.append(off)
             off += nch
         self.net.total_chunks = off
+        acts = [p.act != ACT_NONE for p in plans]
+        assert acts == sorted(acts, reverse=True), "the core runs hidden layers first, then the linear output layer(s)"
         self.wpack = torch.zeros(off * self.chunk_bytes, dtype=torch.uint8, device=device)
         self.bias = torch.zeros(MAX_LAYERS * BIAS_STRIDE, dtype=torch.float32, device=device)
         self.rowmaps = [torch.from_numpy(p.rowmap).to(device) for p in plans]
