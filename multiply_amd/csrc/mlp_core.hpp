@@ -288,7 +288,11 @@ __device__ __forceinline__ void act_piece(const f32x4 (&p)[NB], NB_T& Bn, int pc
             if constexpr (HIDDEN) {
                 if constexpr (HID == HID_SOFTPLUS_SAVE) {
                     const h2 h = softplus2(z);
+#ifdef MP_EXP_NOTRANS
+                    const unsigned sv = bits(z * (h2){(op_t)0.01f, (op_t)0.01f});
+#else
                     const unsigned sv = bits(exp2_h2(z - h));   // sigmoid(z') = 2^(z' - h')
+#endif
                     if (ph == 0) { if (j == 0) sg[nb][0] = sv; else sg[nb][1] = sv; }
                     else { if (j == 0) sg[nb][2] = sv; else sg[nb][3] = sv; }
                     z = h;
@@ -388,6 +392,10 @@ struct NoCapture {
 };
 
 constexpr int A_PF = 3, A_QN = 4;   // A-tile prefetch distance / rotating queue length (tiles)
+// K step of the next block that carries the first activation piece of a finished block.  The reverse sweep's pieces
+// (one multiplication each) sit in K steps 4..7, away from the MFMAs that produced their inputs: -8 % on k_mlp_grad;
+// the softplus pieces are best right at the start (+8 % on k_mlp_fwdsave when shifted).
+__device__ __forceinline__ constexpr int act_shift(int hid) { return hid == 3 /* HID_SIGMUL */ ? 4 : 0; }
 
 // One layer.  Software pipeline: the activation of a finished 16-row block is issued, one piece per K step, inside the
 // MFMA stream of the next block (the two blocks of a chunk accumulate in two register sets, so nothing is copied);
@@ -459,7 +467,11 @@ __device__ __forceinline__ void run_layer(const NetDesc& net, const LayerDesc L,
 #ifdef MP_EXP_NOACT
 #define MP_ACT_STMT(KS)
 #else
-#define MP_ACT_STMT(KS) if (has_pend) act_piece<NB, FWD, HID, HIDDEN, KS>(pend, Bn, pc, ph, sgb[sig_slot<HID>(pc)], sig, sig_layer);
+#define MP_ACT_STMT(KS)                                                                                               \
+    if constexpr (KS >= act_shift(HID)) {                                                                             \
+        if (has_pend)                                                                                                 \
+            act_piece<NB, FWD, HID, HIDDEN, KS - act_shift(HID)>(pend, Bn, pc, ph, sgb[sig_slot<HID>(pc)], sig, sig_layer); \
+    }
 #endif
 #ifdef MP_EXP_NOLDS
 #define MP_LDS_STMT (void)src;
