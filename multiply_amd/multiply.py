@@ -291,7 +291,6 @@ class Multiply(nn.Module):
         S = NZ - 1
         stats = {"n_hit": n_hit, "iters": [], "n_sdf_evals": [], "n_shaded": []}
 
-        z_l, sdf_l, rgb_l, nrm_l, inv_l = [], [], [], [], []
         for n, p in enumerate(persons):
             pp = per[p]
             Rp = max(int(n_hit[n]), 1)
@@ -341,7 +340,6 @@ class Multiply(nn.Module):
                 hip.check(L.mp_mlp_color(C.byref(pk_col.net), hip.ptr(pk_col.wpack), hip.ptr(pk_col.bias), hip.ptr(xc),
                                          hip.ptr(nrm), hip.ptr(feat), hip.ptr(work2), hip.ptr(wc2), npts, hip.ptr(rgb),
                                          st), "mp_mlp_color")
-            z_l.append(zfinal); sdf_l.append(sdf); rgb_l.append(rgb); nrm_l.append(nrm); inv_l.append(pp["inv_index"])
             stats["iters"].append(iters); stats["n_sdf_evals"].append(wcount)
             per[p].update(zfinal=zfinal, sdf=sdf, rgb=rgb, nrm=nrm, xc=xc, work2=work2, wc2=wc2)
 
@@ -353,34 +351,70 @@ class Multiply(nn.Module):
                             hit_index=per[p]["hit_index"][:max(int(n_hit[n]), 1)], n_hit=int(n_hit[n]))
                     for n, p in enumerate(persons)}
 
-        # ---- background (multiply.py:482-484, 514-539)
-        bg_rgb = None
-        if input.get("idx", None) is not None:
-            key = "image_id" if "image_id" in input else "idx"      # multiply.py:407-410
-            code = self.frame_latent_encoder.weight.detach()[int(torch.as_tensor(input[key]).reshape(-1)[0])]
-            t = torch.linspace(0.0, 1.0, rs.N_samples_inverse_sphere, device=dev)
-            z_bg = torch.flip(t * (1.0 / rs.scene_bounding_sphere), dims=[0]).contiguous()
-            with self._ph("background"):
-                bg_rgb = hip.background(self.bg_implicit_network, self.bg_rendering_network, dirs,
-                                        pose.reshape(4, 4)[:3, 3].contiguous(), z_bg, code,
-                                        radius=self.sdf_bounding_sphere)
+        stats["n_shaded"] = [per[p]["wc2"] for p in persons]
+        self.last_stats = stats
+        bg_rgb = self._background(input, cx)
+        out, bg_T, keep = self._composite(cx, persons, bg_rgb)
+        self._last = dict(per=per, dirs=dirs, far=far, bg_T=bg_T, bg_rgb=bg_rgb, persons=persons, keep=keep)
+        return out
 
-        # ---- compositing (multiply.py:425-480, 544-545)
-        def table(ts):
-            return torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device=dev)
-        t_inv, t_z, t_sdf, t_rgb, t_nrm = table(inv_l), table(z_l), table(sdf_l), table(rgb_l), table(nrm_l)
+    def _background(self, input, cx):
+        """NeRF++ background colour of every ray of the call, or None without a frame index (multiply.py:482-484,
+        514-539)."""
+        if input.get("idx", None) is None:
+            return None
+        rs = self.ray_sampler
+        dev = cx["dev"]
+        key = "image_id" if "image_id" in input else "idx"      # multiply.py:407-410
+        code = self.frame_latent_encoder.weight.detach()[int(torch.as_tensor(input[key]).reshape(-1)[0])]
+        t = torch.linspace(0.0, 1.0, rs.N_samples_inverse_sphere, device=dev)
+        z_bg = torch.flip(t * (1.0 / rs.scene_bounding_sphere), dims=[0]).contiguous()
+        with self._ph("background"):
+            return hip.background(self.bg_implicit_network, self.bg_rendering_network, cx["dirs"],
+                                  cx["pose"].reshape(4, 4)[:3, 3].contiguous(), z_bg, code,
+                                  radius=self.sdf_bounding_sphere)
+
+    def _composite(self, cx, persons, bg_rgb):
+        """Packed multi-person compositing of the per-person sample arrays in cx['per'] for the subset `persons`
+        (multiply.py:425-480, 544-545) -> (output dict, background transmittance, tensors to keep alive)."""
+        L = hip.lib()
+        dev, R, per = cx["dev"], cx["R"], cx["per"]
+        f32 = dict(dtype=torch.float32, device=dev)
+        NZ = self.ray_sampler.N_samples + self.ray_sampler.N_samples_extra + 2
+
+        def table(key):
+            return torch.tensor([per[p][key].data_ptr() for p in persons], dtype=torch.int64, device=dev)
+        t_inv, t_z, t_sdf, t_rgb, t_nrm = table("inv_index"), table("zfinal"), table("sdf"), table("rgb"), table("nrm")
         rgb_values = torch.empty(R, 3, **f32); fg_rgb_values = torch.empty(R, 3, **f32)
         normal_values = torch.empty(R, 3, **f32); acc_map = torch.empty(R, **f32)
         acc_person = torch.empty(R, len(persons), **f32); bg_T = torch.empty(R, **f32)
-        ph = self._ph("composite"); ph.__enter__()
-        hip.check(L.mp_composite(R, len(persons), NZ, hip.ptr(t_inv), hip.ptr(t_z), hip.ptr(t_sdf), hip.ptr(t_rgb),
-                                 hip.ptr(t_nrm), hip.ptr(beta), hip.ptr(bg_rgb) if bg_rgb is not None else None,
-                                 hip.ptr(rgb_values), hip.ptr(fg_rgb_values), hip.ptr(normal_values), hip.ptr(acc_map),
-                                 hip.ptr(acc_person), hip.ptr(bg_T), st), "mp_composite")
-        ph.__exit__()
-        stats["n_shaded"] = [per[p]["wc2"] for p in persons]
-        self.last_stats = stats
-        self._last = dict(per=per, dirs=dirs, far=far, bg_T=bg_T, bg_rgb=bg_rgb, persons=persons, keep=(t_inv, t_z, t_sdf,
-                                                                                                        t_rgb, t_nrm))
-        return {"acc_map": acc_map, "acc_person_list": acc_person, "rgb_values": rgb_values,
-                "fg_rgb_values": fg_rgb_values, "normal_values": normal_values}
+        with self._ph("composite"):
+            hip.check(L.mp_composite(R, len(persons), NZ, hip.ptr(t_inv), hip.ptr(t_z), hip.ptr(t_sdf), hip.ptr(t_rgb),
+                                     hip.ptr(t_nrm), hip.ptr(cx["beta"]), hip.ptr(bg_rgb) if bg_rgb is not None else None,
+                                     hip.ptr(rgb_values), hip.ptr(fg_rgb_values), hip.ptr(normal_values), hip.ptr(acc_map),
+                                     hip.ptr(acc_person), hip.ptr(bg_T), hip.stream()), "mp_composite")
+        out = {"acc_map": acc_map, "acc_person_list": acc_person, "rgb_values": rgb_values,
+               "fg_rgb_values": fg_rgb_values, "normal_values": normal_values}
+        return out, bg_T, (t_inv, t_z, t_sdf, t_rgb, t_nrm)
+
+    def render_views(self, input, ids=None, canonical_pose=False):
+        """Every view the reference's caller renders of one frame -- all persons (id -1) and each person alone
+        (multiply_model.py:982-989, 1183-1190: P + 1 full chunk loops of forward(s, id)) -- from ONE sampling + shading
+        pass: a person's samples do not depend on who else is rendered (multiply.py:254-423 loops persons independently),
+        so view `id` is a compositing pass over that person's arrays plus the shared background.
+        Returns {id: the eval output dict of forward(input, id)}; bit-identical to the separate calls."""
+        assert not self.training, "render_views is an eval-mode entry point"
+        with torch.no_grad():
+            samples = self._forward_eval(input, -1, canonical_pose, composite=False)
+            cx = self._last["cx"]
+            persons = cx["persons"]
+            if ids is None:
+                ids = [-1] + (persons if len(persons) > 1 else [])
+            bg_rgb = self._background(input, cx)
+            views, keep = {}, []
+            for i in ids:
+                out, bg_T, k = self._composite(cx, persons if i == -1 else [int(i)], bg_rgb)
+                views[i] = out
+                keep.append((bg_T, k))
+            self._last.update(bg_rgb=bg_rgb, keep=keep, samples=samples)
+            return views

@@ -35,3 +35,17 @@ def test_loss_nan_rays_are_filtered_and_schedules():
     assert float(lo["in_shape_loss"]) == 0.0 and float(lo["sam_mask_loss"]) == 0.0      # no mask given / no flags
     want = lo["rgb_loss"] + 0.1 * lo["eikonal_loss"] + 5e-3 * lo["bce_loss"] + lo["temporal_loss"]
     assert torch.allclose(lo["loss"], want)
+
+
+def test_split_input_and_merge_output_round_trip():
+    """idr_utils mirrors (reference lib/utils/idr_utils.py:3-30): chunks cover the pixels in order, merge restores them"""
+    from multiply_amd.idr_utils import merge_output, split_input
+    R = 150
+    inp = {"uv": torch.arange(R * 2, dtype=torch.float32).reshape(1, R, 2), "pose": torch.eye(4)[None]}
+    chunks = split_input(inp, R, n_pixels=64)
+    assert [c["uv"].shape[1] for c in chunks] == [64, 64, 22] and all(c["pose"] is inp["pose"] for c in chunks)
+    res = [{"rgb_values": c["uv"][0].repeat(1, 2)[:, :3], "acc_map": c["uv"][0, :, 0], "skipped": None} for c in chunks]
+    m = merge_output(res, R, 1)
+    assert sorted(m) == ["acc_map", "rgb_values"]
+    assert m["acc_map"].shape == (R,) and torch.equal(m["acc_map"], inp["uv"][0, :, 0])
+    assert m["rgb_values"].shape == (R, 3) and torch.equal(m["rgb_values"][:, 0], inp["uv"][0, :, 0])

@@ -218,3 +218,42 @@ def test_forward_mode_and_reverse_mode_shading_agree():
         d = (a[k] - b[k]).abs().max().item()
         print(f"[parity] reverse vs forward shading, {k}: max {d:.3e}")
         assert d < tol, k
+
+
+def test_render_views_equal_separate_calls_and_the_chunked_loop():
+    """Multiply.render_views: the all-person view and every single-person view of a frame from ONE sampling + shading
+    pass are bit-identical to separate forward(input, id) calls (the reference's validation_step, multiply_model.py:
+    982-989), and with convergence_group = pixel_per_batch to the reference's chunk loop through split_input /
+    merge_output (multiply_model.py:1045-1069)."""
+    from multiply_amd.idr_utils import merge_output, split_input
+    model, oracle, inp = build(H=15, W=15)
+    gin = _gpu(inp)
+    R = inp["uv"].shape[1]
+    views = model.render_views(gin)
+    torch.cuda.synchronize()
+    assert sorted(views) == [-1, 0, 1]
+    for i in (-1, 0, 1):
+        want = model(gin) if i == -1 else model(gin, i)
+        torch.cuda.synchronize()
+        assert sorted(views[i]) == sorted(want)
+        for k in want:
+            assert views[i][k].shape == want[k].shape
+            assert torch.equal(torch.nan_to_num(views[i][k]), torch.nan_to_num(want[k])), (i, k)
+    assert views[0]["acc_person_list"].shape == (R, 1) and views[-1]["acc_person_list"].shape == (R, 2)
+    # a person alone is never more opaque than ... itself inside the group: its own accumulated weight can only grow
+    assert (views[0]["acc_map"] + 1e-5 >= views[-1]["acc_person_list"][:, 0]).all()
+    # the caller's chunk loop, pixel_per_batch = 64
+    model.convergence_group = 64
+    grouped = model.render_views(gin)
+    torch.cuda.synchronize()
+    model.convergence_group = None
+    for i in (-1, 1):
+        res = []
+        for s in split_input(gin, R, n_pixels=64):
+            out = model(s) if i == -1 else model(s, i)
+            res.append({k: out[k] for k in ("rgb_values", "normal_values", "fg_rgb_values")})
+        torch.cuda.synchronize()
+        merged = merge_output(res, R, 1)
+        for k, v in merged.items():
+            got = grouped[i][k].reshape(v.shape)
+            assert torch.equal(torch.nan_to_num(got), torch.nan_to_num(v)), (i, k)
