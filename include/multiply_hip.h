@@ -307,6 +307,15 @@ int mp_query_weights(const float* pts, int n, const float* verts, int n_verts, c
                      unsigned char* outlier, void* stream);
 int mp_skinning(const float* pts, const float* weights, int n, const float* tfs, int inverse, float* out, void* stream);
 
+/* ---- input producer (code/lib/datasets/Hi4D.py:8-20 bilinear_interpolation, :59-88 weighted_sampling) --------------
+ * Sub-pixel samples of a frame that is RESIDENT in device memory: img [H][W][3] bytes (RGB), mask [H][W] bytes (the sum of
+ * the per-person masks, Hi4D.py:236-245), extra [H][W][n_extra] fp32 (optional, e.g. the SAM mask), pos [n][2] doubles
+ * (row, col) as the reference draws them (row < H-1, col < W-1).  Outputs (each optional): rgb [n][3] = interpolated
+ * img/255, uv [n][2] = (col, row), mask_out [n], extra_out [n][n_extra]; double arithmetic, rounded once to fp32. */
+int mp_sample_pixels(const unsigned char* img, const unsigned char* mask, const float* extra, int n_extra,
+                     const double* pos, int n, int H, int W, float* rgb, float* uv, float* mask_out, float* extra_out,
+                     void* stream);
+
 /* library / device info: returns the gfx arch string compiled in, and checks the current device */
 const char* mp_arch(void);
 int mp_device_ok(void);

@@ -132,3 +132,54 @@ def make_scene(num_person=2, seed=0, H=512, W=512):
     uv = np.mgrid[:H, :W].astype(np.int32)
     uv = np.flip(uv, axis=0).copy().reshape(2, -1).T.astype(np.float32)  # (x, y) order as Hi4D.py:254-255
     return dict(smpl_params=params, intrinsics=intr[None], pose=pose[None], uv=uv[None])
+
+
+def write_sequence(root, n_frames=4, H=96, W=128, num_person=2, seed=0, with_edges=False):
+    """Writes a small synthetic sequence in the reference's on-disk scene format (the layout `Hi4DDataset` reads,
+    code/lib/datasets/Hi4D.py:92-130, written by preprocessing/preprocessing_multiple_trace.py:529-599):
+    image/%04d.png, mask/<p>/%04d.png, [edge/%04d.png,] poses.npy, mean_shape.npy, normalize_trans.npy,
+    cameras_normalize.npz (scale_mat_i, world_mat_i), gender.npy.  Returns the arrays it wrote."""
+    import os
+    from PIL import Image
+    rs = np.random.RandomState(seed)
+    os.makedirs(os.path.join(root, "image"), exist_ok=True)
+    sc = make_scene(num_person, seed=seed, H=H, W=W)
+    K, pose = sc["intrinsics"][0].astype(np.float64), sc["pose"][0].astype(np.float64)
+    R, C = pose[:3, :3].T, pose[:3, 3]
+    world = np.eye(4)
+    world[:3, :4] = K[:3, :3] @ np.concatenate([R, (-R @ C)[:, None]], 1)
+    cams, images, masks = {}, [], []
+    yy, xx = np.mgrid[:H, :W]
+    for f in range(n_frames):
+        img = (rs.rand(H // 8 + 1, W // 8 + 1, 3) * 255).astype(np.uint8).repeat(8, 0).repeat(8, 1)[:H, :W]
+        img = (img.astype(np.int32) + rs.randint(-20, 20, (H, W, 3))).clip(0, 255).astype(np.uint8)
+        Image.fromarray(img).save(os.path.join(root, "image", "%04d.png" % f))
+        images.append(img)
+        per = []
+        for p in range(num_person):
+            cx, cy = W * (0.3 + 0.4 * p / max(num_person - 1, 1)) + 3 * f, H * 0.5
+            m = (((xx - cx) / (0.16 * W)) ** 2 + ((yy - cy) / (0.38 * H)) ** 2) < 1.0
+            os.makedirs(os.path.join(root, "mask", "%d" % p), exist_ok=True)
+            Image.fromarray((m[:, :, None] * np.array([255, 255, 255])).astype(np.uint8)).save(
+                os.path.join(root, "mask", "%d" % p, "%04d.png" % f))
+            per.append(m)
+        masks.append(np.stack(per))
+        if with_edges:
+            os.makedirs(os.path.join(root, "edge"), exist_ok=True)
+            any_m = np.any(per, axis=0)
+            edge = any_m & ~(np.roll(any_m, 2, 0) & np.roll(any_m, -2, 0) & np.roll(any_m, 2, 1) & np.roll(any_m, -2, 1))
+            Image.fromarray((edge[:, :, None] * np.array([255, 255, 255])).astype(np.uint8)).save(
+                os.path.join(root, "edge", "%04d.png" % f))
+        s = np.eye(4)
+        s[:3, :3] *= 1.0 + 0.0 * f
+        cams["scale_mat_%d" % f] = s
+        cams["world_mat_%d" % f] = world
+    poses = np.repeat(sc["smpl_params"][0, None, :, 4:76], n_frames, 0) + rs.normal(0, 0.01, (n_frames, num_person, 72))
+    trans = np.repeat(sc["smpl_params"][0, None, :, 1:4], n_frames, 0)
+    shape = sc["smpl_params"][0, :, 76:]
+    np.save(os.path.join(root, "poses.npy"), poses)
+    np.save(os.path.join(root, "normalize_trans.npy"), trans)
+    np.save(os.path.join(root, "mean_shape.npy"), shape)
+    np.save(os.path.join(root, "gender.npy"), np.array(["male"] * num_person))
+    np.savez(os.path.join(root, "cameras_normalize.npz"), **cams)
+    return dict(images=np.stack(images), masks=np.stack(masks), poses=poses, trans=trans, shape=shape, intrinsics=K, pose=pose)

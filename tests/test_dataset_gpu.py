@@ -1,0 +1,110 @@
+"""Input producer on the GPU: mp_sample_pixels against golden vectors from the reference's own weighted_sampling /
+bilinear_interpolation / edge_sampling (tests/golden/make_dataset_golden.py), and the Hi4DDataset mirror against the CPU
+oracle on a sequence written in the reference's on-disk format."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dataset_golden.npz")
+
+
+def _opt(root, **kw):
+    from multiply_amd.config import to_config
+    base = dict(data_root=os.path.dirname(root), data_dir=os.path.basename(root), start_frame=0, end_frame=3, num_sample=64,
+                using_SAM=False, pixel_per_batch=512)
+    base.update(kw)
+    return to_config(base)
+
+
+def test_sample_pixels_matches_the_reference_functions():
+    from multiply_amd import hip
+    g = np.load(GOLD)
+    H, W = g["img"].shape[:2]
+    dev = torch.device("cuda")
+    img = torch.from_numpy(g["img"]).to(dev)
+    mask = torch.from_numpy(g["person"].sum(0).astype(np.uint8)).to(dev)
+    sam = torch.from_numpy(g["sam"]).to(dev)
+    pos = torch.from_numpy(g["pos"]).to(dev)
+    n = pos.shape[0]
+    f32 = dict(dtype=torch.float32, device=dev)
+    rgb, uv, om, ex = torch.empty(n, 3, **f32), torch.empty(n, 2, **f32), torch.empty(n, **f32), torch.empty(n, 2, **f32)
+    hip.check(hip.lib().mp_sample_pixels(hip.ptr(img), hip.ptr(mask), hip.ptr(sam), 2, hip.ptr(pos), n, H, W, hip.ptr(rgb),
+                                         hip.ptr(uv), hip.ptr(om), hip.ptr(ex), hip.stream()), "mp_sample_pixels")
+    torch.cuda.synchronize()
+    for name, got, want in (("rgb", rgb, g["rgb"]), ("uv", uv, g["uv"]), ("object_mask", om, g["object_mask"]),
+                            ("sam_mask", ex, g["sam_mask"])):
+        want32 = want.astype(np.float32)
+        err = np.abs(got.cpu().numpy() - want32).max()
+        print(f"[parity] sample_pixels {name}: max |err| {err:.3e} (fp32 ulp of the value range {np.spacing(np.float32(np.abs(want32).max())):.1e})")
+        assert err <= 2 * np.spacing(np.float32(np.abs(want32).max())), name      # double arithmetic, one rounding
+    # argument errors, empty input
+    assert hip.lib().mp_sample_pixels(hip.ptr(img), hip.ptr(mask), None, 0, hip.ptr(pos), 0, H, W, hip.ptr(rgb), None, None,
+                                      None, hip.stream()) == 0
+    assert hip.lib().mp_sample_pixels(hip.ptr(img), hip.ptr(mask), None, 2, hip.ptr(pos), n, H, W, hip.ptr(rgb), None, None,
+                                      None, hip.stream()) == -1
+
+
+def test_dataset_items_match_the_cpu_oracle(tmp_path):
+    from multiply_amd.datasets import Hi4DDataset, Hi4DTestDataset, Hi4DValDataset
+    from multiply_amd.synthetic import write_sequence
+    from oracle.dataset_oracle import Hi4DDatasetOracle
+    root = str(tmp_path / "seq")
+    w = write_sequence(root, n_frames=4, H=72, W=96, with_edges=True)
+    ds = Hi4DDataset(_opt(root, start_frame=1, end_frame=4), rng=np.random.RandomState(11))
+    ora = Hi4DDatasetOracle(root, 1, 4, 64)
+    assert len(ds) == 3 and tuple(ds.img_size) == (72, 96) and ds.num_person == 2
+    assert ds.store.images.dtype == torch.uint8 and ds.store.images.is_cuda and ds.store.images.shape == (3, 72, 96, 3)
+    rs = np.random.RandomState(11)
+    for idx in (2, 0):
+        inputs, images = ds[idx]
+        want_in, want_im = ora.__getitem__(idx, rng=rs)
+        torch.cuda.synchronize()
+        assert inputs["uv"].is_cuda and images["rgb"].is_cuda
+        assert np.abs(inputs["uv"].cpu().numpy() - want_in["uv"]).max() <= 1e-5
+        assert np.abs(images["rgb"].cpu().numpy() - want_im["rgb"]).max() <= 1.2e-7
+        assert np.array_equal(inputs["index_outside"], want_in["index_outside"]) and inputs["idx"] == idx
+        assert torch.equal(inputs["smpl_params"], torch.from_numpy(want_in["smpl_params"]))
+        assert np.abs(inputs["intrinsics"].numpy() - want_in["intrinsics"]).max() < 1e-4
+        assert np.abs(inputs["pose"].numpy() - want_in["pose"]).max() < 1e-6
+        assert np.allclose(inputs["P"], want_in["P"]) and np.allclose(inputs["C"], want_in["C"])
+        assert inputs["org_img"].shape == (72, 96, 3) and inputs["is_certain"] is True
+    # full-frame items (num_sample = 0), the validation and test wrappers
+    full = Hi4DDataset(_opt(root, num_sample=0))
+    fin, fim = full[1]
+    oin, oim = Hi4DDatasetOracle(root, 0, 3, 0)[1]
+    assert torch.equal(fin["uv"].cpu(), torch.from_numpy(oin["uv"]))
+    assert np.abs(fim["rgb"].cpu().numpy() - oim["rgb"]).max() <= 1.2e-7
+    assert np.array_equal(fin["org_object_mask"].cpu().numpy(), oin["org_object_mask"])
+    val = Hi4DValDataset(_opt(root, num_sample=0), rng=np.random.RandomState(3))
+    vin, vim = val[0]
+    assert len(val) == 1 and vin["image_id"] == vin["idx"] and vim["pixel_per_batch"] == 512 and vim["total_pixels"] == 72 * 96
+    test = Hi4DTestDataset(_opt(root, num_sample=0))
+    tin, tim, ppb, total, i = test[2]
+    assert (ppb, total, i) == (512, 72 * 96, 2) and tin["img_size"].tolist() == [72, 96] and "org_img" in tim
+    # the model consumes an item as it is (batch dimension added by the DataLoader's collate in the reference)
+    assert fin["uv"].shape == (72 * 96, 2) and fin["smpl_params"].shape == (2, 86)
+
+
+def test_edge_sampling_picks_like_the_reference():
+    """edge_sampling (Hi4D.py:28-56): same randint stream -> same pixels; checked through the dataset's code path on the
+    golden frame (the reference function's outputs are in the golden file)."""
+    g = np.load(GOLD)
+    H, W = g["img"].shape[:2]
+    n = int(g["edge_n"])
+    mask = g["person"].sum(0)
+    edge = np.logical_and(mask, g["edge"])
+    rng = np.random.RandomState(int(g["edge_seed"]))
+    n_mask, n_edge = int(n * 0.5), int(n * 0.4)
+    mask_loc, edge_loc = np.where(mask.reshape(-1))[0], np.where(edge.reshape(-1))[0]
+    pick = np.concatenate([mask_loc[rng.randint(0, len(mask_loc), n_mask)], edge_loc[rng.randint(0, len(edge_loc), n_edge)],
+                           rng.randint(0, H * W, n - n_mask - n_edge)])
+    dev = torch.device("cuda")
+    img = torch.from_numpy(g["img"]).to(dev).float() / 255
+    rows, cols = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing="ij")
+    uv = torch.stack([cols, rows], -1).float().reshape(-1, 2)
+    p = torch.from_numpy(pick).to(dev)
+    assert np.abs(uv[p].cpu().numpy() - g["edge_uv"]).max() == 0
+    assert np.abs(img.reshape(-1, 3)[p].cpu().numpy() - g["edge_rgb"].astype(np.float32)).max() <= 1.2e-7
