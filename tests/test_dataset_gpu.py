@@ -108,3 +108,39 @@ def test_edge_sampling_picks_like_the_reference():
     p = torch.from_numpy(pick).to(dev)
     assert np.abs(uv[p].cpu().numpy() - g["edge_uv"]).max() == 0
     assert np.abs(img.reshape(-1, 3)[p].cpu().numpy() - g["edge_rgb"].astype(np.float32)).max() <= 1.2e-7
+
+
+def test_sequence_on_disk_to_training_step(tmp_path):
+    """disk -> Hi4DDataset -> DataLoader(num_workers=0) -> the reference's training_step input preparation
+    (multiply_model.py:162-192) -> Multiply.forward (train) -> Loss -> backward"""
+    import warnings
+    warnings.filterwarnings("ignore")
+    from multiply_amd.config import load_config
+    from multiply_amd.datasets import Hi4DDataset
+    from multiply_amd.loss import Loss
+    from multiply_amd.multiply import Multiply
+    from multiply_amd.synthetic import make_smpl_tables, write_sequence
+    root = str(tmp_path / "seq")
+    w = write_sequence(root, n_frames=3, H=64, W=64)
+    ds = Hi4DDataset(_opt(root, num_sample=96), rng=np.random.RandomState(2))
+    loader = torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False, num_workers=0)
+    opt = load_config()
+    torch.manual_seed(0)
+    model = Multiply(opt, w["shape"], smpl_tables=make_smpl_tables(0)).train()
+    loss_fn = Loss(opt.loss)
+    inputs, targets = next(iter(loader))
+    assert inputs["uv"].shape == (1, 96, 2) and inputs["uv"].is_cuda and targets["rgb"].shape == (1, 96, 3)
+    assert inputs["smpl_params"].shape == (1, 2, 86) and inputs["intrinsics"].shape == (1, 4, 4)
+    inputs["smpl_pose"] = inputs["smpl_params"][..., 4:76]
+    inputs["smpl_shape"] = inputs["smpl_params"][..., 76:]
+    inputs["smpl_trans"] = inputs["smpl_params"][..., 1:4]
+    inputs["smpl_pose_last"] = inputs["smpl_pose"]      # the opt_smpl branch provides it (multiply_model.py:172-180)
+    inputs["current_epoch"] = 301
+    out = model(inputs)
+    loss = loss_fn(out, targets)["loss"]
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss) and out["rgb_values"].shape == (96, 3)
+    g = model.foreground_implicit_network_list[0].lin0.weight_v.grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
+    assert out["index_outside"] is not None
