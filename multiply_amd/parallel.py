@@ -169,3 +169,52 @@ def render_person_sharded(model, input, canonical_pose=False):
     torch.cuda.synchronize()                                  # the pointer tables / blocks above must outlive the launch
     out.update(acc_map=acc_map, acc_person_list=acc_person)
     return out, (s0, s0 + n_my)
+
+
+# ======================================================================================================================
+# Person-sharded TRAINING: rank g owns the networks and SMPL state of persons {p : p % world == g}.
+#   forward : each rank samples + evaluates its persons for all rays; ONE all_gather moves the per-sample rows
+#             [ray, z, sdf, rgb, normal] (+ eikonal gradients, in/off-surface flags) of every person to every rank
+#             (2.6 MB per person at 512 rays x 161 samples); every rank then composites all 512 rays and evaluates the
+#             loss, so the compositing adjoint needs no second exchange; the background branch is sliced by rays and its
+#             colours all-gathered (6 KB).
+#   backward: the compositing adjoint gives d(sdf, rgb) for all persons on every rank; each rank back-propagates its
+#             own persons.  Person networks are rank-private (no collective); density.beta's gradient is identical on
+#             all ranks; the background networks' and the frame code's gradients are partial sums over the rank's ray
+#             slice -> PersonShardedGradSync (one flat all-reduce, 0.58 M floats).
+# ======================================================================================================================
+def train_person_sharded(model, input, cond_zero_shit=False, canonical_pose=False, draws=None):
+    """Training-mode Multiply.forward with the persons sharded over the ranks; same output dict on every rank."""
+    from . import train
+    assert model.training
+    return train.forward_train(model, input, -1, cond_zero_shit, canonical_pose, draws=draws,
+                               shard=(dist.get_world_size(), dist.get_rank()))
+
+
+class PersonShardedGradSync:
+    """After loss.backward() of a person-sharded step: sums the gradients of the parameters every rank holds a partial
+    gradient for (background networks, frame latent codes) in ONE flat all-reduce, and leaves alone what is rank-private
+    (the person networks; other ranks' copies get no gradient) or already identical (density.beta)."""
+
+    def __init__(self, model):
+        self.params = [p for m in (model.bg_implicit_network, model.bg_rendering_network, model.frame_latent_encoder)
+                       for p in m.parameters() if p.requires_grad]
+        self.flat = None
+
+    def __call__(self):
+        if not dist.is_initialized() or dist.get_world_size() == 1:
+            return
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        if self.flat is None or self.flat.numel() != n:
+            self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        o = 0
+        for p in self.params:
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            self.flat[o:o + p.numel()] = g.reshape(-1)
+            o += p.numel()
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        o = 0
+        for p in self.params:
+            p.grad = self.flat[o:o + p.numel()].reshape(p.shape).clone()
+            o += p.numel()

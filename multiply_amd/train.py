@@ -17,6 +17,7 @@ import math
 
 import numpy as np
 import torch
+import torch.distributed as dist
 
 from . import hip
 
@@ -452,9 +453,12 @@ def make_draws(model, cx, gen=None):
 class TrainGraph:
     """Everything one training forward keeps for its backward."""
 
-    def __init__(self, model, cx, input, cond_zero, draws, surface_flags=False, pose_grad=False):
+    def __init__(self, model, cx, input, cond_zero, draws, surface_flags=False, pose_grad=False, shard=None):
+        """shard = (world, rank): person-sharded training: cx holds only this rank's persons
+        {p : p % world == rank}; their per-sample rows are all-gathered once in the forward, every rank composites all rays
+        (512 of them: cheaper than a second exchange in the backward), the background branch is ray-sliced."""
         self.model, self.cx, self.input, self.cond_zero, self.draws = model, cx, input, cond_zero, draws
-        self.surface_flags, self.pose_grad = surface_flags, pose_grad
+        self.surface_flags, self.pose_grad, self.shard = surface_flags, pose_grad, shard
 
     # ---- forward ------------------------------------------------------------------------------------------------
     def run(self):
@@ -515,6 +519,60 @@ class TrainGraph:
                               nn_cano=nn_cano)
             z_l.append(zfinal); sdf_l.append(sdf); rgb_l.append(rt.rgb); nrm_l.append(nrm); inv_l.append(pp["inv_index"])
 
+        all_persons = list(persons)
+        self.remote = {}
+        s0, s1 = 0, R
+        if self.shard is not None:
+            world, rank = self.shard
+            P_total = int(self.input["smpl_trans"].shape[1])
+            all_persons = list(range(P_total))
+            n_slot = (P_total + world - 1) // world
+            E = N_EIKONAL
+            width = NZ + 7 * S + 3                                   # z, sdf, rgb3, nrm3 per sample; hit, off, in flags
+            send = torch.zeros(n_slot, R * width + E * 3, **f32)
+            for j, p in enumerate(persons):
+                f, pp = self.fg[p], cx["per"][p]
+                n_hit = int(cx["n_hit"][j])
+                rows = pp["hit_index"][:n_hit].long()
+                dense = torch.zeros(R, width, **f32)
+                dense[rows, :NZ] = f["zfinal"][:n_hit]
+                dense[rows, NZ:NZ + S] = f["sdf"][:n_hit * S].reshape(n_hit, S)
+                dense[rows, NZ + S:NZ + 4 * S] = f["rt"].rgb[:n_hit * S].reshape(n_hit, 3 * S)
+                dense[rows, NZ + 4 * S:NZ + 7 * S] = f["nrm"][:n_hit * S].reshape(n_hit, 3 * S)
+                dense[rows, NZ + 7 * S] = 1.0
+                if f["flags"] is not None:
+                    dense[rows, NZ + 7 * S + 1] = f["flags"][0][:n_hit].float()
+                    dense[rows, NZ + 7 * S + 2] = f["flags"][1][:n_hit].float()
+                send[j, :R * width] = dense.reshape(-1)
+                send[j, R * width:] = f["gth"].reshape(-1)
+            bufs = [torch.empty_like(send) for _ in range(world)]
+            dist.all_gather(bufs, send)                               # THE exchange step of the forward
+            ar = torch.arange(R, device=dev, dtype=torch.int32)
+            for p in all_persons:
+                if p in self.fg:
+                    continue
+                blk = bufs[p % world][p // world]
+                d = blk[:R * width].reshape(R, width)
+                hit = d[:, NZ + 7 * S] > 0.5
+                self.remote[p] = dict(z=d[:, :NZ].contiguous(), sdf=d[:, NZ:NZ + S].contiguous(),
+                                      rgb=d[:, NZ + S:NZ + 4 * S].contiguous(), nrm=d[:, NZ + 4 * S:NZ + 7 * S].contiguous(),
+                                      inv=torch.where(hit, ar, torch.full_like(ar, -1)).contiguous(), hit=hit,
+                                      off=d[:, NZ + 7 * S + 1] > 0.5, inn=d[:, NZ + 7 * S + 2] > 0.5,
+                                      gth=blk[R * width:].reshape(E, 3).contiguous())
+            z_l, sdf_l, rgb_l, nrm_l, inv_l = [], [], [], [], []
+            for p in all_persons:
+                if p in self.fg:
+                    f = self.fg[p]
+                    z_l.append(f["zfinal"]); sdf_l.append(f["sdf"]); rgb_l.append(f["rt"].rgb); nrm_l.append(f["nrm"])
+                    inv_l.append(cx["per"][p]["inv_index"])
+                else:
+                    r = self.remote[p]
+                    z_l.append(r["z"]); sdf_l.append(r["sdf"]); rgb_l.append(r["rgb"]); nrm_l.append(r["nrm"]); inv_l.append(r["inv"])
+            n_slice = (R + world - 1) // world
+            s0, s1 = min(R, rank * n_slice), min(R, (rank + 1) * n_slice)
+            self.n_slice = n_slice
+        self.all_persons, self.ray_slice = all_persons, (s0, s1)
+
         # ---- background (multiply.py:482-484, 514-539); depths jittered per ray in training (ray_sampler.py:32-40)
         self.bg = None
         bg_rgb = None
@@ -523,38 +581,51 @@ class TrainGraph:
             self.frame = int(torch.as_tensor(self.input[key]).reshape(-1)[0])
             code = m.frame_latent_encoder.weight.detach()[self.frame].contiguous()
             NB = rs.N_samples_inverse_sphere
-            t = torch.linspace(0.0, 1.0, NB, device=dev)[None].expand(R, NB)
+            Rb = s1 - s0                                              # this rank's rays of the background branch
+            bdirs = dirs[s0:s1].contiguous()
+            t = torch.linspace(0.0, 1.0, NB, device=dev)[None].expand(Rb, NB)
             mids = 0.5 * (t[:, 1:] + t[:, :-1])
             upper = torch.cat([mids, t[:, -1:]], -1); lower = torch.cat([t[:, :1], mids], -1)
-            zb = lower + (upper - lower) * self.draws["bg_rand"]
+            zb = lower + (upper - lower) * self.draws["bg_rand"][s0:s1]
             zbg = torch.flip(zb * (1.0 / rs.scene_bounding_sphere), dims=[-1]).contiguous()
-            pts = torch.empty(R * NB, 4, **f32)
-            cam = pose.reshape(4, 4)[:3, 3].contiguous()
-            _chk(L.mp_tr_bg_points(_p(dirs), _p(cam), _p(zbg), R, NB, C.c_float(m.sdf_bounding_sphere), _p(pts), st),
-                 "mp_tr_bg_points")
-            bit = ImplicitTrain(m.bg_implicit_network, pts, code, fwd=False)
-            drep = dirs[:, None, :].expand(R, NB, 3).reshape(-1, 3).contiguous()
-            XAb = torch.empty(R * NB, 27, **f32)
-            _chk(L.mp_tr_pe(_p(drep), 3, R * NB, 4, 0, C.c_float(1.0), _p(XAb), 27, 0, st), "mp_tr_pe")
-            brt = RenderTrain(m.bg_rendering_network, XAb, off(bit.out, 1), 257, R * NB, code)
-            sdfb = torch.empty(R * NB, **f32)
-            _chk(L.mp_tr_copy_cols(_p(bit.out), 257, 0, _p(sdfb), 1, 0, R * NB, 1, C.c_float(1.0), 0, st), "mp_tr_copy_cols")
-            bg_rgb = torch.empty(R, 3, **f32)
-            _chk(L.mp_tr_bg_comp_fwd(_p(sdfb), _p(brt.rgb), _p(zbg), R, NB, _p(bg_rgb), st), "mp_tr_bg_comp_fwd")
-            self.bg = dict(it=bit, rt=brt, zbg=zbg, sdfb=sdfb, XAb=XAb, NB=NB, code=code, pts=pts)
+            bg_rgb = torch.zeros(R, 3, **f32)
+            if Rb > 0:
+                pts = torch.empty(Rb * NB, 4, **f32)
+                cam = pose.reshape(4, 4)[:3, 3].contiguous()
+                _chk(L.mp_tr_bg_points(_p(bdirs), _p(cam), _p(zbg), Rb, NB, C.c_float(m.sdf_bounding_sphere), _p(pts), st),
+                     "mp_tr_bg_points")
+                bit = ImplicitTrain(m.bg_implicit_network, pts, code, fwd=False)
+                drep = bdirs[:, None, :].expand(Rb, NB, 3).reshape(-1, 3).contiguous()
+                XAb = torch.empty(Rb * NB, 27, **f32)
+                _chk(L.mp_tr_pe(_p(drep), 3, Rb * NB, 4, 0, C.c_float(1.0), _p(XAb), 27, 0, st), "mp_tr_pe")
+                brt = RenderTrain(m.bg_rendering_network, XAb, off(bit.out, 1), 257, Rb * NB, code)
+                sdfb = torch.empty(Rb * NB, **f32)
+                _chk(L.mp_tr_copy_cols(_p(bit.out), 257, 0, _p(sdfb), 1, 0, Rb * NB, 1, C.c_float(1.0), 0, st),
+                     "mp_tr_copy_cols")
+                bg_slice = torch.empty(Rb, 3, **f32)
+                _chk(L.mp_tr_bg_comp_fwd(_p(sdfb), _p(brt.rgb), _p(zbg), Rb, NB, _p(bg_slice), st), "mp_tr_bg_comp_fwd")
+                bg_rgb[s0:s1] = bg_slice
+                self.bg = dict(it=bit, rt=brt, zbg=zbg, sdfb=sdfb, XAb=XAb, NB=NB, code=code, pts=pts, Rb=Rb)
+            if self.shard is not None:                                # every rank composites all rays
+                pad = torch.zeros(self.n_slice, 3, **f32)
+                pad[:Rb] = bg_rgb[s0:s1]
+                parts = [torch.empty_like(pad) for _ in range(self.shard[0])]
+                dist.all_gather(parts, pad)
+                bg_rgb = torch.cat(parts, 0)[:R].contiguous()
         self.bg_rgb = bg_rgb
 
         # ---- compositing (multiply.py:425-480, 544-545)
         self.tabs = tuple(_table(ts, dev) for ts in (inv_l, z_l, sdf_l, rgb_l, nrm_l))
         t_inv, t_z, t_sdf, t_rgb, t_nrm = self.tabs
-        P = len(persons)
+        P = len(all_persons)
         rgb_values = torch.empty(R, 3, **f32); fg_rgb_values = torch.empty(R, 3, **f32)
         normal_values = torch.empty(R, 3, **f32); acc_map = torch.empty(R, **f32)
         acc_person = torch.empty(R, P, **f32); bg_T = torch.empty(R, **f32)
         _chk(L.mp_composite(R, P, NZ, _p(t_inv), _p(t_z), _p(t_sdf), _p(t_rgb), _p(t_nrm), _p(beta),
                             _p(bg_rgb) if bg_rgb is not None else None, _p(rgb_values), _p(fg_rgb_values),
                             _p(normal_values), _p(acc_map), _p(acc_person), _p(bg_T), st), "mp_composite")
-        grad_theta = torch.cat([self.fg[p]["gth"] for p in persons], 0)[None]       # multiply.py:565
+        grad_theta = torch.cat([self.fg[p]["gth"] if p in self.fg else self.remote[p]["gth"] for p in all_persons],
+                               0)[None]                                            # multiply.py:565
         self.bg_T = bg_T
         self.NZ = NZ
         return rgb_values, normal_values, acc_map, acc_person, grad_theta
@@ -567,12 +638,15 @@ class TrainGraph:
         st = hip.stream()
         f32 = dict(dtype=F32, device=dev)
         persons = cx["persons"]
-        P = len(persons)
+        all_persons = self.all_persons
+        P = len(all_persons)
+        S = self.NZ - 1
         t_inv, t_z, t_sdf, t_rgb, _ = self.tabs
         zero = lambda t, shape: torch.zeros(shape, **f32) if t is None else t.contiguous().float()
         d_rgb_values = zero(d_rgb_values, (R, 3)); d_acc_map = zero(d_acc_map, (R,)); d_acc_person = zero(d_acc_person, (R, P))
-        dsdf_l = [torch.zeros(self.fg[p]["npts"], **f32) for p in persons]
-        drgb_l = [torch.zeros(self.fg[p]["npts"], 3, **f32) for p in persons]
+        # remote persons (person-sharded mode) get scratch rows: their owners compute the same compositing adjoint
+        dsdf_l = [torch.zeros(self.fg[p]["npts"] if p in self.fg else R * S, **f32) for p in all_persons]
+        drgb_l = [torch.zeros(self.fg[p]["npts"] if p in self.fg else R * S, 3, **f32) for p in all_persons]
         d_bg_rgb = torch.zeros(R, 3, **f32)
         d_beta = torch.zeros(1, **f32)
         t_dsdf, t_drgb = _table(dsdf_l, dev), _table(drgb_l, dev)
@@ -587,7 +661,8 @@ class TrainGraph:
             for prm, g in zip(obj.params(), obj.param_grads()):
                 grads[id(prm)] = g if id(prm) not in grads else grads[id(prm)] + g
 
-        for n, p in enumerate(persons):
+        for p in persons:
+            n = all_persons.index(p)                                  # position among the composited persons
             f = self.fg[p]
             it, rt, npts, Pt = f["it"], f["rt"], f["npts"], f["Pt"]
             rev = isinstance(it, ImplicitTrainRev)
@@ -622,10 +697,12 @@ class TrainGraph:
                 self.pose_grads[p] = dprm
         if self.bg is not None:
             b = self.bg
-            bit, brt, NB = b["it"], b["rt"], b["NB"]
-            rows = R * NB
+            bit, brt, NB, Rb = b["it"], b["rt"], b["NB"], b["Rb"]
+            rows = Rb * NB
+            s0, s1 = self.ray_slice
+            d_bg_slice = d_bg_rgb[s0:s1].contiguous()
             dsdfb = torch.empty(rows, **f32); drgbb = torch.empty(rows, 3, **f32)
-            _chk(L.mp_tr_bg_comp_bwd(_p(b["sdfb"]), _p(brt.rgb), _p(b["zbg"]), R, NB, _p(d_bg_rgb), _p(dsdfb), _p(drgbb),
+            _chk(L.mp_tr_bg_comp_bwd(_p(b["sdfb"]), _p(brt.rgb), _p(b["zbg"]), Rb, NB, _p(d_bg_slice), _p(dsdfb), _p(drgbb),
                                      st), "mp_tr_bg_comp_bwd")
             dZ8b = torch.zeros(rows, 257, **f32)
             dXAb = torch.empty(rows, 27, **f32)
@@ -667,7 +744,7 @@ class _TrainFn(torch.autograd.Function):
         return (None, *body) + tuple(g.get(id(p)) for p in ctx.params)
 
 
-def forward_train(model, input, id=-1, cond_zero_shit=False, canonical_pose=False, draws=None):
+def forward_train(model, input, id=-1, cond_zero_shit=False, canonical_pose=False, draws=None, shard=None):
     """Multiply.forward with self.training == True.  Returns the reference's 19-key dict (multiply.py:566-588); the five
     tensors rgb_values / acc_map / acc_person_list / grad_theta (/ normal_values, not differentiable) hang off ONE autograd
     node whose backward is the hand-written adjoint sweep."""
@@ -675,6 +752,9 @@ def forward_train(model, input, id=-1, cond_zero_shit=False, canonical_pose=Fals
     if model.smpl_surface_weight > 0 or model.zero_pose_weight > 0:
         raise NotImplementedError("the smpl_surface / zero_pose regularisers (multiply.py:336-394, weight 0 in the shipped "
                                   "configs) are not built; set their weights to 0")
+    if shard is not None:                   # person-sharded: this rank evaluates persons {p : p % world == rank}
+        assert id == -1, "person-sharded training renders all persons"
+        id = [p for p in range(int(input["smpl_trans"].shape[1])) if p % shard[0] == shard[1]]
     cx = model._setup(input, id, canonical_pose)
     dev = cx["dev"]
     cond_zero = epoch < 20 or epoch % 20 == 0 or bool(cond_zero_shit)              # multiply.py:271-273
@@ -682,29 +762,41 @@ def forward_train(model, input, id=-1, cond_zero_shit=False, canonical_pose=Fals
         draws = make_draws(model, cx)
     body = [input["smpl_pose"], input["smpl_trans"], input["smpl_shape"]]
     pose_grad = (not canonical_pose) and any(torch.is_tensor(t) and t.requires_grad for t in body)
-    graph = TrainGraph(model, cx, input, cond_zero, draws, surface_flags=epoch < 250, pose_grad=pose_grad)
+    graph = TrainGraph(model, cx, input, cond_zero, draws, surface_flags=epoch < 250, pose_grad=pose_grad, shard=shard)
     params = [p for p in model.parameters() if p.requires_grad]
     with torch.enable_grad():                                                       # multiply.py:176
         rgb_values, normal_values, acc_map, acc_person, grad_theta = _TrainFn.apply(graph, *body, *params)
         temporal_loss = torch.zeros(1, device=dev)
         if epoch > 250:                                                             # multiply.py:242-243
             temporal_loss = torch.mean(torch.square(input["smpl_pose_last"].to(dev) - input["smpl_pose"].to(dev)))
-    last = cx["persons"][-1]
-    fl = graph.fg[last]
-    hit = cx["per"][last]["hit_index"][:fl["Rp"]].long()
+    last = graph.all_persons[-1]
     cam = cx["pose"].reshape(4, 4)[:3, 3]
-    points = cam[None, None, :] + fl["zfinal"][:, :-1, None] * cx["dirs"][hit][:, None, :]
+    if last in graph.fg:
+        fl = graph.fg[last]
+        hit = cx["per"][last]["hit_index"][:fl["Rp"]].long()
+        points = cam[None, None, :] + fl["zfinal"][:, :-1, None] * cx["dirs"][hit][:, None, :]
+    else:                                   # person-sharded: the last person lives on another rank
+        rl = graph.remote[last]
+        hit = torch.nonzero(rl["hit"]).flatten()
+        if hit.numel() == 0:
+            hit = torch.zeros(1, dtype=torch.long, device=dev)      # the reference's empty-hit fallback, multiply.py:262-263
+        points = cam[None, None, :] + rl["z"][hit][:, :-1, None] * cx["dirs"][hit][:, None, :]
     zeros1 = lambda: torch.zeros(1, device=dev)
     index_off_surface = index_in_surface = None
     if epoch < 250:                                                                 # multiply.py:549-557
-        P = len(cx["persons"])
+        P = len(graph.all_persons)
         off_all = torch.ones(cx["R"], P, dtype=torch.bool, device=dev)
         in_all = torch.zeros(cx["R"], P, dtype=torch.bool, device=dev)
-        for n, p in enumerate(cx["persons"]):
-            f = graph.fg[p]
-            rays = cx["per"][p]["hit_index"][:f["Rp"]].long()
-            off_all[rays, n] = f["flags"][0]
-            in_all[rays, n] = f["flags"][1]
+        for n, p in enumerate(graph.all_persons):
+            if p in graph.fg:
+                f = graph.fg[p]
+                rays = cx["per"][p]["hit_index"][:f["Rp"]].long()
+                off_all[rays, n] = f["flags"][0]
+                in_all[rays, n] = f["flags"][1]
+            else:
+                r = graph.remote[p]
+                off_all[:, n] = torch.where(r["hit"], r["off"], off_all[:, n])
+                in_all[:, n] = torch.where(r["hit"], r["inn"], in_all[:, n])
         index_off_surface, index_in_surface = off_all.all(dim=1), in_all.any(dim=1)
     out = {
         "zero_pose_loss": zeros1(), "t_list": [], "fg_rgb_values_each_person_list": [],

@@ -92,3 +92,50 @@ def test_two_rank_gradient_allreduce():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res)
+
+
+def _sharded_sync_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+
+    class M(torch.nn.Module):          # the attribute surface PersonShardedGradSync touches
+        def __init__(self):
+            super().__init__()
+            self.bg_implicit_network = torch.nn.Linear(4, 3)
+            self.bg_rendering_network = torch.nn.Linear(3, 2)
+            self.frame_latent_encoder = torch.nn.Embedding(5, 3)
+            self.foreground_implicit_network_list = torch.nn.ModuleList([torch.nn.Linear(2, 2), torch.nn.Linear(2, 2)])
+    m = M()
+    # partial gradients of the shared parameters (each rank's ray slice); the person networks are rank-private
+    for i, p in enumerate(list(m.bg_implicit_network.parameters()) + list(m.bg_rendering_network.parameters())):
+        p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+    if rank == 0:
+        m.frame_latent_encoder.weight.grad = torch.ones(5, 3)          # rank 1 has none: treated as zeros
+    mine = m.foreground_implicit_network_list[rank]
+    mine.weight.grad = torch.full((2, 2), 7.0 + rank)
+    parallel.PersonShardedGradSync(m)()
+    ok = True
+    for i, p in enumerate(list(m.bg_implicit_network.parameters()) + list(m.bg_rendering_network.parameters())):
+        ok = ok and torch.equal(p.grad, torch.full_like(p, 3.0 * (i + 1)))           # SUM over the two ranks
+    ok = ok and torch.equal(m.frame_latent_encoder.weight.grad, torch.ones(5, 3))
+    ok = ok and torch.equal(mine.weight.grad, torch.full((2, 2), 7.0 + rank))        # untouched
+    ok = ok and m.foreground_implicit_network_list[1 - rank].weight.grad is None     # the other rank's person: none
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok))
+
+
+def test_person_sharded_grad_sync_sums_only_the_shared_parameters():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sharded_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)

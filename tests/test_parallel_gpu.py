@@ -9,10 +9,20 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_person_sharded_render_matches_single_process():
+def _run_two_ranks(script, port_base):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29600 + os.getpid() % 300), os.path.join(root, "tests", "dist_person_sharded.py")]
+           "--master-port", str(port_base + os.getpid() % 300), os.path.join(root, "tests", script)]
     r = subprocess.run(cmd, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     print(r.stdout[-3000:])
     assert r.returncode == 0
+
+
+def test_person_sharded_render_matches_single_process():
+    _run_two_ranks("dist_person_sharded.py", 29600)
+
+
+def test_person_sharded_training_matches_single_process():
+    """loss, outputs and every local gradient of a person-sharded training step (one all_gather of the per-sample rows in the
+    forward, one flat all-reduce of the background gradients after the backward) equal the single-process step"""
+    _run_two_ranks("dist_person_sharded_train.py", 29950)
