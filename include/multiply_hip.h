@@ -316,6 +316,31 @@ int mp_sample_pixels(const unsigned char* img, const unsigned char* mask, const 
                      const double* pos, int n, int H, int W, float* rgb, float* uv, float* mask_out, float* extra_out,
                      void* stream);
 
+/* ---- canonical-mesh extraction (code/lib/libmise/mise.pyx: MISE.__cinit__ :33-78, update :80-97, query :99-120,
+ * to_dense :122-154, subdivide_voxels :172-222; driver code/lib/utils/mesh.py:78-131) on a DENSE lattice:
+ * resolution R = res0 << depth, n = R + 1 points per axis.  state [n^3] bytes (0 no grid point, 1 unknown, 2 known),
+ * val [n^3] fp32, vox / pos / neg [sum_l (res0<<l)^3, l = 0..depth] bytes (voxel tree: 0 absent, 1 leaf, 2 split; and
+ * the "touches a value >= / <= threshold" flags, which the caller zeroes before every mp_mise_refine).
+ *   mp_mise_init    : level-0 voxels are leaves, their corners are unknown grid points
+ *   mp_mise_collect : packs the unknown grid points (x, y, z ints, unspecified order) -> out_xyz, *count (device int,
+ *                     zeroed by the caller; may exceed max_out, then only max_out were written)
+ *   mp_mise_scatter : stores the values of `count` queried points and marks them known
+ *   mp_mise_refine  : one update step: mark leaves from ALL known points, split the active ones (*n_split += splits)
+ *   mp_mise_fill    : to_dense: holes inherit the previous value along x, then y, then z
+ * Marching cubes over the dense values (skimage.measure.marching_cubes in the reference, third party): tri_table
+ * [256][16] ints (edge triples, -1 terminated; corner / edge numbering of csrc/mise.hip), case bit k = corner k below
+ * `level`; mp_mc_count -> triangles per cube [(n-1)^3]; mp_mc_emit with exclusive-scan offsets -> verts [3T][3] in
+ * lattice units and edge_id [3T] (equal ids = same mesh vertex). */
+int mp_mise_init(int res0, int depth, unsigned char* state, unsigned char* vox, void* stream);
+int mp_mise_collect(int n, const unsigned char* state, int* count, int max_out, int* out_xyz, void* stream);
+int mp_mise_scatter(int n, const int* xyz, const float* values, int count, unsigned char* state, float* val, void* stream);
+int mp_mise_refine(int res0, int depth, float threshold, unsigned char* state, const float* val, unsigned char* vox,
+                   unsigned char* pos, unsigned char* neg, int* n_split, void* stream);
+int mp_mise_fill(int n, unsigned char* state, float* val, void* stream);
+int mp_mc_count(const float* val, int n, float level, const int* tri_table, int* counts, void* stream);
+int mp_mc_emit(const float* val, int n, float level, const int* tri_table, const long long* offsets, float* verts,
+               long long* edge_id, void* stream);
+
 /* library / device info: returns the gfx arch string compiled in, and checks the current device */
 const char* mp_arch(void);
 int mp_device_ok(void);
