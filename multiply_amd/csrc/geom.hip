@@ -694,6 +694,15 @@ int warp_grid(int n_slab, int nw) {
     return g < 1 ? 1 : (g > 256 ? 256 : g);
 }
 
+// Waves per workgroup of the warp kernels.  One workgroup per CU either way (its vertex structure fills 110 KB of LDS);
+// 16 waves amortise that fill over a whole frame's slabs, but a training call has only ~900 slabs (512 rays x 128
+// samples / 64) and would occupy 57 of the 256 CUs -- there, fewer waves per workgroup spread the slabs over the chip.
+int warp_threads(int n_slab) {
+    int nw = (n_slab + 255) / 256;          // waves per workgroup that give every CU a workgroup
+    nw = nw < 1 ? 1 : (nw > WARP_THREADS / 64 ? WARP_THREADS / 64 : nw);
+    return nw * 64;
+}
+
 }  // namespace
 
 extern "C" int mp_smpl_pose(const float* v_template, const float* shapedirs, const float* posedirs,
@@ -765,9 +774,9 @@ extern "C" int mp_warp_inverse(const float* pts, const float* dirs, const float*
     static int once = (int)hipFuncSetAttribute((const void*)k_warp_inverse, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                WARP_LDS);
     (void)once;
-    const int nw = WARP_THREADS / 64;
     const int n_slab = pts ? (max_rays + 63) / 64 : ((max_rays + 63) / 64) * n_s;
-    hipLaunchKernelGGL(k_warp_inverse, dim3(warp_grid(n_slab, nw)), dim3(WARP_THREADS), WARP_LDS, st, pts, dirs, pose,
+    const int threads = warp_threads(n_slab), nw = threads / 64;
+    hipLaunchKernelGGL(k_warp_inverse, dim3(warp_grid(n_slab, nw)), dim3(threads), WARP_LDS, st, pts, dirs, pose,
                        hit_index, hit_count, z, z_stride, n_s, max_rays, pts ? max_rays : 0, vsorted, cbound, skin_w, tfs,
                        mode & 3, ray_active, (const float*)nullptr, launch_active, xc, outlier, (unsigned char*)nullptr, sdf_out,
                        worklist, work_count, (int*)nullptr);
@@ -785,9 +794,9 @@ extern "C" int mp_warp_inverse_shade(const float* dirs, const float* pose, const
     static int once = (int)hipFuncSetAttribute((const void*)k_warp_inverse, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                WARP_LDS);
     (void)once;
-    const int nw = WARP_THREADS / 64;
     const int n_slab = ((max_rays + 63) / 64) * n_s;
-    hipLaunchKernelGGL(k_warp_inverse, dim3(warp_grid(n_slab, nw)), dim3(WARP_THREADS), WARP_LDS, st,
+    const int threads = warp_threads(n_slab), nw = threads / 64;
+    hipLaunchKernelGGL(k_warp_inverse, dim3(warp_grid(n_slab, nw)), dim3(threads), WARP_LDS, st,
                        (const float*)nullptr, dirs, pose, hit_index, hit_count, z, z_stride, n_s, max_rays, 0, vsorted,
                        cbound, skin_w, tfs, eval_mode ? 2 : 0, (const int*)nullptr, beta, (const int*)nullptr, xc, outlier,
                        need_flag, sdf_out, worklist, work_count, nn_index);
@@ -803,9 +812,9 @@ extern "C" int mp_warp_jacobian(const float* xc, const unsigned char* need, cons
     static int once = (int)hipFuncSetAttribute((const void*)k_warp_jacobian, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                WARP_LDS);
     (void)once;
-    const int nw = WARP_THREADS / 64;
     const int n_slab = n_s > 0 ? ((max_rays + 63) / 64) * n_s : (n_pts + 63) / 64;
-    hipLaunchKernelGGL(k_warp_jacobian, dim3(warp_grid(n_slab, nw)), dim3(WARP_THREADS), WARP_LDS, st, xc, need, hit_count,
+    const int threads = warp_threads(n_slab), nw = threads / 64;
+    hipLaunchKernelGGL(k_warp_jacobian, dim3(warp_grid(n_slab, nw)), dim3(threads), WARP_LDS, st, xc, need, hit_count,
                        max_rays, n_s, n_pts, vsorted_c, cbound_c, skin_w, tfs, jinv, nn_index, seed, verts_c);
     return (int)hipGetLastError();
 }
