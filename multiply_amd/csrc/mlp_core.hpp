@@ -395,14 +395,15 @@ constexpr int A_PF = 3, A_QN = 4;   // A-tile prefetch distance / rotating queue
 // K step of the next block that carries the first activation piece of a finished block.  The reverse sweep's pieces
 // (one multiplication each) sit in K steps 4..7, away from the MFMAs that produced their inputs: -8 % on k_mlp_grad;
 // the softplus pieces are best right at the start (+8 % on k_mlp_fwdsave when shifted).
-__device__ __forceinline__ constexpr int act_shift(int hid) { return hid == 3 /* HID_SIGMUL */ ? 4 : 0; }
+__device__ __forceinline__ constexpr int act_shift(int hid) { return hid == HID_SIGMUL ? 4 : 0; }
 
 // One layer.  Software pipeline: the activation of a finished 16-row block is issued, one piece per K step, inside the
 // MFMA stream of the next block (the two blocks of a chunk accumulate in two register sets, so nothing is copied);
 // A tiles run A_PF tiles ahead in a rotating register queue across block and chunk boundaries; the bias of the next
 // block is fetched one block ahead; weight chunks are loaded two chunks ahead into a 3-slot LDS ring (one barrier per
-// chunk).  Everything inside a block is straight-line code: a wave-uniform branch per K step costs issue slots AND
-// makes hipcc drain the LDS queue (s_waitcnt lgkmcnt(0)) where a partial wait would do.
+// chunk).  Everything inside a block is straight-line code (a wave-uniform branch per K step costs issue slots and
+// fences the scheduler), and its LDS waits are counted (s_waitcnt lgkmcnt(3)), which needs the weight DMA to be issued
+// from inline asm: see lds_dma_16.
 template <int NB, bool FWD, int KS_IN, int HID, int WAVES, bool HIDDEN, typename Cap, typename NB_T>
 __device__ __forceinline__ void run_layer(const NetDesc& net, const LayerDesc L, int l, const char* __restrict__ wpack,
                                           const float* bias_lds, char* wring, opx8 (&Bcur)[KS_REG][NB], NB_T& Bn,
