@@ -1,4 +1,4 @@
-"""CPU restatement of the reference's input producer -- TEST INFRASTRUCTURE ONLY (tests/, bench cpu baselines); the
+"""CPU restatement of the reference's input producer -- TEST INFRASTRUCTURE ONLY (tests/, incl. the CPU-baseline timing tests/bench_producer.py); the
 product path is multiply_amd/datasets.py + csrc/data.hip.
 
 Follows code/lib/datasets/Hi4D.py: bilinear_interpolation (:8-20), get_index_outside_of_bbox (:22-26),

@@ -1,9 +1,10 @@
 #!/usr/bin/env python
-"""Canonical-mesh extraction: multiply_amd.mesh (dense device lattice, whole-pass network queries, marching-cubes kernels)
+"""(Lives under tests/ because it runs the reference extractor built into oracle/_ref as the baseline.)
+Canonical-mesh extraction: multiply_amd.mesh (dense device lattice, whole-pass network queries, marching-cubes kernels)
 vs the reference's structure -- its own CPU octree extractor (oracle/_ref/mise*.so, built from code/lib/libmise/mise.pyx
 by `make -C oracle`) fed through 10 000-point network batches with a host round trip per batch
 (code/lib/utils/mesh.py:88-109; the marching cubes that follows there is skimage's and is not timed).
-    python tools/mesh_bench.py [res_up ...]      (default 2 4: the trainer's refresh and the validation setting)"""
+    python tests/bench_mesh.py [res_up ...]      (default 2 4: the trainer's refresh and the validation setting)"""
 import os
 import sys
 import time

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
-"""Input producer: items/s of the HBM-resident dataset (multiply_amd/datasets.py, one mp_sample_pixels launch per item)
+"""(Lives under tests/ because it times the CPU oracle as the baseline.)  Input producer: items/s of the HBM-resident dataset (multiply_amd/datasets.py, one mp_sample_pixels launch per item)
 vs the reference's per-item path restated on the CPU (oracle/dataset_oracle.py: decode the frame's PNGs, gather with
 numpy -- what one DataLoader worker of the reference does, code/lib/datasets/Hi4D.py:229-306).
-    python tools/producer_bench.py [frames=12] [H=940] [W=1280]"""
+    python tests/bench_producer.py [frames=12] [H=940] [W=1280]"""
 import os
 import sys
 import tempfile
