@@ -120,3 +120,11 @@ def test_cluster_perm_partitions_all_vertices(smpl_tables):
         ids = ids[ids >= 0]
         rad.append(np.linalg.norm(v[ids] - v[ids].mean(0), axis=1).max())
     assert np.mean(rad) < 0.15
+
+
+def test_docs_quote_the_current_number_of_entry_points():
+    hdr = open(os.path.join(REPO, "include", "multiply_hip.h")).read()
+    n = len(set(re.findall(r"\b(mp_[a-z_0-9]+)\s*\(", hdr)))
+    for doc in ("README.md", "DESIGN.md"):
+        quoted = re.findall(r"(\d+) `extern \"C\"` entry points", open(os.path.join(REPO, doc)).read())
+        assert quoted and all(int(q) == n for q in quoted), (doc, quoted, n)
