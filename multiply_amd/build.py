@@ -6,7 +6,10 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "libmultiply_hip.so")
+# MP_BUILD_TAG=<name> (+ MP_EXTRA_FLAGS=-D...): an ablation side library multiply_amd/ab_libs/libmultiply_hip_<name>.so
+# with its own object directory; load it with MP_LIB_PATH (tools/ab_run.sh).  Unset: the product library.
+TAG = os.environ.get("MP_BUILD_TAG", "")
+OUT = os.path.join(HERE, "ab_libs", f"libmultiply_hip_{TAG}.so") if TAG else os.path.join(HERE, "libmultiply_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + os.environ.get("MP_EXTRA_FLAGS", "").split()
 
 
@@ -22,8 +25,9 @@ def build(force=False, verbose=True):
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "multiply_hip.h"))
-    bdir = os.path.join(CSRC, "_build")
+    bdir = os.path.join(CSRC, "_build" + ("_" + TAG if TAG else ""))
     os.makedirs(bdir, exist_ok=True)
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
     jobs = []
     for s in srcs:
         src, obj = os.path.join(CSRC, s), os.path.join(bdir, s[:-4] + ".o")

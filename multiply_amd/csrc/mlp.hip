@@ -101,6 +101,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_sdf(const NetDesc net, const
     op_t* stage = (op_t*)(smem + L::stage) + wave * L::PTS * in_stride(KS_IN);
     load_bias(net, bias, bias_lds);
     for (int t = blockIdx.x; t * L::TILE < count; t += gridDim.x) {
+        MP_STAMP_AT(HID_SOFTPLUS, 120, 0);
         const int w = t * L::TILE + wave * L::PTS + lane;
         const int id = (lane < L::PTS && w < count) ? (worklist ? worklist[w] : w) : -1;
         if (lane < L::PTS) {
@@ -108,16 +109,20 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_sdf(const NetDesc net, const
             if (id >= 0) { x[0] = xc[3 * (size_t)id]; x[1] = xc[3 * (size_t)id + 1]; x[2] = xc[3 * (size_t)id + 2]; }
             stage_pe<3, 6, KS_IN>(stage + lane * in_stride(KS_IN), x);
         }
+        MP_STAMP_AT(HID_SOFTPLUS, 120, 1);
         opx8 Bcur[KS_REG][NB];
         f32x4 out[NB];
         zero_b<NB>(Bcur);
         prologue<KS_IN, WAVES>(net, wpack, smem + L::ring, wave, lane);  // barrier inside: staging rows visible
+        MP_STAMP_AT(HID_SOFTPLUS, 120, 2);
         run_net<NB, false, KS_IN, HID_SOFTPLUS, WAVES>(net, wpack, bias_lds, smem + L::ring, Bcur, stage, out, wave, lane);
+        MP_STAMP_AT(HID_SOFTPLUS, 120, 3);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int pid = __shfl(id, nb * 16 + (lane & 15));
             if (lane < 16 && pid >= 0) sdf_out[pid] = out[nb][0];
         }
+        MP_STAMP_AT(HID_SOFTPLUS, 121, 0);
     }
 }
 
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(512) void k_mlp_shade(const NetDesc net, const char
         opx8 Bcur[KS_REG][NB];
         f32x4 out[NB];
         zero_b<NB>(Bcur);
-        prologue<KS_IN, WAVES>(net, wpack, smem + L::ring, wave, lane);
+        prologue<KS_IN, WAVES, false>(net, wpack, smem + L::ring, wave, lane);
         run_net<NB, true, KS_IN, HID_SOFTPLUS, WAVES>(net, wpack, bias_lds, smem + L::ring, Bcur, stage, out, wave, lane);
         if ((lane & 8) == 0) {   // value columns: features of point lane&7
             const int lp = ((lane & 15) + 8 * (wave & 1)) + 16 * (lane >> 4);
@@ -309,6 +314,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_fwdsave(const NetDesc net, c
         f32x4 out[NB];
         zero_b<NB>(Bcur);
         prologue<KS_IN, WAVES>(net, wpack, smem + L::ring, wave, lane);
+        MP_STAMP_AT(HID_SOFTPLUS_SAVE, 120, 2);
         #ifdef MP_EXP_SIGCACHED   // ablation: every tile uses the first workgroup-slots of the buffer (cache resident)
         const SigIO sio = {sigbuf + ((size_t)(blockIdx.x) * WAVES + wave) * (size_t)(8 * SIG_LAYER), SIG_LAYER};
 #else
@@ -316,6 +322,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_fwdsave(const NetDesc net, c
 #endif
         run_net<NB, false, KS_IN, HID_SOFTPLUS_SAVE, WAVES>(net, wpack, bias_lds, smem + L::ring, Bcur, stage, out, wave, lane,
                                                             sio);
+        MP_STAMP_AT(HID_SOFTPLUS_SAVE, 120, 3);
         // features in the colour kernel's layout: tiles of 64 work items (offset is a multiple of 256), 4 blocks of 16 columns
         const size_t tile = (size_t)(offset / 64) + (size_t)t * 4 + (wave >> 1);
 #pragma unroll
@@ -390,9 +397,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_grad(const NetDesc net, cons
         }
         float g[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
         f32x4 out[NB];
+#ifdef MP_EXP_GRAD_OLD
+        prologue<KS_IN, WAVES, false>(net, wpack, smem, wave, lane);
+#else
         prologue<KS_IN, WAVES>(net, wpack, smem, wave, lane);   // barrier inside: tables visible
+#endif
+        MP_STAMP_AT(HID_SIGMUL, 120, 2);
         run_net<NB, false, KS_IN, HID_SIGMUL, WAVES, GradCapture>(net, wpack, nullptr, smem, Bcur, nullptr, out, wave, lane, sio,
                                                                    GradCapture{tabs, tabs + PTS * 48, g});
+        MP_STAMP_AT(HID_SIGMUL, 120, 3);
         GradCapture::unrotate(g);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -467,7 +480,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_color(const NetDesc net, con
                 Bcur[ks][nb] = live ? *(const opx8*)(feat_frag + (((size_t)tile * KS_REG + ks) * 4 + nb0 + nb) * 1024 + lane * 16)
                                     : (opx8)(op_t)0.0f;
         prologue<KS_IN, WAVES>(net, wpack, smem + L::ring, wave, lane);
+        MP_STAMP_AT(HID_RELU, 120, 2);
         run_net<NB, false, KS_IN, HID_RELU, WAVES>(net, wpack, bias_lds, smem + L::ring, Bcur, stage, out, wave, lane);
+        MP_STAMP_AT(HID_RELU, 120, 3);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int pid = __shfl(id, nb * 16 + (lane & 15));

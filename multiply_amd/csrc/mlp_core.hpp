@@ -117,9 +117,16 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #ifdef MP_EXP_STAMP   // ablation tooling: shader-clock stamps of workgroup 0 at every chunk boundary (mp_debug_stamps)
 __device__ unsigned long long mp_stamps[8 * 128 * 4];
-#define MP_STAMP(ev) do { if (blockIdx.x == 0 && lane == 0 && ci < 128) mp_stamps[((wave) * 128 + ci) * 4 + (ev)] = __builtin_amdgcn_s_memtime(); } while (0)
+#ifndef MP_STAMP_HID   // -DMP_STAMP_HID=<Hidden value>: only the kernels of that activation kind stamp (0 softplus, 1 relu,
+#define MP_STAMP_HID -1   // 2 softplus + stored sigmoids, 3 reverse sweep); default: every kernel, the last one launched survives
+#endif
+#define MP_STAMP_OK(hid) (MP_STAMP_HID < 0 || (hid) == MP_STAMP_HID)
+#define MP_STAMP(ev) do { if (MP_STAMP_OK(HID) && blockIdx.x == 0 && lane == 0 && ci < 120) mp_stamps[((wave) * 128 + ci) * 4 + (ev)] = __builtin_amdgcn_s_memtime(); } while (0)
+// tile-level stamps in slots 120..127 of the same table (tools/tile_timeline.py)
+#define MP_STAMP_AT(hid, slot, ev) do { if (MP_STAMP_OK(hid) && blockIdx.x == 0 && (threadIdx.x & 63) == 0) mp_stamps[((threadIdx.x >> 6) * 128 + (slot)) * 4 + (ev)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define MP_STAMP(ev)
+#define MP_STAMP_AT(hid, slot, ev)
 #endif
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -386,12 +393,336 @@ __device__ __forceinline__ void act_drain(const f32x4 (&p)[NB], NB_T& Bn, int pc
 #undef MP_SG
 }
 
+constexpr int A_PF = 3, A_QN = 4;   // A-tile prefetch distance / rotating queue length (tiles), interleaved stream
+#ifndef MP_PP_PF
+#define MP_PP_PF 3
+#endif
+constexpr int PP_PF = MP_PP_PF, PP_QN = PP_PF + 1;   // the same for the phase-separated stream (its M phase is dense)
+constexpr int AQ_LEN = PP_QN > A_QN ? PP_QN : A_QN;
+// ---------------------------------------------------------------------------------------------------------------------
+// Phase-separated ("ping-pong") hidden softplus layers, plain mode.
+//
+// Measured on MI355X (tools/valu_rate.hip, tools/issue_model.hip): packed-half VALU instructions cost 4 cycles of the
+// SIMD's vector pipe, v_exp/v_log 8, a wave issues at most one instruction per ~5 cycles, and MFMA 16x16x32 occupies
+// the matrix pipe for 16.  A softplus(+sigmoid) layer needs 52 (72) VALU-pipe cycles per row pair against 64 matrix-pipe
+// cycles: both pipes are needed almost all the time, so they must run CONCURRENTLY.  When both waves of a SIMD run the
+// same finely interleaved MFMA + activation stream they do not: the stream of act_piece keeps the matrix pipe ~30 % busy.
+// Here a wave's stream per weight chunk is two homogeneous phases,
+//     M(c): the chunk's 32 MFMAs back to back (4 independent accumulators: 2 row blocks x 2 column blocks), then
+//     V(c): the activation of its 8 row pairs in lock step (one instruction per pair and stage: every producer is 8
+//           instructions back -- no s_nop for the transcendental / SDWA result hazards, no dependent-issue stall),
+// and the two waves of a SIMD run them in ANTI-PHASE: waves 0..3 (one per SIMD) put the chunk barrier after V(c), waves
+// 4..7 between M(c) and V(c).  Between two barriers a SIMD therefore sees  [M(c) V(c)]  from one wave and
+// [V(c-1) M(c)]  from the other: one wave's MFMAs beside the other's VALU work.  The ring protocol is unchanged (every
+// wave passes one barrier per chunk, after its M(c): chunk c's slot may be refilled, chunk c+1 is complete), and V(c)
+// has a compile-time chunk index, so the run-time "drain" of the layer's last block does not exist on this path.
+// Arithmetic per element is exactly act_piece's.
+struct ActRegs8 {
+    unsigned z[8], u[8], lg[8], r[8], h[8], d[8], s[8];
+};
+// stages of the V program per layer kind (HIDDEN = false: the linear output layers, conversion only)
+__host__ __device__ constexpr int pp_stages(int hid, bool hidden) {
+    return !hidden ? 1 : hid == HID_SOFTPLUS_SAVE ? 11 : hid == HID_SOFTPLUS ? 8 : 2;
+}
+
+// stage ST for row pair q = 4 mbl + 2 nb + j  (mbl: 16-row block of the chunk, nb: column block, j: row pair)
+template <int HID, bool HIDDEN, int ST, int q, typename NB_T>
+__device__ __forceinline__ void pp_instr(ActRegs8& a, const f32x4 (&acc)[CHUNK_MB][2], NB_T& Bn, int c, u32x4 (&sg)[2]) {
+    constexpr int mbl = q / 4, nb = (q / 2) % 2, j = q % 2;
+    constexpr bool SP = HIDDEN && (HID == HID_SOFTPLUS || HID == HID_SOFTPLUS_SAVE);
+    if constexpr (ST == 0) {          // left to the compiler: it knows the MFMA -> VALU read hazard
+        a.z[q] = bits(to_h2(acc[mbl][nb][2 * j], acc[mbl][nb][2 * j + 1]));
+        if constexpr (!HIDDEN) {
+            if (c < KS_REG) Bn.put(c, nb, mbl, j, __builtin_bit_cast(h2, a.z[q]));
+        }
+    } else if constexpr (!SP) {       // ReLU / multiplication by the stored sigmoid: one packed instruction
+        static_assert(ST == 1 && HIDDEN, "pp_instr: stage");
+        h2 z = __builtin_bit_cast(h2, a.z[q]);
+        if constexpr (HID == HID_SIGMUL) {
+            // dword 2 mbl + j of the fragment, picked by NAME: hipcc 7.2 folds a subscript on the loaded u32x4 to
+            // element 0 here (same miscompile as noted at act_drain)
+            constexpr int e = 2 * mbl + j;
+            unsigned sv;
+            if constexpr (e == 0) sv = sg[nb].x;
+            else if constexpr (e == 1) sv = sg[nb].y;
+            else if constexpr (e == 2) sv = sg[nb].z;
+            else sv = sg[nb].w;
+            z = z * __builtin_bit_cast(h2, sv);
+        } else {
+            z = relu_h2(z);
+        }
+        if (c < KS_REG) Bn.put(c, nb, mbl, j, z);
+    } else if constexpr (ST == 1) {   // u = 2^-|z'|: low half (writes the dword), then the high half in place
+        asm volatile("v_exp_f16_sdwa %0, -|%1| dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(a.u[q]) : "v"(a.z[q]));
+    } else if constexpr (ST == 2) {
+        asm volatile("v_exp_f16_sdwa %0, -|%1| dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(a.u[q]) : "v"(a.z[q]));
+    } else if constexpr (ST == 3) {   // 1 + u
+        asm volatile("v_pk_add_f16 %0, %0, 1.0 op_sel_hi:[1,0]" : "+v"(a.u[q]));
+    } else if constexpr (ST == 4) {   // log2(1 + u)
+        asm volatile("v_log_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=&v"(a.lg[q]) : "v"(a.u[q]));
+    } else if constexpr (ST == 5) {
+        asm volatile("v_log_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(a.lg[q]) : "v"(a.u[q]));
+    } else if constexpr (ST == 6) {   // max(z', 0) on the bit pattern
+        asm volatile("v_pk_max_i16 %0, %1, 0" : "=v"(a.r[q]) : "v"(a.z[q]));
+    } else if constexpr (ST == 7) {   // h' = max(z', 0) + log2(1 + 2^-|z'|): the next layer's operand register as it stands
+        asm volatile("v_pk_add_f16 %0, %1, %2" : "=v"(a.h[q]) : "v"(a.r[q]), "v"(a.lg[q]));
+        if (c < KS_REG) Bn.put(c, nb, mbl, j, __builtin_bit_cast(h2, a.h[q]));
+    } else if constexpr (ST == 8) {   // z' - h'
+        asm volatile("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(a.d[q]) : "v"(a.z[q]), "v"(a.h[q]));
+    } else if constexpr (ST == 9) {   // sigmoid(z') = 2^(z' - h')
+        asm volatile("v_exp_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=&v"(a.s[q]) : "v"(a.d[q]));
+    } else {
+        static_assert(ST == 10, "pp_instr: stage");
+        asm volatile("v_exp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(a.s[q]) : "v"(a.d[q]));
+        constexpr int e = 2 * mbl + j;   // by name, see the note at the HID_SIGMUL read
+        if constexpr (e == 0) sg[nb].x = a.s[q];
+        else if constexpr (e == 1) sg[nb].y = a.s[q];
+        else if constexpr (e == 2) sg[nb].z = a.s[q];
+        else sg[nb].w = a.s[q];
+    }
+}
+template <int HID, bool HIDDEN, int I, typename NB_T>
+__device__ __forceinline__ void pp_program(ActRegs8& a, const f32x4 (&acc)[CHUNK_MB][2], NB_T& Bn, int c, u32x4 (&sg)[2]) {
+    if constexpr (I < 8 * pp_stages(HID, HIDDEN)) {
+        pp_instr<HID, HIDDEN, I / 8, I % 8>(a, acc, Bn, c, sg);
+        pp_program<HID, HIDDEN, I + 1>(a, acc, Bn, c, sg);
+    }
+}
+
+// Which weight chunks have register-fed / input-fed K steps (a chunk's unused tiles are never fetched): bit ci of the
+// two masks, built once per network from the layer table.
+struct ChunkMasks {
+    unsigned long long reg[2], in[2];
+    __device__ __forceinline__ bool has_reg(int ci) const { return ((ci < 64 ? reg[0] >> ci : reg[1] >> (ci - 64)) & 1ull) != 0; }
+    __device__ __forceinline__ bool has_in(int ci) const { return ((ci < 64 ? in[0] >> ci : in[1] >> (ci - 64)) & 1ull) != 0; }
+};
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {   // keeps the value in scalar registers
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ ChunkMasks chunk_masks(const NetDesc& net) {
+    unsigned long long r0 = 0, r1 = 0, i0 = 0, i1 = 0;
+    int ci = 0;
+    for (int l = 0; l < net.n_layers; ++l) {
+        const int n = net.layer[l].n_chunk;
+        // n consecutive bits from bit ci (n <= 9): split over the two words
+        const unsigned long long run = (1ull << n) - 1ull;
+        const unsigned long long lo = ci < 64 ? run << ci : 0ull;
+        const unsigned long long hi = ci >= 64 ? run << (ci - 64) : (ci + n > 64 ? run >> (64 - ci) : 0ull);
+        if (net.layer[l].use_reg) { r0 |= lo; r1 |= hi; }
+        if (net.layer[l].use_in) { i0 |= lo; i1 |= hi; }
+        ci += n;
+    }
+    return ChunkMasks{{uniform_u64(r0), uniform_u64(r1)}, {uniform_u64(i0), uniform_u64(i1)}};
+}
+
+// The phase-separated stream's weight DMA: issued by the LATE waves only (wl = wave - WAVES/2 = 0..3), right behind
+// their barrier, i.e. at the head of a V phase -- an LDS-DMA instruction costs 25-60 cycles to issue among VALU work
+// and 100-185 among MFMAs (MI355X_MICROARCH.md), and it is waited for a whole M phase later.  Pieces of chunk `cn` (1 KiB
+// each, chunk layout [row block][8 register-fed tiles | KS_IN input-fed tiles]): wave wl takes register-fed tiles
+// {wl, wl + 4} of both row blocks and input-fed pieces {wl, wl + 4} of the 2 KS_IN; tiles the chunk's layer never
+// multiplies are skipped.  Addressing: ONE scalar source base per chunk + per-piece lane offsets prepared once per
+// network (DmaLanes), the LDS destination through M0 (s_add per piece).
+template <int KS_IN>
+struct DmaLanes {
+    unsigned reg[4];                 // lane*16 + byte offset of this wave's four register-fed pieces
+    unsigned in[(2 * KS_IN + 3) / 4 + 1];   // ... of its input-fed pieces (the last may not exist; + 1: never a zero-length array)
+    unsigned wl;
+};
+template <int KS_IN>
+__device__ __forceinline__ DmaLanes<KS_IN> dma_lanes(int wl, int lane) {
+    DmaLanes<KS_IN> d;
+    d.wl = wl;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d.reg[i] = lane * 16 + (i / 2) * mb_bytes(KS_IN) + (wl + 4 * (i % 2)) * TILE_BYTES;
+    if constexpr (KS_IN > 0) {
+#pragma unroll
+        for (int i = 0; i < (2 * KS_IN + 3) / 4; ++i) {
+            const int k = wl + 4 * i;                      // input-fed piece index: row block k / KS_IN, tile k % KS_IN
+            d.in[i] = lane * 16 + (k / KS_IN) * mb_bytes(KS_IN) + (KS_REG + k % KS_IN) * TILE_BYTES;
+        }
+    }
+    return d;
+}
+__device__ __forceinline__ void pp_dma_piece(const char* src_chunk_uniform, unsigned lane_off, unsigned lds_chunk_base,
+                                             unsigned piece_off_uniform) {
+    asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"
+                 ::"s"(lds_chunk_base), "s"(piece_off_uniform), "v"(lane_off), "s"(src_chunk_uniform) : "memory");
+}
+template <int KS_IN>
+__device__ __forceinline__ void pp_issue(const char* __restrict__ wpack, char* wring, int cn, int ring_slot,
+                                         const ChunkMasks& cm, const DmaLanes<KS_IN>& d) {
+    constexpr int CB = chunk_bytes(KS_IN);
+    const int cn_u = __builtin_amdgcn_readfirstlane(cn);
+    const char* src = uniform_ptr(wpack) + (size_t)cn_u * CB;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_offset(wring)) + __builtin_amdgcn_readfirstlane(ring_slot) * CB;
+    const unsigned wl = __builtin_amdgcn_readfirstlane(d.wl);
+    if (cm.has_reg(cn_u)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            pp_dma_piece(src, d.reg[i], dst, (i / 2) * mb_bytes(KS_IN) + (wl + 4 * (i % 2)) * TILE_BYTES);
+    }
+    if constexpr (KS_IN > 0) {
+        if (cm.has_in(cn_u)) {
+#pragma unroll
+            for (int i = 0; i < (2 * KS_IN + 3) / 4; ++i) {
+                const unsigned k = wl + 4 * i;
+                if (k < 2 * KS_IN) pp_dma_piece(src, d.in[i], dst, (k / KS_IN) * mb_bytes(KS_IN) + (KS_REG + k % KS_IN) * TILE_BYTES);
+            }
+        }
+    }
+}
+
 struct NoCapture {
     template <int NB>
     __device__ __forceinline__ void operator()(int, int, const f32x4 (&)[NB]) const {}
 };
 
-constexpr int A_PF = 3, A_QN = 4;   // A-tile prefetch distance / rotating queue length (tiles)
+// One layer of the phase-separated stream (every layer kind of the plain-mode kernels: softplus with or without the
+// stored sigmoids, ReLU, the reverse sweep's multiplication by the stored sigmoids, and -- HIDDEN = false -- the linear
+// output layers).  `pp_last`: last chunk index of the network.
+template <int KS_IN, int HID, int WAVES, bool HIDDEN, typename Cap, typename NB_T>
+__device__ __forceinline__ void run_layer_pp(const NetDesc& net, const LayerDesc L, int l, const char* __restrict__ wpack,
+                                             const float* bias_lds, char* wring, opx8 (&Bcur)[KS_REG][2], NB_T& Bn,
+                                             opx8 (&aq)[AQ_LEN], u32x4 (&sgb)[SIG_BUFS][2], const op_t* stage_wave,
+                                             f32x4 (&out)[2], int wave, int lane, const SigIO& sig, Cap& cap, int& ci,
+                                             int& ring_pos, const ChunkMasks& cm, const DmaLanes<KS_IN>& dl, int pp_last) {
+    constexpr int PF = PP_PF, QN = PP_QN, NT = 2 * KS_REG;   // register-fed A tiles of a chunk, order (ks, mbl)
+    constexpr bool BIAS = HID != HID_SIGMUL;                 // the reverse sweep has no bias
+    const int g = lane >> 4;
+    const float* bl = BIAS ? bias_lds + l * BIAS_STRIDE + g * 4 : nullptr;
+    const int sig_layer = HID == HID_SIGMUL ? (L.aux & 0xff) - 1 : l;
+    const int cap_id = (L.aux >> 8) & 0xff;
+    // second wave of its SIMD (a workgroup's waves are dealt to the 4 SIMDs cyclically): barrier between M(c) and V(c).
+    // readfirstlane: a scalar branch, not an exec-masked region
+    const bool late = __builtin_amdgcn_readfirstlane(wave) >= WAVES / 2;
+#pragma unroll
+    for (int c = 0; c < MAX_CHUNKS; ++c) {
+        if ((HIDDEN ? c < KS_REG : true) && c < L.n_chunk) {
+            MP_STAMP(0);
+            // ring_pos = ci % RING_SLOTS, carried along (a division by 3 per use costs ~8 scalar instructions)
+            const int ring_next = ring_pos + 1 == RING_SLOTS ? 0 : ring_pos + 1;
+            const char* slot = wring + ring_pos * chunk_bytes(KS_IN) + lane * 16;
+            const char* slot_next = wring + ring_next * chunk_bytes(KS_IN) + lane * 16;
+            u32x4 (&sg)[2] = sgb[0];
+            if constexpr (HID == HID_SIGMUL && HIDDEN) {   // this chunk's stored sigmoids: needed in V(c), a whole M phase away
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    sg[nb] = *(const u32x4*)(sig.base + (size_t)sig_layer * sig.layer_bytes + (c * 2 + nb) * 1024 + lane * 16);
+            }
+            // ---- M(c): 4 accumulators (block mbl, column block nb), biased
+            f32x4 acc[CHUNK_MB][2];
+#pragma unroll
+            for (int mbl = 0; mbl < CHUNK_MB; ++mbl) {
+                f32x4 bv = (f32x4){0, 0, 0, 0};
+                if constexpr (BIAS) bv = *(const f32x4*)(bl + (2 * c + mbl) * 16);
+                acc[mbl][0] = bv;
+                acc[mbl][1] = bv;
+            }
+            if (L.use_reg) {   // tiles 0 .. PF-1 are in the queue already (loaded at the end of the previous chunk)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int ks = t / 2, mbl = t % 2;
+                    const opx8 a = aq[t % QN];
+#ifndef MP_EXP_NOLDS
+                    if (t + PF < NT) {
+                        const int tn = t + PF;
+                        aq[tn % QN] = *(const opx8*)(slot + (tn % 2) * mb_bytes(KS_IN) + (tn / 2) * TILE_BYTES);
+                    }
+#endif
+                    // pinned: left alone, the scheduler sinks each read to just before its use and the M phase stalls
+                    // on LDS latency at every tile (measured: 850 instead of 500 cycles)
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+                        acc[mbl][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, Bcur[ks][nb], acc[mbl][nb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if constexpr (KS_IN > 0) {
+                if (L.use_in) {
+#pragma unroll
+                    for (int ks = 0; ks < KS_IN; ++ks) {
+                        opx8 bi[2];
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb)
+                            bi[nb] = *(const opx8*)(stage_wave + (nb * 16 + (lane & 15)) * in_stride(KS_IN) + ks * 32 + g * 8);
+#pragma unroll
+                        for (int mbl = 0; mbl < CHUNK_MB; ++mbl) {
+                            const opx8 a = *(const opx8*)(slot + mbl * mb_bytes(KS_IN) + (KS_REG + ks) * TILE_BYTES);
+#pragma unroll
+                            for (int nb = 0; nb < 2; ++nb)
+                                acc[mbl][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bi[nb], acc[mbl][nb], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            if (cap_id == 1) {          // rows 0..47: blocks (0,0), (0,1), (1,0)
+                if (c == 0) { cap(1, 0, acc[0]); cap(1, 1, acc[1]); }
+                else if (c == 1) cap(1, 2, acc[0]);
+            } else if (cap_id == 2) {   // rows 208..255: blocks (6,1), (7,0), (7,1)
+                if (c == 6) cap(2, 0, acc[1]);
+                else if (c == 7) { cap(2, 1, acc[0]); cap(2, 2, acc[1]); }
+            }
+            if constexpr (!HIDDEN) {
+                if (c == 0 || c == MAX_CHUNKS - 1) {
+                    if (c == L.out_chunk) {  // fp32 rows 0..15 of the out chunk
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb) out[nb] = acc[0][nb];
+                    }
+                }
+            }
+            MP_STAMP(1);
+            // The reverse sweep's sigmoid loads (issued before M(c)) are waited for HERE by both kinds of wave: hipcc
+            // does not know the asm-issued DMA, so a wait it inserted in V(c) -- reached by the late waves right behind
+            // their DMA issue -- would wait for the fresh DMA pieces as well (measured: +9 % on k_mlp_grad).
+            if constexpr (HID == HID_SIGMUL && HIDDEN) dma_wait_all();
+            if (late) {
+                // every DMA piece this wave issued (one whole M phase ago) has landed; every wave is done with chunk ci:
+                // its ring slot is free for chunk ci + 3
+                dma_wait_all();
+                __syncthreads();
+#ifndef MP_EXP_NOLOAD
+                if (ci + 3 <= pp_last) pp_issue<KS_IN>(wpack, wring, ci + 3, ring_pos, cm, dl);   // (ci + 3) % 3 == ring_pos
+#endif
+                MP_STAMP(2);
+            }
+            // ---- V(c)
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                ActRegs8 a;
+#ifdef MP_EXP_NOV   // ablation: no V phase (accumulators kept alive)
+                asm volatile("" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1]));
+#else
+                pp_program<HID, HIDDEN, 0>(a, acc, Bn, c, sg);
+#endif
+                if constexpr (HID == HID_SOFTPLUS_SAVE && HIDDEN) {
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+                        *(u32x4*)(sig.base + (size_t)sig_layer * sig.layer_bytes + (c * 2 + nb) * 1024 + lane * 16) = sg[nb];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!late) {
+                MP_STAMP(2);
+                __syncthreads();   // the early waves issue no DMA: nothing to wait for (their stores need no wait)
+            }
+            MP_STAMP(3);
+            // the next chunk's first tiles (complete in the ring: both kinds of wave are past the barrier behind M(c))
+#pragma unroll
+            for (int t = 0; t < PF; ++t)
+                aq[t % QN] = *(const opx8*)(slot_next + (t % 2) * mb_bytes(KS_IN) + (t / 2) * TILE_BYTES);
+            ++ci;
+            ring_pos = ring_next;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KS_REG; ++k)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) Bcur[k][nb] = Bn.get(k, nb);
+}
+
+
 // K step of the next block that carries the first activation piece of a finished block.  The reverse sweep's pieces
 // (one multiplication each) sit in K steps 4..7, away from the MFMAs that produced their inputs: -8 % on k_mlp_grad;
 // the softplus pieces are best right at the start (+8 % on k_mlp_fwdsave when shifted).
@@ -407,7 +738,7 @@ __device__ __forceinline__ constexpr int act_shift(int hid) { return hid == HID_
 template <int NB, bool FWD, int KS_IN, int HID, int WAVES, bool HIDDEN, typename Cap, typename NB_T>
 __device__ __forceinline__ void run_layer(const NetDesc& net, const LayerDesc L, int l, const char* __restrict__ wpack,
                                           const float* bias_lds, char* wring, opx8 (&Bcur)[KS_REG][NB], NB_T& Bn,
-                                          opx8 (&aq)[A_QN], u32x4 (&sgb)[SIG_BUFS][NB], const op_t* stage_wave,
+                                          opx8 (&aq)[AQ_LEN], u32x4 (&sgb)[SIG_BUFS][NB], const op_t* stage_wave,
                                           f32x4 (&out)[NB], int wave, int lane, const SigIO& sig, Cap& cap, int& ci) {
     constexpr int PF = A_PF, QN = A_QN;
     constexpr bool BIAS = HID != HID_SIGMUL;   // the reverse sweep has no bias
@@ -586,26 +917,64 @@ __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restri
         for (int nb = 0; nb < NB; ++nb) sgb[b][nb] = (u32x4){0u, 0u, 0u, 0u};
     NextB<NB, false> Bn;
     Bn.zero();
-    opx8 aq[A_QN];
+    opx8 aq[AQ_LEN];
 #pragma unroll
     for (int t = 0; t < A_PF; ++t) aq[t] = *(const opx8*)(wring + t * TILE_BYTES + lane * 16);  // chunk 0, block 0
     // every network on this path is a run of hidden layers followed by its linear output layer(s): two loops instead of
     // a per-layer dispatch keep the two instantiations of the layer body out of each other's register allocation
     int l = 0;
-    for (; l < net.n_layers && net.layer[l].act != ACT_NONE; ++l)
-        run_layer<NB, FWD, KS_IN, HID, WAVES, true>(net, net.layer[l], l, wpack, bias_lds, wring, Bcur, Bn, aq, sgb, stage_wave,
-                                                    out, wave, lane, sig, cap, ci);
+#ifdef MP_EXP_NOPP   // ablation: the interleaved stream of run_layer for every layer
+    constexpr bool PP = false;
+#else
+#ifdef MP_EXP_GRAD_OLD   // ablation: the reverse sweep on the interleaved stream
+    constexpr bool PP = !FWD && NB == 2 && HID != HID_SIGMUL;
+#else
+    constexpr bool PP = !FWD && NB == 2;
+#endif
+#endif
+    if constexpr (PP) {
+        // The phase-separated stream keeps THREE chunks in flight (prologue<.., true>: chunks 0, 1 and 2) and fetches
+        // chunk ci + 3 behind the barrier that frees chunk ci's slot.
+        const int pp_last = net.total_chunks - 1;
+        const ChunkMasks cm = chunk_masks(net);
+        const DmaLanes<KS_IN> dl = dma_lanes<KS_IN>(__builtin_amdgcn_readfirstlane(wave) & (WAVES / 2 - 1), lane);
+        int ring_pos = 0;
+        // tile order of the phase-separated stream: (K step, row block); chunk 0's first tiles
+#pragma unroll
+        for (int t = 0; t < PP_PF; ++t)
+            aq[t % PP_QN] = *(const opx8*)(wring + (t % 2) * mb_bytes(KS_IN) + (t / 2) * TILE_BYTES + lane * 16);
+        for (; l < net.n_layers && net.layer[l].act != ACT_NONE; ++l)
+            run_layer_pp<KS_IN, HID, WAVES, true>(net, net.layer[l], l, wpack, bias_lds, wring, Bcur, Bn, aq, sgb, stage_wave, out,
+                                                  wave, lane, sig, cap, ci, ring_pos, cm, dl, pp_last);
+        for (; l < net.n_layers; ++l)
+            run_layer_pp<KS_IN, HID, WAVES, false>(net, net.layer[l], l, wpack, bias_lds, wring, Bcur, Bn, aq, sgb, stage_wave, out,
+                                                   wave, lane, sig, cap, ci, ring_pos, cm, dl, pp_last);
+    }
+    if constexpr (!PP) {
+        for (; l < net.n_layers && net.layer[l].act != ACT_NONE; ++l)
+            run_layer<NB, FWD, KS_IN, HID, WAVES, true>(net, net.layer[l], l, wpack, bias_lds, wring, Bcur, Bn, aq, sgb, stage_wave,
+                                                        out, wave, lane, sig, cap, ci);
+    }
     for (; l < net.n_layers; ++l)
         run_layer<NB, FWD, KS_IN, HID, WAVES, false>(net, net.layer[l], l, wpack, bias_lds, wring, Bcur, Bn, aq, sgb, stage_wave,
                                                      out, wave, lane, sig, cap, ci);
 }
 
 // Issues the first two weight chunks into ring slots 0 and 1 and synchronises (also publishes the staging rows).
-template <int KS_IN, int WAVES>
+// THREE: the phase-separated stream (plain-mode kernels) starts with all three ring slots filled.
+#ifdef MP_EXP_NOPP
+constexpr bool PROLOGUE_THREE = false;
+#else
+constexpr bool PROLOGUE_THREE = true;
+#endif
+template <int KS_IN, int WAVES, bool THREE = PROLOGUE_THREE>
 __device__ __forceinline__ void prologue(const NetDesc& net, const char* __restrict__ wpack, char* wring, int wave,
                                          int lane) {
     issue_chunk<KS_IN, WAVES>(wpack, wring, 0, wave, lane);
     if (net.total_chunks > 1) issue_chunk<KS_IN, WAVES>(wpack, wring, 1, wave, lane);
+    if constexpr (THREE) {
+        if (net.total_chunks > 2) issue_chunk<KS_IN, WAVES>(wpack, wring, 2, wave, lane);
+    }
     dma_wait_all();
     __syncthreads();
 }
