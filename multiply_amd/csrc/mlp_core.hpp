@@ -242,7 +242,15 @@ __device__ __forceinline__ h2 softplus2(h2 z) {   // h' = max(z',0) + log2(1 + 2
     return relu_h2(z) + z * (h2){(op_t)0.001f, (op_t)0.001f};
 #else
     const h2 u = exp2_neg_abs_h2(z);
+#ifdef MP_EXP_LOGTRANS
     return relu_h2(z) + log2_h2(u + (h2){(op_t)1.0f, (op_t)1.0f});
+#else   // the same three fused multiply-adds as the phase-separated stream's V program (pp_instr): identical results
+    const h2 c1 = {(op_t)1.42459527f, (op_t)1.42459527f}, c2 = {(op_t)-0.58921265f, (op_t)-0.58921265f},
+             c3 = {(op_t)0.16538905f, (op_t)0.16538905f};
+    h2 t = __builtin_elementwise_fma(u, c3, c2);
+    t = __builtin_elementwise_fma(t, u, c1);
+    return __builtin_elementwise_fma(t, u, relu_h2(z));
+#endif
 #endif
 }
 // lanes 8..15 of every 16-lane row receive lane-8's register, lanes 0..7 keep their own (DPP row_shr:8).  Inline asm on
@@ -420,16 +428,40 @@ constexpr int AQ_LEN = PP_QN > A_QN ? PP_QN : A_QN;
 struct ActRegs8 {
     unsigned z[8], u[8], lg[8], r[8], h[8], d[8], s[8];
 };
+// log2(1 + u) on u in [0, 1] as u (C1 + u (C2 + u C3)): minimax cubic (max error 7.7e-4; evaluated in packed half 1.3e-3,
+// the v_exp / +1 / v_log chain it replaces loses u below 2^-11 in the half-precision sum 1 + u and is no better).  Three
+// packed FMAs instead of an addition and two transcendentals per row pair -- beside the partner wave's MFMAs a v_log costs
+// 13.3 cycles of the SIMD's vector pipe, a packed FMA 8.25 (tools/pair_model.hip) -- and the last FMA adds max(z', 0).
+#ifdef MP_EXP_LOGTRANS   // ablation: the transcendental chain
+constexpr bool LOG_POLY = false;
+#else
+constexpr bool LOG_POLY = true;
+#endif
+constexpr float LOG2P_C1 = 1.42459527f, LOG2P_C2 = -0.58921265f, LOG2P_C3 = 0.16538905f;
+struct ActConst {
+    unsigned c1, c2, c3;   // the coefficients as packed half pairs, in vector registers (gfx9 VOP3P: no literals, one SGPR)
+};
+__device__ __forceinline__ ActConst act_const() {
+    const h2 a = {(op_t)LOG2P_C1, (op_t)LOG2P_C1}, b = {(op_t)LOG2P_C2, (op_t)LOG2P_C2}, c = {(op_t)LOG2P_C3, (op_t)LOG2P_C3};
+    return ActConst{bits(a), bits(b), bits(c)};
+}
 // stages of the V program per layer kind (HIDDEN = false: the linear output layers, conversion only)
 __host__ __device__ constexpr int pp_stages(int hid, bool hidden) {
-    return !hidden ? 1 : hid == HID_SOFTPLUS_SAVE ? 11 : hid == HID_SOFTPLUS ? 8 : 2;
+    return !hidden ? 1 : hid == HID_SOFTPLUS_SAVE ? (LOG_POLY ? 10 : 11) : hid == HID_SOFTPLUS ? (LOG_POLY ? 7 : 8) : 2;
 }
 
 // stage ST for row pair q = 4 mbl + 2 nb + j  (mbl: 16-row block of the chunk, nb: column block, j: row pair)
 template <int HID, bool HIDDEN, int ST, int q, typename NB_T>
-__device__ __forceinline__ void pp_instr(ActRegs8& a, const f32x4 (&acc)[CHUNK_MB][2], NB_T& Bn, int c, u32x4 (&sg)[2]) {
+__device__ __forceinline__ void pp_instr(ActRegs8& a, const ActConst& k, const f32x4 (&acc)[CHUNK_MB][2], NB_T& Bn, int c,
+                                         u32x4 (&sg)[2]) {
     constexpr int mbl = q / 4, nb = (q / 2) % 2, j = q % 2;
     constexpr bool SP = HIDDEN && (HID == HID_SOFTPLUS || HID == HID_SOFTPLUS_SAVE);
+    // softplus stage ids: E0 E1 = u = 2^-|z'| (low half writes the dword, high half in place); then either
+    //   polynomial: P0 t = C3 u + C2, P1 t = t u + C1, RL r = max(z', 0), HH h' = t u + r
+    //   transcendental: A1 u += 1, L0 L1 lg = log2(u), RL, HH h' = r + lg
+    // and for the stored sigmoids: SB d = z' - h', S0 S1 sigmoid = 2^d
+    constexpr int E0 = 1, E1 = 2, P0 = LOG_POLY ? 3 : -1, P1 = LOG_POLY ? 4 : -1, A1 = LOG_POLY ? -1 : 3, L0 = LOG_POLY ? -1 : 4,
+                  L1 = LOG_POLY ? -1 : 5, RL = LOG_POLY ? 5 : 6, HH = LOG_POLY ? 6 : 7, SB = HH + 1, S0 = HH + 2, S1 = HH + 3;
     if constexpr (ST == 0) {          // left to the compiler: it knows the MFMA -> VALU read hazard
         a.z[q] = bits(to_h2(acc[mbl][nb][2 * j], acc[mbl][nb][2 * j + 1]));
         if constexpr (!HIDDEN) {
@@ -452,27 +484,32 @@ __device__ __forceinline__ void pp_instr(ActRegs8& a, const f32x4 (&acc)[CHUNK_M
             z = relu_h2(z);
         }
         if (c < KS_REG) Bn.put(c, nb, mbl, j, z);
-    } else if constexpr (ST == 1) {   // u = 2^-|z'|: low half (writes the dword), then the high half in place
+    } else if constexpr (ST == E0) {
         asm volatile("v_exp_f16_sdwa %0, -|%1| dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(a.u[q]) : "v"(a.z[q]));
-    } else if constexpr (ST == 2) {
+    } else if constexpr (ST == E1) {
         asm volatile("v_exp_f16_sdwa %0, -|%1| dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(a.u[q]) : "v"(a.z[q]));
-    } else if constexpr (ST == 3) {   // 1 + u
+    } else if constexpr (ST == P0) {
+        asm volatile("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(a.lg[q]) : "v"(a.u[q]), "v"(k.c3), "v"(k.c2));
+    } else if constexpr (ST == P1) {
+        asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(a.lg[q]) : "v"(a.u[q]), "v"(k.c1));
+    } else if constexpr (ST == A1) {
         asm volatile("v_pk_add_f16 %0, %0, 1.0 op_sel_hi:[1,0]" : "+v"(a.u[q]));
-    } else if constexpr (ST == 4) {   // log2(1 + u)
+    } else if constexpr (ST == L0) {
         asm volatile("v_log_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=&v"(a.lg[q]) : "v"(a.u[q]));
-    } else if constexpr (ST == 5) {
+    } else if constexpr (ST == L1) {
         asm volatile("v_log_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(a.lg[q]) : "v"(a.u[q]));
-    } else if constexpr (ST == 6) {   // max(z', 0) on the bit pattern
+    } else if constexpr (ST == RL) {  // max(z', 0) on the bit pattern
         asm volatile("v_pk_max_i16 %0, %1, 0" : "=v"(a.r[q]) : "v"(a.z[q]));
-    } else if constexpr (ST == 7) {   // h' = max(z', 0) + log2(1 + 2^-|z'|): the next layer's operand register as it stands
-        asm volatile("v_pk_add_f16 %0, %1, %2" : "=v"(a.h[q]) : "v"(a.r[q]), "v"(a.lg[q]));
+    } else if constexpr (ST == HH) {  // h' = max(z', 0) + log2(1 + 2^-|z'|): the next layer's operand register as it stands
+        if constexpr (LOG_POLY) asm volatile("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(a.h[q]) : "v"(a.lg[q]), "v"(a.u[q]), "v"(a.r[q]));
+        else asm volatile("v_pk_add_f16 %0, %1, %2" : "=v"(a.h[q]) : "v"(a.r[q]), "v"(a.lg[q]));
         if (c < KS_REG) Bn.put(c, nb, mbl, j, __builtin_bit_cast(h2, a.h[q]));
-    } else if constexpr (ST == 8) {   // z' - h'
+    } else if constexpr (ST == SB) {  // z' - h'
         asm volatile("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(a.d[q]) : "v"(a.z[q]), "v"(a.h[q]));
-    } else if constexpr (ST == 9) {   // sigmoid(z') = 2^(z' - h')
+    } else if constexpr (ST == S0) {  // sigmoid(z') = 2^(z' - h')
         asm volatile("v_exp_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=&v"(a.s[q]) : "v"(a.d[q]));
     } else {
-        static_assert(ST == 10, "pp_instr: stage");
+        static_assert(ST == S1, "pp_instr: stage");
         asm volatile("v_exp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(a.s[q]) : "v"(a.d[q]));
         constexpr int e = 2 * mbl + j;   // by name, see the note at the HID_SIGMUL read
         if constexpr (e == 0) sg[nb].x = a.s[q];
@@ -482,10 +519,11 @@ __device__ __forceinline__ void pp_instr(ActRegs8& a, const f32x4 (&acc)[CHUNK_M
     }
 }
 template <int HID, bool HIDDEN, int I, typename NB_T>
-__device__ __forceinline__ void pp_program(ActRegs8& a, const f32x4 (&acc)[CHUNK_MB][2], NB_T& Bn, int c, u32x4 (&sg)[2]) {
+__device__ __forceinline__ void pp_program(ActRegs8& a, const ActConst& k, const f32x4 (&acc)[CHUNK_MB][2], NB_T& Bn, int c,
+                                           u32x4 (&sg)[2]) {
     if constexpr (I < 8 * pp_stages(HID, HIDDEN)) {
-        pp_instr<HID, HIDDEN, I / 8, I % 8>(a, acc, Bn, c, sg);
-        pp_program<HID, HIDDEN, I + 1>(a, acc, Bn, c, sg);
+        pp_instr<HID, HIDDEN, I / 8, I % 8>(a, k, acc, Bn, c, sg);
+        pp_program<HID, HIDDEN, I + 1>(a, k, acc, Bn, c, sg);
     }
 }
 
@@ -596,6 +634,7 @@ __device__ __forceinline__ void run_layer_pp(const NetDesc& net, const LayerDesc
     // second wave of its SIMD (a workgroup's waves are dealt to the 4 SIMDs cyclically): barrier between M(c) and V(c).
     // readfirstlane: a scalar branch, not an exec-masked region
     const bool late = __builtin_amdgcn_readfirstlane(wave) >= WAVES / 2;
+    const ActConst kact = act_const();
 #pragma unroll
     for (int c = 0; c < MAX_CHUNKS; ++c) {
         if ((HIDDEN ? c < KS_REG : true) && c < L.n_chunk) {
@@ -694,7 +733,7 @@ __device__ __forceinline__ void run_layer_pp(const NetDesc& net, const LayerDesc
 #ifdef MP_EXP_NOV   // ablation: no V phase (accumulators kept alive)
                 asm volatile("" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1]));
 #else
-                pp_program<HID, HIDDEN, 0>(a, acc, Bn, c, sg);
+                pp_program<HID, HIDDEN, 0>(a, kact, acc, Bn, c, sg);
 #endif
                 if constexpr (HID == HID_SOFTPLUS_SAVE && HIDDEN) {
 #pragma unroll
