@@ -5,9 +5,15 @@
 
 A "step" is one pass of the hot path (Multiply.forward, eval mode, all persons, with background) over one batch of
 synthetic input = one full 512x512 frame = 262,144 rays (BASELINE.json configs[1]: 2 persons, 128 importance
-samples/ray, half-precision MFMA MLPs: f16 operands, fp32 accumulate).  Inputs (rays' uv, camera, SMPL parameters, weights) are resident in HBM before the timed
-region.  N > 1: one process per GPU (torchrun), every rank renders its own frames of the sequence (rays/frames shard
-without any data-path collective -> weak scaling); time = max over ranks between barriers.
+samples/ray, half-precision MFMA MLPs: f16 operands, fp32 accumulate).  Inputs (rays' uv, camera, SMPL parameters,
+weights) are resident in HBM before the timed region.
+
+N > 1 (BASELINE.json configs[2]): one process per GPU.  `python bench.py --gpus N` without a launcher
+re-executes itself under torch.distributed.run; under a launcher it asserts WORLD_SIZE == N.  The headline line is STRONG
+scaling: ONE frame per step, its convergence groups (64x8-pixel blocks) dealt round robin to the ranks (body rays cost ~30x
+background rays), every rank renders its share and ONE RCCL all_gather per output reassembles the image on every rank, inside
+the timed region; time = max over ranks between barriers.  The frame-per-rank weak-scaling throughput (no data-path
+collective at all) is reported beside it under "weak".  Training: 512 / N rays per rank + one flat gradient all-reduce.
 
 The JSON line also carries
   roofline     : the dominant kernel's algorithmic FLOP/s (HIP events inside the timed region) vs the dense 16-bit MFMA peak
@@ -61,14 +67,38 @@ def to_dev(inp):
     return {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inp.items()}
 
 
-def cpu_baseline(model, inp, tables, sc, n_samples, rows=1, stride=4):
-    """Times the CPU oracle on a bounded sample of the same frame: every `stride`-th pixel of the middle image row
-    (which crosses both bodies).  Also returns the GPU-vs-oracle pixel error on that sample."""
+def host_cpu():
+    """(threads torch uses, physical cores, model name) of this host"""
+    model, cores = "unknown", set()
+    try:
+        phys, core = None, None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name") and model == "unknown":
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":", 1)[1].strip()
+                elif not line.strip() and phys is not None:
+                    cores.add((phys, core))
+                    phys = core = None
+    except OSError:
+        pass
+    return torch.get_num_threads(), (len(cores) or None), model
+
+
+def cpu_baseline(model, inp, tables, sc, n_samples, n_rays=2048):
+    """Times the CPU oracle on a bounded sample of the same frame: `n_rays` rays = a centred block of image rows that crosses
+    both bodies, every pixel of those rows (>= 2 k rays, extrapolated and labelled).  Also returns the
+    GPU-vs-oracle pixel error on that sample."""
     from oracle import multiply_oracle as O
     H = W = int(round(np.sqrt(inp["uv"].shape[1])))
+    rows = max(1, n_rays // W)
+    r0 = H // 2 - rows // 2
     uvx, uvy = inp["uv"][0, :, 0], inp["uv"][0, :, 1]
-    sel = torch.nonzero((uvy == H // 2) & (uvx % stride == 0)).flatten()
-    sel = sel[torch.argsort(uvx[sel])]
+    sel = torch.nonzero((uvy >= r0) & (uvy < r0 + rows)).flatten()
+    sel = sel[torch.argsort(uvy[sel] * W + uvx[sel])]
     sub = dict(inp)
     sub["uv"] = inp["uv"][:, sel]
     got = model(to_dev(sub))
@@ -82,9 +112,11 @@ def cpu_baseline(model, inp, tables, sc, n_samples, rows=1, stride=4):
     dt = time.time() - t0
     err = (got["rgb_values"].cpu() - want["rgb_values"]).abs()
     err = err[~err.isnan()]
-    return dict(value=len(sel) / dt, unit="rays/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{len(sel)} rays (every {stride}th pixel of image row {H // 2}) of the same frame, fp32 torch "
-                       f"oracle, {dt:.1f} s", parity_rgb_max_abs=float(err.max()), parity_rgb_mean_abs=float(err.mean()))
+    threads, phys, name = host_cpu()
+    return dict(value=len(sel) / dt, unit="rays/s", cores=threads, physical_cores=phys, cpu_model=name, kind="port",
+                sample=f"{len(sel)} rays (image rows {r0}..{r0 + rows - 1} of the same {H}x{W} frame, hit rays "
+                       f"{[int(len(h)) for h in hit]}), fp32 torch oracle on {threads} threads, {dt:.1f} s; the frame rate "
+                       f"is this rate extrapolated", parity_rgb_max_abs=float(err.max()), parity_rgb_mean_abs=float(err.mean()))
 
 
 def train_iterations(model, gin, steps, warmup, dist, barrier, seed=0, rays=512):
@@ -141,10 +173,11 @@ def train_iterations(model, gin, steps, warmup, dist, barrier, seed=0, rays=512)
     return dt, [a / max(steps, 1) for a in acc], float(lo["loss"]), model.last_stats
 
 
-def train_cpu_baseline(model, gin, inp, tables, sc, n_samples, rays=128, seed=0):
-    """One training iteration of the CPU oracle (fp32 torch autograd incl. the double backward through the normals and
-    the eikonal term) on a bounded sample: `rays` random pixels of the frame instead of 512.  The sampler's depths and the
-    random draws are taken from a GPU call on the same pixels (the sampler runs without gradients in the reference)."""
+def train_cpu_baseline(model, gin, inp, tables, sc, n_samples, rays=512, iters=3, seed=0):
+    """`iters` training iterations of the CPU oracle (fp32 torch autograd incl. the double backward through the normals and
+    the eikonal term) on `rays` random pixels of the frame (the GPU figure's 512 rays).  The sampler's depths
+    and the random draws are taken from a GPU call on the same pixels (the sampler runs without gradients in the
+    reference)."""
     from oracle import multiply_oracle as O
     from multiply_amd.config import load_config
     from multiply_amd.loss import Loss
@@ -177,18 +210,51 @@ def train_cpu_baseline(model, gin, inp, tables, sc, n_samples, rays=128, seed=0)
     oin["uv"] = inp["uv"][:, sel]
     loss_fn = Loss(load_config().loss)
     gt = {"rgb": torch.rand(1, rays, 3, generator=g)}
-    t0 = time.time()
-    want = oracle.forward_train(oin, hit, z_given, draws)
-    want.update(fg_rgb_values_each_person_list=[], index_in_surface=None, epoch=301, temporal_loss=torch.zeros(1),
-                smpl_surface_loss=torch.zeros(1), zero_pose_loss=torch.zeros(1))
-    with contextlib.redirect_stdout(sys.stderr):
-        lo = loss_fn(want, gt)
-    torch.autograd.grad(lo["loss"], [v for v in sd.values() if v.requires_grad], allow_unused=True)
-    dt = time.time() - t0
-    return {"value": 1e3 * dt, "unit": "ms/train-iter", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"ONE iteration on {rays} rays (the GPU number is for 512 rays): forward from the sampler's depths + "
-                      f"loss + autograd on the fp32 torch oracle, {dt:.1f} s", "rays": rays,
-            "ms_per_iter_scaled_to_512_rays": 1e3 * dt * 512.0 / rays}
+    times = []
+    for _ in range(iters):
+        t0 = time.time()
+        want = oracle.forward_train(oin, hit, z_given, draws)
+        want.update(fg_rgb_values_each_person_list=[], index_in_surface=None, epoch=301, temporal_loss=torch.zeros(1),
+                    smpl_surface_loss=torch.zeros(1), zero_pose_loss=torch.zeros(1))
+        with contextlib.redirect_stdout(sys.stderr):
+            lo = loss_fn(want, gt)
+        torch.autograd.grad(lo["loss"], [v for v in sd.values() if v.requires_grad], allow_unused=True)
+        times.append(time.time() - t0)
+    dt = float(np.mean(times))
+    threads, phys, name = host_cpu()
+    return {"value": 1e3 * dt, "unit": "ms/train-iter", "cores": threads, "physical_cores": phys, "cpu_model": name,
+            "kind": "port", "rays": rays, "iters": iters,
+            "sample": f"mean of {iters} iterations on {rays} rays (hit rays {[int(len(h)) for h in hit]}): forward from the "
+                      f"sampler's depths + loss + autograd on the fp32 torch oracle, {threads} threads; per iteration "
+                      f"{[round(t, 1) for t in times]} s"}
+
+
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` without a launcher: one process per GPU through torch.distributed.run (the driver starts the
+    same module itself for its multi-GPU runs)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+def timed_frames(model, gin, steps, barrier, after=None):
+    """EXACTLY `steps` forward passes between two barriers; after(out) runs inside the timed region (the all_gather of the
+    strong-scaling mode).  Returns elapsed seconds and the per-step statistics."""
+    shaded, sdf_evals = [], []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = model(gin)
+        if after is not None:
+            after(out)
+        shaded.append(model.last_stats["n_shaded"])
+        sdf_evals.append(model.last_stats["n_sdf_evals"])
+    barrier()
+    return time.perf_counter() - t0, shaded, sdf_evals
 
 
 def main():
@@ -202,18 +268,26 @@ def main():
     ap.add_argument("--train-steps", type=int, default=10, help="timed training iterations for ms/train-iter (0 = skip)")
     ap.add_argument("--train-warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the CPU oracle's render sample")
+    ap.add_argument("--cpu-train-iters", type=int, default=3)
+    ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the frame-per-rank weak-scaling leg")
     ap.add_argument("--breakdown", action="store_true", help="print per-phase GPU times to stderr")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        relaunch_under_torchrun(args.gpus)            # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
     dist = world > 1
     # one rank per GPU.  (MP_BENCH_BACKEND=gloo lets the multi-rank code path be smoke-tested on a box with fewer GPUs
     # than ranks: ranks then share devices and collectives go through the host.)
     backend = os.environ.get("MP_BENCH_BACKEND", "nccl")
     local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
+    td = None
     if dist:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -221,12 +295,7 @@ def main():
             td.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             td.init_process_group(backend)
-
-    # every rank renders its own frame of the synthetic sequence (seed = rank)
-    model, inp, tables, sc = build_model(args.samples, seed=rank, H=args.res, W=args.res, tile=args.tile)
-    model.convergence_group = 512            # the reference renders frames in chunks of pixel_per_batch = 512 rays
-    gin = to_dev(inp)
-    R = gin["uv"].shape[1]
+        assert td.get_world_size() == args.gpus, "process group size differs from --gpus"
 
     def barrier():
         torch.cuda.synchronize()
@@ -234,54 +303,86 @@ def main():
             td.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if not dist:
+            return x
+        tt = torch.tensor([x], device="cuda", dtype=torch.float64)
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        return float(tt.item())
+
+    GROUP = 512                              # the reference renders frames in chunks of pixel_per_batch = 512 rays
+    # strong scaling: every rank holds the SAME frame (seed 0) and renders its round-robin share of the convergence groups
+    model, inp, tables, sc = build_model(args.samples, seed=0, H=args.res, W=args.res, tile=args.tile)
+    model.convergence_group = GROUP
+    R = inp["uv"].shape[1]
+    if dist:
+        from multiply_amd.parallel import gather_rays_interleaved, shard_input_interleaved
+        share, my_ids = shard_input_interleaved(inp, rank, world, GROUP)
+        gin = to_dev(share)
+        image = {}
+
+        def assemble(out):                   # ONE all_gather per output the caller keeps (multiply_model.py:1045-1069)
+            for k in ("rgb_values", "normal_values", "fg_rgb_values"):
+                image[k] = gather_rays_interleaved(out[k], R, world, GROUP)
+    else:
+        gin, assemble = to_dev(inp), None
+
     model.profile = True                     # the warm-up also creates the pool of timing events the phases use
     for _ in range(args.warmup):
-        model(gin)
+        o = model(gin)
+        if assemble is not None:
+            assemble(o)
     torch.cuda.synchronize()
     model.phase_events = {}
-    shaded, sdf_evals = [], []
-    barrier()
-    t0 = time.perf_counter()
-    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    host_t = [time.perf_counter()]
-    step_ev[0].record()
-    for i in range(args.steps):
-        model(gin)
-        step_ev[i + 1].record()
-        host_t.append(time.perf_counter())
-        shaded.append(model.last_stats["n_shaded"])
-        sdf_evals.append(model.last_stats["n_sdf_evals"])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if args.breakdown and rank == 0:
-        print("  per-step GPU ms (events):", [round(step_ev[i].elapsed_time(step_ev[i + 1]), 1) for i in range(args.steps)],
-              " host ms between returns:", [round(1e3 * (host_t[i + 1] - host_t[i]), 1) for i in range(args.steps)],
-              file=sys.stderr)
+    elapsed, shaded, sdf_evals = timed_frames(model, gin, args.steps, barrier, assemble)
     model.profile = False
-    if dist:
-        tt = torch.tensor([elapsed], device="cuda")
-        td.all_reduce(tt, op=td.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
+    elapsed = max_over_ranks(elapsed)
     render_stats = model.last_stats
+    phases = model.phase_times_ms()
+
+    weak = None
+    if dist and not args.no_weak:            # frame-per-rank: rank r renders frame r of the synthetic sequence, no collective
+        wmodel, winp, _, _ = build_model(args.samples, seed=rank, H=args.res, W=args.res, tile=args.tile)
+        wmodel.convergence_group = GROUP
+        wgin = to_dev(winp)
+        for _ in range(args.warmup):
+            wmodel(wgin)
+        wel, _, _ = timed_frames(wmodel, wgin, args.steps, barrier)
+        wel = max_over_ranks(wel)
+        weak = {"value": R * args.steps * world / wel, "unit": "rays/s", "ms_per_step": 1e3 * wel / args.steps, "scaling": "weak",
+                "parallelism": f"frame-sharded dp{world}: every rank renders its own frame, no data-path collective"}
+        del wmodel, wgin
+
     train = None
     if args.train_steps > 0:
-        tdt, tph, tloss, tstats = train_iterations(model, gin, args.train_steps, args.train_warmup, dist, barrier, seed=rank)
-        if dist:
-            tt = torch.tensor([tdt], device="cuda")
-            td.all_reduce(tt, op=td.ReduceOp.MAX)
-            tdt = float(tt.item())
+        rays_rank = 512 // world             # strong scaling: the reference's 512 pixels per iteration split over the ranks
+        full = to_dev(inp)
+        tdt, tph, tloss, tstats = train_iterations(model, full, args.train_steps, args.train_warmup, dist, barrier, seed=rank,
+                                                   rays=rays_rank)
+        tdt = max_over_ranks(tdt)
+        # exact op count of the iteration's differentiable MLP work: fg SDF net 6 GEMM passes over
+        # (hit-ray samples + eikonal points) rows, colour net 3, background nets 3 over 32 samples per ray (fp32 MFMA)
+        S = args.samples + 33
+        hit_rows = sum(int(h) for h in tstats["n_hit"]) * S
+        eik_rows = 512 * len(tstats["n_hit"])
+        tflop = (6 * (hit_rows + eik_rows) * 2 * M_IMP + 3 * hit_rows * 2 * M_REN + 3 * 32 * rays_rank * 2 * (M_BGIMP + M_BGREN))
         train = {"metric": "ms/train-iter (forward + loss + backward + gradient all-reduce + Adam step)",
                  "ms_per_iter": 1e3 * tdt / args.train_steps, "steps": args.train_steps, "warmup": args.train_warmup,
-                 "rays_per_iter_per_gpu": 512, "rays_per_iter": 512 * world, "scaling": "weak", "dtype": "f32",
+                 "rays_per_iter_per_gpu": rays_rank, "rays_per_iter": rays_rank * world, "scaling": "strong" if dist else "weak",
+                 "dtype": "f32",
                  "gpu_ms": {"forward+loss": tph[0], "backward": tph[1], "allreduce": tph[2], "adam": tph[3]},
-                 "hit_rays": tstats["n_hit"], "last_loss": tloss}
+                 "hit_rays": tstats["n_hit"], "last_loss": tloss,
+                 "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": 157.3, "flop_per_iter_this_rank": tflop,
+                              "achieved": tflop / (tdt / args.train_steps) / 1e12,
+                              "frac": tflop / (tdt / args.train_steps) / 1e12 / 157.3,
+                              "note": "exact-fp32 MFMA GEMM work of the differentiable path (the f16 sampler queries are not "
+                                      "counted) over the whole iteration's wall time"}}
 
-    phases = model.phase_times_ms()
-    n_shaded = float(sum(int(w.sum()) for s in shaded for w in s)) / args.steps          # per frame
-    n_sdf = float(sum(int(w[:-1].sum()) for s in sdf_evals for w in s)) / args.steps
+    n_shaded = float(sum(int(w.sum()) for s_ in shaded for w in s_)) / args.steps          # per frame (this rank's share)
+    n_sdf = float(sum(int(w[:-1].sum()) for s_ in sdf_evals for w in s_)) / args.steps
+    R_rank = gin["uv"].shape[1]
     flops = {"mlp_shade": n_shaded * 4 * M_IMP, "sampler_mlp_sdf": n_sdf * 2 * M_IMP, "mlp_color": n_shaded * 2 * M_REN,
-             "background": R * 32 * 2 * (M_BGIMP + M_BGREN)}
+             "background": R_rank * 32 * 2 * (M_BGIMP + M_BGREN)}
     dom = max(flops, key=lambda k: phases.get(k, (0, 0.0))[1])
     n_launch, ms = phases[dom]
     per_launch_s = ms / 1e3 / max(n_launch, 1)
@@ -300,8 +401,9 @@ def main():
     traffic = None
     kernels = {"mlp_shade": ["k_mlp_fwdsave", "k_mlp_grad"] if model.shade_mode == "reverse" else ["k_mlp_shade"],
                "mlp_color": ["k_mlp_color"], "background": ["k_background"], "sampler_mlp_sdf": ["k_mlp_sdf"]}[dom]
-    pmc_file = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(pmc_file) and args.res == 512 and args.samples == 128:
+    pmc_file = next((os.path.join(REPO, "profiles", f) for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+                     if os.path.exists(os.path.join(REPO, "profiles", f))), None)
+    if pmc_file and args.res == 512 and args.samples == 128 and world == 1:
         with open(pmc_file) as f:
             pmc = json.load(f)                      # per-dispatch averages of ONE frame (bench.py --steps 1 --warmup 0)
         rd = wr = 0.0
@@ -312,31 +414,39 @@ def main():
         if rd + wr > 0:
             traffic = {"bytes_per_launch": (rd + wr) / launches_per_frame, "read": rd / launches_per_frame,
                        "write": wr / launches_per_frame,
-                       "source": "profiles/r01_pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+                       "source": os.path.relpath(pmc_file, REPO).replace(".json", ".txt") +
+                                 " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; Infinity-Cache hits are "
+                                 "counted: an upper bound on HBM bytes)"}
 
     if rank == 0:
         out = {
             "metric": "rays/sec rendering full 512x512 frames (eval forward, all persons, with background)",
-            "value": R * args.steps * world / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "value": R * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "scaling": "strong" if dist else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"2-person synthetic SMPL scene, {args.res}x{args.res} rays/frame, N_samples="
                                    f"{args.samples} (+32 extra +2 bounds = {args.samples + 33} composited samples/ray/"
                                    f"person), N_samples_eval={max(128, args.samples)}, 32 background samples, "
                                    f"convergence groups of 512 rays (reference pixel_per_batch), geometric-init weights",
-                       "rays_per_step": R, "frames_per_rank": args.steps, "parallelism": f"frame-sharded dp{world}"},
+                       "rays_per_step": R, "frames": args.steps,
+                       "parallelism": (f"ray-sharded dp{world}: one frame per step, convergence groups dealt round robin, "
+                                       f"all_gather of the image on every rank") if dist else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": dom + " = " + " + ".join(kernels), "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "avg_launch_ms": 1e3 * per_launch_s, "launches_per_step": launches_per_frame,
-                         "algorithmic_flop_per_launch": flops[dom] / launches_per_frame},
+                         "algorithmic_flop_per_launch": flops[dom] / launches_per_frame,
+                         "note": "rank 0's share of the frame" if dist else None},
             "phases_ms_per_step": {k: v[1] / args.steps for k, v in phases.items()},
         }
+        if weak is not None:
+            out["weak"] = weak
         if train is not None:
             out["train_iter"] = train
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, inp, tables, sc, args.samples)
+            out["cpu_baseline"] = cpu_baseline(model, inp, tables, sc, args.samples, n_rays=args.cpu_rays)
             if train is not None:
-                train["cpu_baseline"] = train_cpu_baseline(model, gin, inp, tables, sc, args.samples)
+                train["cpu_baseline"] = train_cpu_baseline(model, to_dev(inp), inp, tables, sc, args.samples,
+                                                           iters=args.cpu_train_iters)
         print(json.dumps(out))
     if dist:
         td.barrier()

@@ -20,7 +20,10 @@ class SMPLDeformer(nn.Module):
             server = SMPLServer(gender=gender, betas=betas)
         self.max_dist = max_dist
         self.K = K
-        self.smpl = server
+        # deformer.py:11: the deformer owns ITS OWN SMPLServer(gender) (no betas) -- a second set of SMPL parameters in the
+        # checkpoint (deformer_list.N.smpl.smpl.*); the device tables are shared with the scene's server
+        from .smpl import SMPLServer as _Server
+        self.smpl = _Server(gender=gender, smpl_tables=server.tables)
         # canonical ("A-pose") vertices of this shape = SMPLServer(betas).verts_c (deformer.py:12-18)
         self.smpl_verts = server.verts_c
         self.smpl_weights = server.tables.lbs_weights[None]

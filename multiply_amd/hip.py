@@ -415,26 +415,35 @@ def grad_net(imp):
     return g.refresh()
 
 
-SEG_POINTS = 1 << 21          # work items per segment of the reverse-mode shading: 8 GiB of stored sigmoids
+SEG_POINTS = int(os.environ.get("MP_SEG_POINTS", 1 << 21))   # work items per segment of the reverse-mode shading (x 4 KiB of stored sigmoids)
 
 
-def sig_scratch(device):
-    """per-device buffer for the stored sigmoids of the reverse-mode shading kernels.  Zero-initialised once: the K steps
-    a narrower layer never writes (layer 3 has 217 outputs) must read as finite numbers in the reverse sweep."""
+def sig_scratch(device, n_points):
+    """(buffer, segment size) for the stored sigmoids of the reverse-mode shading kernels: 4 KiB per work item of ONE
+    segment, sized to the call (min(n rounded up to a tile, SEG_POINTS)) and grown on demand -- never the fixed 8 GiB.
+    New parts are zero-initialised: the K steps a narrower layer never writes (layer 3 has 217 outputs) must read as finite
+    numbers in the reverse sweep."""
+    seg = min(SEG_POINTS, max(256, (int(n_points) + 255) // 256 * 256))
     key = str(device)
     buf = _SCRATCH.get(key)
-    if buf is None:
-        buf = _SCRATCH[key] = torch.zeros(SEG_POINTS * 4096, dtype=torch.uint8, device=device)
-    return buf
+    if buf is None or buf.numel() < seg * 4096:
+        grown = torch.empty(seg * 4096, dtype=torch.uint8, device=device)
+        old = 0 if buf is None else buf.numel()
+        if old:
+            grown[:old] = buf
+        grown[old:].zero_()
+        buf = _SCRATCH[key] = grown
+    return buf, seg
 
 
 _SCRATCH = {}
 
 
 def shade_rev_launch(pki, gn, x_c, jinv, worklist, count, n, sdf, nrm, feat):
+    buf, seg = sig_scratch(x_c.device, n)
     check(lib().mp_mlp_shade_rev(C.byref(pki.net), ptr(pki.wpack), ptr(pki.bias), C.byref(gn.pk.net), ptr(gn.pk.wpack),
                                  ptr(gn.w8), ptr(x_c), ptr(jinv), ptr(worklist), ptr(count), n, ptr(sdf), ptr(nrm),
-                                 ptr(feat), ptr(sig_scratch(x_c.device)), SEG_POINTS, stream()), "mp_mlp_shade_rev")
+                                 ptr(feat), ptr(buf), seg, stream()), "mp_mlp_shade_rev")
 
 
 def shade_points(imp, ren, x_c, jinv, cond_vec, mode=None):

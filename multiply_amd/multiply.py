@@ -2,7 +2,9 @@
 
 Drop-in for `lib.model.multiply.Multiply` (reference code/lib/model/multiply.py:23-598):
   * constructor Multiply(opt, betas_path) building the same sub-module tree, in the same order and with the same
-    state-dict names (multiply.py:35-100), so checkpoints load and seeded initialisation is bit-identical;
+    state-dict names (multiply.py:35-100) -- including the SMPL tables under smpl_server_list.N.smpl.* and
+    deformer_list.N.smpl.smpl.* -- so the reference's checkpoints load with strict=True (tests/test_state_dict_gpu.py) and
+    seeded initialisation is bit-identical;
   * forward(input, id=-1, cond_zero_shit=False, canonical_pose=False) -> the reference's output dict
     (multiply.py:566-597);
   * the attributes the Lightning module reaches into.
@@ -63,8 +65,15 @@ class Multiply(nn.Module):
             raise NotImplementedError("only the SMPL deformer branch exists in the reference's shipped configs")
 
         if gender_list is None:
+            # multiply.py:71: gender.npy next to mean_shape.npy.  Without it the reference fails; a silent default would
+            # pick the wrong body model -- only the explicit synthetic-table route (tests, benchmarks) has no genders.
             gpath = betas_path[:-14] + "gender.npy" if isinstance(betas_path, str) else None
-            gender_list = np.load(gpath) if gpath and os.path.exists(gpath) else ["male"] * self.num_person
+            if gpath and os.path.exists(gpath):
+                gender_list = np.load(gpath)
+            elif smpl_tables is not None:
+                gender_list = ["male"] * self.num_person
+            else:
+                raise FileNotFoundError(f"gender.npy not found ({gpath}); pass gender_list=[...] explicitly")
         self.gender_list = gender_list
         device = torch.device("cuda")
         cache = {}
@@ -89,10 +98,14 @@ class Multiply(nn.Module):
         self.density = LaplaceDensity(**opt.density)
         self.bg_density = AbsDensity()
         self.ray_sampler = ErrorBoundSampler(self.sdf_bounding_sphere, inverse_sphere_bg=True, **opt.ray_sampler)
-        if opt.get("smpl_init", False):
-            import warnings
-            warnings.warn("smpl_init: outputs/smpl_init_male_256.pth is an asset of the reference that is not shipped; "
-                          "load it with load_state_dict(strict=False) on foreground_implicit_network_list if you have it")
+        if opt.get("smpl_init", False):      # multiply.py:101-108
+            path = os.path.abspath(opt.get("smpl_init_path", "./outputs/smpl_init_male_256.pth"))
+            if not os.path.exists(path):
+                raise FileNotFoundError(f"smpl_init is set but {path} (an asset of the reference, not shipped here) is missing; "
+                                        f"set smpl_init: false to start from the geometric initialisation instead")
+            state = torch.load(path, map_location=device)
+            for net in self.foreground_implicit_network_list:
+                net.load_state_dict(state["model_state_dict"], strict=False)
         self.mesh_v_cano_list = [s.verts_c for s in self.smpl_server_list]
         self.mesh_f_cano_list = [torch.tensor(s.smpl.faces.astype(np.int64), device=device) for s in self.smpl_server_list]
         self.mesh_face_vertices_list = [v[0][f] [None] for v, f in zip(self.mesh_v_cano_list, self.mesh_f_cano_list)]
@@ -195,6 +208,8 @@ class Multiply(nn.Module):
             inv_index = torch.empty(R, **i32)
             if "hit_index" in input and input["hit_index"] is not None:
                 hi = input["hit_index"][p].to(dev).to(torch.int32).contiguous()
+                if hi.numel() == 0:      # multiply.py:262-263: no ray meets the box -> ray 0
+                    hi = torch.zeros(1, dtype=torch.int32, device=dev)
                 hit_index[:hi.numel()] = hi
                 hip.check(L.mp_ray_hits_from_index(hip.ptr(hit_index), hi.numel(), R, hip.ptr(counts[n:n + 1]),
                                                    hip.ptr(inv_index), st), "mp_ray_hits_from_index")

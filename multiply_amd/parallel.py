@@ -21,6 +21,41 @@ def shard_bounds(n_rays, world, group):
     return bounds
 
 
+def shard_indices_interleaved(n_rays, world, group):
+    """Load-balanced sharding of ONE frame (body rays cost ~30x background-only rays, so contiguous slices
+    of the image are badly balanced): the frame's convergence groups (`group` consecutive rays -- with the tile-ordered
+    ray list of bench.py a 64x8-pixel block) are dealt round robin, rank r takes groups r, r + world, ...  Cutting at
+    whole groups keeps the sampler's vote (ray_sampler.py:137) per group, so every pixel equals the single-process render
+    with convergence_group = group.  Returns one ascending long tensor of ray ids per rank."""
+    n_groups = (n_rays + group - 1) // group
+    ids = torch.arange(n_rays)
+    gid = ids // group
+    return [ids[gid % world == r] for r in range(world)]
+
+
+def shard_input_interleaved(inp, rank, world, group):
+    """The rank's interleaved share of a Multiply.forward input dict and the ray ids it holds."""
+    idx = shard_indices_interleaved(inp["uv"].shape[1], world, group)[rank]
+    out = dict(inp)
+    out["uv"] = inp["uv"][:, idx.to(inp["uv"].device)].contiguous()
+    return out, idx
+
+
+def gather_rays_interleaved(local, n_rays, world, group):
+    """all_gather of per-ray outputs of an interleaved sharding into (n_rays, ...) in the frame's ray order (every rank gets
+    the whole image: one collective of (n_rays / world) rows per rank)."""
+    shards = shard_indices_interleaved(n_rays, world, group)
+    width = max(len(s) for s in shards)
+    pad = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    out = torch.empty((n_rays,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    for b, s in zip(bufs, shards):
+        out[s.to(local.device)] = b[:len(s)]
+    return out
+
+
 def shard_input(inp, rank, world, group):
     """The rank's slice of a Multiply.forward input dict (only `uv` is per-ray)."""
     n = inp["uv"].shape[1]

@@ -3,7 +3,8 @@
 Mirrors the constructor / attribute / forward contract of the reference's SMPLServer (code/lib/model/smpl.py:6-94) and
 of the SMPL class it wraps (code/lib/smpl/body_models.py:60-365) for what the hot path and its callers read:
 `verts_c`, `joints_c`, `tfs_c_inv`, `faces`, `smpl.faces`, `bone_parents`, `param_canonical`, and
-forward(scale, transl, thetas, betas, absolute=False) -> {'smpl_verts','smpl_tfs','smpl_jnts','smpl_weights'}.
+forward(scale, transl, thetas, betas, absolute=False) -> {'smpl_verts','smpl_tfs','smpl_jnts','smpl_all_jnts',
+'smpl_weights'}; the SMPL sub-module's parameters / buffers keep the reference's state-dict names.
 The arithmetic (blend shapes, Rodrigues, kinematic chain, LBS) runs in csrc/geom.hip (mp_smpl_pose).
 """
 import os
@@ -88,12 +89,41 @@ def knn_cluster_perm(verts_np):
     return perm
 
 
-class _SMPLHandle:
-    """stands in for `smpl_server.smpl` (only `.faces` / `.bone_parents` are read by callers)"""
+FACE_KEYPOINT_VERTS = (332, 6260, 2800, 4071, 583)   # nose, reye, leye, rear, lear (lib/smpl/vertex_ids.py 'smplh')
+
+
+class _VertexJointSelector(nn.Module):
+    """lib/smpl/vertex_joint_selector.py with use_hands=False, use_feet_keypoints=False (smpl.py:12-17): the five face
+    keypoints appended to the 24 kinematic joints."""
+
+    def __init__(self, device):
+        super().__init__()
+        self.register_buffer("extra_joints_idxs", torch.tensor(FACE_KEYPOINT_VERTS, dtype=torch.long, device=device))
+
+
+class _SMPLModule(nn.Module):
+    """Stands in for `smpl_server.smpl` (lib/smpl/body_models.py SMPL): callers read `.faces` / `.bone_parents`, and its
+    registered parameters / buffers are part of the checkpoint contract -- the reference's state dict carries
+    `smpl_server_list.N.smpl.{betas,global_orient,body_pose,transl,faces_tensor,v_template,shapedirs,J_regressor,posedirs,
+    parents,lbs_weights}` and `...smpl.vertex_joint_selector.extra_joints_idxs` (body_models.py:152-249), the same again
+    under `deformer_list.N.smpl.smpl.`.  The buffers ALIAS the device tables the kernels read (same shapes and layouts as
+    the reference's), so a loaded checkpoint's tables are the ones used."""
 
     def __init__(self, tables):
+        super().__init__()
+        dev = tables.v_template.device
         self.faces = tables.faces
         self.bone_parents = tables.parents_np.copy()
+        self.vertex_joint_selector = _VertexJointSelector(dev)
+        self.register_buffer("faces_tensor", torch.from_numpy(tables.faces).to(dev))
+        z = lambda n: nn.Parameter(torch.zeros(1, n, dtype=torch.float32, device=dev), requires_grad=True)
+        self.betas, self.global_orient, self.body_pose, self.transl = z(10), z(3), z(69), z(3)   # body_models.py:158-211
+        self.register_buffer("v_template", tables.v_template)
+        self.register_buffer("shapedirs", tables.shapedirs)
+        self.register_buffer("J_regressor", tables.j_regressor)
+        self.register_buffer("posedirs", tables.posedirs)
+        self.register_buffer("parents", torch.from_numpy(tables.parents_np.copy()).to(dev))          # long, parents[0] = -1
+        self.register_buffer("lbs_weights", tables.lbs_weights)
 
 
 class SMPLServer(nn.Module):
@@ -105,7 +135,7 @@ class SMPLServer(nn.Module):
         device = torch.device(device or "cuda")
         raw = smpl_tables if smpl_tables is not None else load_smpl_tables(gender)
         self.tables = raw if isinstance(raw, SMPLDeviceTables) else SMPLDeviceTables(raw, device)
-        self.smpl = _SMPLHandle(self.tables)
+        self.smpl = _SMPLModule(self.tables)
         self.faces = self.tables.faces
         self.bone_parents = self.tables.parents_np.astype(int)
         self.bone_ids = [[int(self.bone_parents[i]), i] for i in range(NUM_JOINTS)]
@@ -146,5 +176,8 @@ class SMPLServer(nn.Module):
         tfs = torch.empty(NUM_JOINTS, 4, 4, dtype=torch.float32, device=dev)
         jnts = torch.empty(NUM_JOINTS, 3, dtype=torch.float32, device=dev)
         self.pose_into(p, verts, tfs, jnts, absolute=absolute)
-        return {"smpl_verts": verts[None], "smpl_jnts": jnts[None], "smpl_tfs": tfs[None],
+        # smpl_all_jnts: the 24 kinematic joints + the face keypoint vertices (body_models.py:345; smpl.py:83-84) -- the
+        # vertices are already scaled / translated exactly like the joints (smpl.py:77-84)
+        all_jnts = torch.cat([jnts, verts[self.smpl.vertex_joint_selector.extra_joints_idxs]], 0)
+        return {"smpl_verts": verts[None], "smpl_jnts": jnts[None], "smpl_all_jnts": all_jnts[None], "smpl_tfs": tfs[None],
                 "smpl_weights": self.tables.lbs_weights[None]}

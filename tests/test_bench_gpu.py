@@ -1,0 +1,56 @@
+"""bench.py's contract (the driver depends on it): one JSON line with the headline metric, `roofline` and `cpu_baseline`
+at N = 1; `--gpus N` starts N ranks itself (or asserts the launcher's WORLD_SIZE) and reports n_gpus = N with the
+strong-scaling leg of one frame.  Small frames so that the whole file runs in about a minute."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=e, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_roofline_and_cpu_baseline():
+    d = _run(["--res", "64", "--steps", "2", "--warmup", "1", "--train-steps", "2", "--train-warmup", "1", "--cpu-rays", "128",
+              "--cpu-train-iters", "1"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "rays/s" and d["value"] > 0 and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c and c["parity_rgb_max_abs"] < 8e-3
+    t = d["train_iter"]
+    assert t["ms_per_iter"] > 0 and t["rays_per_iter"] == 512 and t["cpu_baseline"]["value"] > 0 and 0 < t["roofline"]["frac"] < 1
+
+
+def test_gpus_flag_starts_the_ranks_and_reports_strong_scaling():
+    """`python bench.py --gpus 2` with no launcher: two ranks (sharing this box's GPU over gloo), n_gpus = 2, the frame's
+    convergence groups split between them, the weak-scaling leg beside it"""
+    d = _run(["--gpus", "2", "--res", "64", "--steps", "2", "--warmup", "1", "--train-steps", "2", "--train-warmup", "1"],
+             env={"MP_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and "cpu_baseline" not in d
+    assert d["config"]["rays_per_step"] == 64 * 64 and "ray-sharded dp2" in d["config"]["parallelism"]
+    assert d["weak"]["scaling"] == "weak" and d["weak"]["value"] > 0
+    assert d["train_iter"]["rays_per_iter_per_gpu"] == 256 and d["train_iter"]["rays_per_iter"] == 512
+
+
+def test_world_size_mismatch_is_refused():
+    e = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--res", "64"], cwd=ROOT, env=e,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode != 0 and "--gpus 2" in (r.stderr + r.stdout)

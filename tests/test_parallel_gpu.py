@@ -18,6 +18,13 @@ def _run_two_ranks(script, port_base):
     assert r.returncode == 0
 
 
+def test_ray_sharded_render_and_dp_training_match_the_oracle():
+    """BASELINE.json configs[2] on two ranks: interleaved ray shards rendered by the HIP path vs the CPU oracle on the same
+    rays, the gathered image vs the single-process render, and a data-parallel training step (flat gradient all-reduce) vs
+    the oracle's averaged torch-autograd gradients"""
+    _run_two_ranks("dist_ray_sharded.py", 29300)
+
+
 def test_person_sharded_render_matches_single_process():
     _run_two_ranks("dist_person_sharded.py", 29600)
 

@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from oracle import multiply_oracle as O
+from tests import tolerances as TOL
 from tests.test_render_gpu import build, report
 
 pytestmark = pytest.mark.gpu
@@ -60,8 +61,7 @@ def test_training_sampler_matches_oracle_with_same_draws():
         z, it_o = O.error_bound_sample(oracle.cfg, dirs, cam, fn, oracle.beta().detach(),
                                        dict(t_rand=d["t_rand"], u_final=d["u_final"], extra_idx=d["extra_idx"].long()))
         print("[info] iterations oracle", it_o, "gpu", iters.tolist())
-        mx, mean = report(f"train z_vals person {p}", zfinal, z)
-        assert mean < 2e-3 and mx < 0.3
+        assert TOL.within(report(f"train z_vals person {p}", zfinal, z), TOL.TRAIN_Z_VALS)
 
 
 def test_training_forward_loss_and_all_parameter_gradients():
@@ -91,8 +91,7 @@ def test_training_forward_loss_and_all_parameter_gradients():
     gw = torch.autograd.grad(lw["loss"], [oracle.sd[k] for k in names], allow_unused=True)
 
     # forward: fp32 vs fp32, different summation orders only
-    for k, tol in (("rgb_values", 2e-4), ("acc_map", 2e-4), ("acc_person_list", 2e-4), ("grad_theta", 2e-4),
-                   ("normal_values", 1e-3)):
+    for k, tol in TOL.TRAIN_FWD.items():
         mx, mean = report("train " + k, out[k], want[k].detach())
         assert mx < tol, k
     for k in ("loss", "rgb_loss", "eikonal_loss", "bce_loss", "sam_mask_loss", "temporal_loss"):
@@ -105,6 +104,8 @@ def test_training_forward_loss_and_all_parameter_gradients():
     got = dict(model.named_parameters())
     worst = 0.0
     for k, g in zip(names, gw):
+        if k not in got:          # registered buffers (the SMPL tables) are part of the state dict, not parameters
+            continue
         a = got[k].grad
         if g is None:
             assert a is None or float(a.abs().max()) == 0.0, k
@@ -114,7 +115,7 @@ def test_training_forward_loss_and_all_parameter_gradients():
         b = g.double().reshape(-1)
         rel = float((a - b).norm() / (b.norm() + 1e-12))
         worst = max(worst, rel)
-        tol = 2e-2 if "rendering" in k else 5e-3
+        tol = TOL.TRAIN_GRAD_REL_RENDERING if "rendering" in k else TOL.TRAIN_GRAD_REL
         assert rel < tol or float((a - b).abs().max()) < 1e-7, f"{k}: rel {rel:.3e} |g| {float(b.norm()):.3e}"
     print(f"[parity] worst relative parameter-gradient error {worst:.3e} over {len(names)} tensors")
 
