@@ -39,8 +39,14 @@ class Loss(nn.Module):
         self.depth_loss_milestone = 1000
 
     # -- individual terms (names kept: the reference's trainer logs them one by one)
-    def get_rgb_loss(self, rgb_values, rgb_gt):
-        return (rgb_values - rgb_gt).abs().mean()
+    # The reductions below never read a device value on the host (no boolean-mask indexing, no `if tensor:`): a training
+    # iteration enqueues forward, loss and backward without waiting for the GPU.  Masked means are sum(mask * x) / sum(mask),
+    # the same numbers as the reference's x[mask].mean() (0/0 = NaN where the reference's empty mean is NaN).
+    def get_rgb_loss(self, rgb_values, rgb_gt, keep=None):
+        d = (rgb_values - rgb_gt).abs()
+        if keep is None:
+            return d.mean()
+        return torch.where(keep[:, None], d, torch.zeros_like(d)).sum() / (keep.sum() * d.shape[1])
 
     def get_eikonal_loss(self, grad_theta):
         return (grad_theta.norm(2, dim=-1) - 1).square().mean()
@@ -49,28 +55,37 @@ class Loss(nn.Module):
         a = acc_map
         return -2.0 * (a * (a + self.eps).log() + (1 - a) * (1 - a + self.eps).log()).mean()
 
+    @staticmethod
+    def _masked_mean(x, mask):
+        return torch.where(mask, x, torch.zeros_like(x)).sum() / mask.sum()
+
     def get_opacity_sparse(self, acc_map, index_off_surface):
-        return acc_map[index_off_surface].abs().mean()
+        return self._masked_mean(acc_map.abs(), index_off_surface)
 
     def get_in_shape_loss(self, acc_map, index_in_surface):
-        return (acc_map[index_in_surface] - 1).abs().mean()
+        return self._masked_mean((acc_map - 1).abs(), index_in_surface)
 
     def get_sam_mask_loss(self, sam_mask, acc_person):
         prob = torch.sigmoid(sam_mask)
-        ok = prob.sum(dim=1) <= 1.01
-        return (acc_person[ok] - prob[ok]).abs().mean()
+        ok = (prob.sum(dim=1) <= 1.01)[:, None].expand_as(prob)
+        return self._masked_mean((acc_person - prob).abs(), ok)
 
     def get_sam_mask_clip_loss(self, sam_mask, acc_person):
         n_ray, n_person = sam_mask.shape[0], sam_mask.shape[1]
         prob = torch.sigmoid(sam_mask)
-        ok = prob.sum(dim=1) <= 1.01                       # rays whose SAM masks do not overlap
-        a, m = acc_person[ok].reshape(-1), prob[ok].reshape(-1)
+        ok = (prob.sum(dim=1) <= 1.01)[:, None].expand_as(prob)        # rays whose SAM masks do not overlap
+        a, m = acc_person, prob
         agree = ((a < 0.04) & (m < 0.04)) | ((a > 0.96) & (m > 0.96))
-        keep = ~agree
-        if keep.sum() == 0:
-            print("clip_mask is all False")
-            keep[0] = True
-        return (a[keep] - m[keep]).abs().sum() / (n_ray * n_person)
+        keep = ok & ~agree
+        # loss.py:72-75: if nothing is kept the reference keeps the FIRST element of the selected rays ("clip_mask is all
+        # False"): position of the first selected element, computed on the device
+        first = torch.zeros_like(keep).reshape(-1)
+        okf = ok.reshape(-1)
+        idx = torch.argmax(okf.to(torch.int32))                        # first True (0 if none)
+        first[idx] = True
+        first = first.reshape(keep.shape) & ok
+        keep = torch.where(keep.any(), keep, first)
+        return torch.where(keep, (a - m).abs(), torch.zeros_like(a)).sum() / (n_ray * n_person)
 
     def get_depth_order_loss_samGT(self, t_list, mean_hitted_vertex_list, sam_mask, cam_loc):
         import numpy as np
@@ -94,21 +109,18 @@ class Loss(nn.Module):
             depth_order_loss = self.get_depth_order_loss_samGT(mo["t_list"], mo["mean_hitted_vertex_list"], sam,
                                                                mo["cam_loc"][mo["hitted_mask_idx"]])
 
-        finite = ~torch.any(mo["rgb_values"].isnan(), dim=1)
+        finite = ~torch.any(mo["rgb_values"].isnan(), dim=1)           # loss.py:120-122: rays with a NaN pixel are left out
         rgb_gt = ground_truth["rgb"][0].to(dev)
-        rgb_loss = self.get_rgb_loss(mo["rgb_values"][finite], rgb_gt[finite])
+        rgb_loss = self.get_rgb_loss(torch.nan_to_num(mo["rgb_values"]), rgb_gt, keep=finite)
         eikonal_loss = self.get_eikonal_loss(mo["grad_theta"])
         bce_loss = self.get_bce_los(mo["acc_map"])
-        if bce_loss.isnan():
-            print("Nan: bce_loss")
-            bce_loss = zero()
+        bce_loss = torch.where(bce_loss.isnan(), torch.zeros_like(bce_loss), bce_loss).reshape(1)    # loss.py:124-128 (its
+        # "Nan: bce_loss" print would need the value on the host)
         opacity_sparse_loss = zero()
         if mo["index_in_surface"] is not None:
             in_shape_loss = self.get_in_shape_loss(mo["acc_map"], mo["index_in_surface"])
+            in_shape_loss = torch.where(in_shape_loss.isnan(), torch.zeros_like(in_shape_loss), in_shape_loss).reshape(1)
         else:
-            in_shape_loss = zero()
-        if in_shape_loss.isnan():
-            print("Nan: in_shape_loss")
             in_shape_loss = zero()
 
         e200 = min(self.milestone, epoch)

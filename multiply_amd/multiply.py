@@ -154,9 +154,36 @@ class Multiply(nn.Module):
         with torch.no_grad():
             return self._forward_eval(input, id, canonical_pose)
 
-    def _setup(self, input, id, canonical_pose):
+    def _setup(self, input, id, canonical_pose, side_stream=False):
         """Rays, SMPL posing, nearest-vertex structures and the box cull for every person of the call
-        (multiply.py:177-266).  Ends with the one host sync of the call (hit counts size the workspaces)."""
+        (multiply.py:177-266).  Ends with the one host sync of the call (hit counts size the workspaces).
+
+        side_stream (training): the setup kernels read only the call's inputs -- never a network weight -- so they run on a
+        stream of their own and the host waits for THAT stream only: it does not wait for the previous iteration's backward
+        pass still running on the caller's stream, and keeps enqueueing (the GPU never idles between iterations).  The
+        inputs must be resident and complete (produced by work the host has already waited for, e.g. a data loader's
+        copies); everything allocated here is handed to the caller's stream (record_stream + an event wait)."""
+        if side_stream:
+            main = torch.cuda.current_stream()
+            side = self.__dict__.get("_setup_stream")
+            if side is None:
+                side = self.__dict__["_setup_stream"] = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                cx = self._setup(input, id, canonical_pose)
+
+            def hand_over(o):
+                if torch.is_tensor(o):
+                    if o.is_cuda:
+                        o.record_stream(main)
+                elif isinstance(o, dict):
+                    for v in o.values():
+                        hand_over(v)
+                elif isinstance(o, (list, tuple)):
+                    for v in o:
+                        hand_over(v)
+            hand_over(cx)
+            main.wait_stream(side)
+            return cx
         L = hip.lib()
         dev = self.density.beta.device
         f32 = dict(dtype=torch.float32, device=dev)

@@ -755,7 +755,9 @@ def forward_train(model, input, id=-1, cond_zero_shit=False, canonical_pose=Fals
     if shard is not None:                   # person-sharded: this rank evaluates persons {p : p % world == rank}
         assert id == -1, "person-sharded training renders all persons"
         id = [p for p in range(int(input["smpl_trans"].shape[1])) if p % shard[0] == shard[1]]
-    cx = model._setup(input, id, canonical_pose)
+    # the setup's one host sync must not wait for the previous iteration's backward pass (Multiply._setup); opt in when the
+    # inputs are resident (model.async_setup = True: bench.py, a prefetching data loader)
+    cx = model._setup(input, id, canonical_pose, side_stream=bool(getattr(model, "async_setup", False)))
     dev = cx["dev"]
     cond_zero = epoch < 20 or epoch % 20 == 0 or bool(cond_zero_shit)              # multiply.py:271-273
     if draws is None:
