@@ -5,6 +5,7 @@ missing or the device is not a gfx950, importing/using this module raises.
 PyTorch is used for device memory and streams only (tensor.data_ptr(), torch.cuda.current_stream()).
 """
 import ctypes as C
+import functools
 import math
 import os
 
@@ -476,9 +477,51 @@ def shade_points(imp, ren, x_c, jinv, cond_vec, mode=None):
     return sdf, nrm, rgb
 
 
+@functools.lru_cache(maxsize=None)
+def _feat_frag_index():
+    """feature index of [ks][g][e] in the colour kernel's operand-fragment order (csrc/mlp_core.hpp K permutation)"""
+    idx = np.empty((8, 4, 8), dtype=np.int64)
+    for ks in range(8):
+        for g in range(4):
+            for e in range(8):
+                idx[ks, g, e] = 32 * ks + (4 * g + e if e < 4 else 16 + 4 * g + e - 4)
+    return idx
+
+
+def pack_feature_fragments(feat):
+    """(N, 256) fp32 features -> the f16 fragment stream mp_mlp_color reads:
+    [tile of 64 items][K step][16-column block][lane = column + 16 g][8 halves] (the layout k_mlp_fwdsave writes)."""
+    n, dev = feat.shape[0], feat.device
+    tiles = (n + 255) // 256 * 4
+    f = torch.zeros(tiles * 64, 256, dtype=torch.float32, device=dev)
+    f[:n] = feat
+    idx = torch.from_numpy(_feat_frag_index()).to(dev)                     # (8, 4, 8)
+    frag = f.reshape(tiles, 4, 16, 256)[:, :, :, idx]                      # (tile, block, j, ks, g, e)
+    frag = frag.permute(0, 3, 1, 4, 2, 5).contiguous()                     # (tile, ks, block, g, j, e): lane = j + 16 g
+    return frag.to(torch.float16).reshape(-1).view(torch.uint8)
+
+
 def rendering_forward(net, points, normals, view_dirs, body_pose, feature_vectors, frame_latent_code):
-    raise NotImplementedError("RenderingNet is evaluated inside the fused kernels (hip.shade_points / background); "
-                              "a standalone forward with externally supplied fp32 features is not part of the hot path")
+    """RenderingNet.forward for external callers (networks.py:263-312), mode 'pose_no_view': rgb (N, 3) from canonical
+    points, normals, the pose conditioning (69,) and (N, 256) feature vectors, through mp_mlp_color (features are rounded to
+    f16 operands like everywhere on the inference path).  The background network ('nerf_frame_encoding') exists only fused
+    into mp_background (its inputs never leave the kernel): a standalone call raises."""
+    require_device()
+    if net.mode != "pose_no_view":
+        raise NotImplementedError("the background RenderingNet is evaluated inside mp_background only (hip.background)")
+    x = points.detach().float().reshape(-1, 3).contiguous()
+    nrm = normals.detach().float().reshape(-1, 3).contiguous()
+    n = x.shape[0]
+    cond_vec = body_pose.detach().float().reshape(-1).contiguous()
+    pk = packed(net, "color", 2)
+    pe = net.__dict__.get("_mp_pose_embed") or PoseEmbed(net)
+    net.__dict__["_mp_pose_embed"] = pe
+    pk.refresh(pe(cond_vec))
+    frag = pack_feature_fragments(feature_vectors.detach().float().reshape(n, -1))
+    rgb = torch.empty(n, 3, dtype=torch.float32, device=x.device)
+    check(lib().mp_mlp_color(C.byref(pk.net), ptr(pk.wpack), ptr(pk.bias), ptr(x), ptr(nrm), ptr(frag), None, None, n, ptr(rgb),
+                             stream()), "mp_mlp_color")
+    return rgb
 
 
 def background(bg_imp, bg_ren, dirs, cam, z_bg, frame_code, radius=3.0):

@@ -181,6 +181,82 @@ def largest_component(verts, faces):
     return verts[torch.from_numpy(used).to(verts.device)], torch.from_numpy(remap[fk]).to(faces.device)
 
 
+class ExtractedMesh:
+    """What `generate_mesh` returns: the attribute surface of the `trimesh.Trimesh` the reference hands to its callers
+    (lib/utils/mesh.py:117-131; multiply_model.py:311-314, 504-505, 845-847, 1180: `.vertices`, `.faces` as numpy arrays,
+    `.split(only_watertight=False)`, `.area`, `.export(path)`), plus the device tensors the hot path re-uses
+    (`vertices_t`, `faces_t`) and the extraction record (`value_grid`, `lattice_vertices`, `resolution`, `n_queried`).
+    `mesh["vertices"]` / `mesh["faces"]` (device tensors) keep the dictionary access of the earlier interface."""
+
+    def __init__(self, vertices_t, faces_t, **info):
+        self.vertices_t, self.faces_t = vertices_t, faces_t
+        self.vertices = vertices_t.detach().cpu().numpy()
+        self.faces = faces_t.detach().cpu().numpy().astype(np.int64)
+        self.info = info
+
+    def __getitem__(self, k):
+        if k == "vertices":
+            return self.vertices_t
+        if k == "faces":
+            return self.faces_t
+        return self.info[k]
+
+    def __getattr__(self, k):          # value_grid, lattice_vertices, resolution, n_queried
+        info = self.__dict__.get("info", {})
+        if k in info:
+            return info[k]
+        raise AttributeError(k)
+
+    @property
+    def area(self):
+        v, f = self.vertices.astype(np.float64), self.faces
+        return float(0.5 * np.linalg.norm(np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]]), axis=1).sum())
+
+    @property
+    def is_watertight(self):
+        """every edge is shared by exactly two faces, traversed once in each direction"""
+        f = self.faces
+        e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+        key = e[:, 0] * (f.max() + 1) + e[:, 1]
+        rev = e[:, 1] * (f.max() + 1) + e[:, 0]
+        return bool(np.unique(key).shape[0] == key.shape[0] and np.array_equal(np.sort(key), np.sort(rev)))
+
+    def split(self, only_watertight=False):
+        """connected components (by shared vertices), each an ExtractedMesh -- what trimesh's split(only_watertight=False)
+        gives the reference's largest-area selection (mesh.py:119-129)"""
+        from scipy.sparse import coo_matrix
+        from scipy.sparse.csgraph import connected_components
+        f, nv = self.faces, self.vertices.shape[0]
+        if f.shape[0] == 0:
+            return []
+        rows = np.concatenate([f[:, 0], f[:, 1], f[:, 2]])
+        cols = np.concatenate([f[:, 1], f[:, 2], f[:, 0]])
+        _, label = connected_components(coo_matrix((np.ones(rows.shape[0]), (rows, cols)), shape=(nv, nv)), directed=False)
+        out = []
+        for c in np.unique(label[f[:, 0]]):
+            fk = f[label[f[:, 0]] == c]
+            used = np.unique(fk)
+            remap = np.full(nv, -1, dtype=np.int64)
+            remap[used] = np.arange(used.shape[0])
+            dev = self.vertices_t.device
+            part = ExtractedMesh(self.vertices_t[torch.from_numpy(used).to(dev)], torch.from_numpy(remap[fk]).to(dev))
+            if not only_watertight or part.is_watertight:
+                out.append(part)
+        return out
+
+    def export(self, path):
+        """binary little-endian PLY (vertices float32, faces int32), the format the reference's callers write"""
+        v, f = self.vertices.astype("<f4"), self.faces.astype("<i4")
+        with open(path, "wb") as fh:
+            fh.write((f"ply\nformat binary_little_endian 1.0\nelement vertex {v.shape[0]}\nproperty float x\nproperty float y\n"
+                      f"property float z\nelement face {f.shape[0]}\nproperty list uchar int vertex_indices\nend_header\n").encode())
+            fh.write(v.tobytes())
+            rec = np.empty(f.shape[0], dtype=[("n", "u1"), ("i", "<i4", (3,))])
+            rec["n"], rec["i"] = 3, f
+            fh.write(rec.tobytes())
+        return path
+
+
 def lattice_to_world(points, resolution, gt_scale, gt_center, scale=1.1):
     """mesh.py:96-98 / :113-114, fp32 like the reference"""
     p = (points.float() / resolution - 0.5) * scale
@@ -189,9 +265,16 @@ def lattice_to_world(points, resolution, gt_scale, gt_center, scale=1.1):
 
 def generate_mesh(func, verts, level_set=0.0, res_init=32, res_up=3, point_batch=None):
     """mesh.py:78-131.  func(points (k,3) fp32 device) -> values (k,) / (k,1) or {'occ': ...}; verts (V,3): the box to
-    search is their bounding cube, padded by 1.1.  Returns {'vertices' (V,3) fp32 world, 'faces' (F,3) int64,
-    'lattice_vertices', 'value_grid', 'resolution', 'n_queried'} -- outward-facing triangles of the largest component
-    (open where the level set leaves the box, like any marching-cubes surface)."""
+    search is their bounding cube, padded by 1.1.  Returns an ExtractedMesh (`.vertices` (V,3) / `.faces` (F,3) numpy like the
+    reference's trimesh object, `.split()`, `.area`, `.export()`; device tensors and the extraction record beside them):
+    the outward-facing triangles of the largest-area component (open where the level set leaves the box, like any
+    marching-cubes surface).
+
+    Triangulation: the case table is derived in build_tri_table (ambiguous faces separate their inside corners; no interior
+    ambiguity test).  skimage's Lewiner tables (mesh.py:112, third party, absent here) resolve the ambiguous configurations by
+    the asymptotic decider and so may connect a few saddle cubes differently: both surfaces pass through the same points of the
+    same lattice edges (vertex SETS identical up to skimage's own vertex ordering) and are closed and consistently oriented; they
+    differ, if at all, in how those points are joined inside ambiguous cubes.  Parity with skimage's face list is unpinned."""
     dev = torch.device("cuda")
     v = verts.detach().to(dev).float().reshape(-1, 3)
     lo, hi = v.min(dim=0).values, v.max(dim=0).values
@@ -211,8 +294,8 @@ def generate_mesh(func, verts, level_set=0.0, res_init=32, res_up=3, point_batch
     grid = ex.to_dense()
     mv, mf = marching_cubes(grid, level_set)
     mv, mf = largest_component(mv, mf)
-    return {"vertices": lattice_to_world(mv, ex.resolution, gt_scale, gt_center), "faces": mf, "lattice_vertices": mv,
-            "value_grid": grid, "resolution": ex.resolution, "n_queried": ex.n_queried}
+    return ExtractedMesh(lattice_to_world(mv, ex.resolution, gt_scale, gt_center), mf, lattice_vertices=mv, value_grid=grid,
+                         resolution=ex.resolution, n_queried=ex.n_queried)
 
 
 def canonical_mesh(model, person, cond=None, res_init=32, res_up=2):

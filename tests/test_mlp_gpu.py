@@ -49,6 +49,25 @@ def test_implicit_full_and_sdf(nets_gpu):
     assert report("bg implicit feat", got[:, 1:], want[:, 1:]) < TOL.MLP["bg_feat"]
 
 
+def test_rendering_net_standalone_forward(nets_gpu):
+    """RenderingNet.forward (networks.py:263-312, mode pose_no_view) called like the reference does -- points, normals, view
+    dirs, body pose, fp32 feature vectors -- through the fragment packer + mp_mlp_color"""
+    m, sd = nets_gpu
+    rng = np.random.RandomState(6)
+    n = 777                                                      # not a multiple of any tile size
+    x = torch.tensor(rng.uniform(-0.9, 0.9, (n, 3)), dtype=torch.float32)
+    nrm = torch.nn.functional.normalize(torch.tensor(rng.normal(0, 1, (n, 3)), dtype=torch.float32), dim=1)
+    cond = torch.tensor(rng.normal(0, 0.1, 69), dtype=torch.float32)
+    feat = torch.tensor(rng.normal(0, 0.5, (n, 256)), dtype=torch.float32)
+    want = O.rendering_forward_pose_no_view(sd, "foreground_rendering_network_list.1.", x, nrm, cond, feat)
+    net = m.foreground_rendering_network_list[1]
+    got = net(x.cuda(), nrm.cuda(), None, cond.cuda()[None], feat.cuda())
+    assert got.shape == (n, 3)
+    assert report("standalone RenderingNet rgb", got, want[:, :3]) < 3e-5      # f16-rounded external features: measured 4.9e-6
+    with pytest.raises(NotImplementedError):
+        m.bg_rendering_network(None, None, x.cuda(), None, feat.cuda(), torch.zeros(1, 32).cuda())
+
+
 def test_shade_points(nets_gpu):
     from multiply_amd import hip
     m, sd = nets_gpu

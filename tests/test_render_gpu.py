@@ -294,3 +294,31 @@ def test_render_views_equal_separate_calls_and_the_chunked_loop():
         for k, v in merged.items():
             got = grouped[i][k].reshape(v.shape)
             assert torch.equal(torch.nan_to_num(got), torch.nan_to_num(v)), (i, k)
+
+
+def test_single_person_model_betas_1d():
+    """Multiply(opt, betas of ONE person as a 1-D array) (multiply.py:47, 76-78, 95-97 `else` branches): one network pair, one
+    server / deformer, (R, 1) person maps; vs the oracle"""
+    import warnings
+    warnings.filterwarnings("ignore")
+    from multiply_amd.config import load_config
+    from multiply_amd.multiply import Multiply
+    from multiply_amd.synthetic import make_scene, make_smpl_tables
+    tables = make_smpl_tables(0)
+    sc = make_scene(1, seed=2, H=14, W=14)
+    torch.manual_seed(0)
+    model = Multiply(load_config(), sc["smpl_params"][0, 0, 76:], smpl_tables=tables).eval()      # shape (10,)
+    assert model.num_person == 1 and len(model.foreground_implicit_network_list) == 1 and len(model.deformer_list) == 1
+    sp = t32(sc["smpl_params"])
+    inp = dict(uv=t32(sc["uv"]), intrinsics=t32(sc["intrinsics"]), pose=t32(sc["pose"]), smpl_params=sp,
+               smpl_pose=sp[:, :, 4:76], smpl_shape=sp[:, :, 76:], smpl_trans=sp[:, :, 1:4], idx=torch.tensor([1]))
+    got = model(_gpu(inp))
+    torch.cuda.synchronize()
+    R = inp["uv"].shape[1]
+    assert got["acc_person_list"].shape == (R, 1)
+    hit = [model._last["per"][0]["hit_index"][:model.last_stats["n_hit"][0]].long().cpu()]
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    want = O.MultiplyOracle(sd, tables, sc["smpl_params"][0, :, 76:]).forward_eval(inp, hit)
+    for k in ("rgb_values", "acc_map", "normal_values"):
+        assert TOL.within(report("single person " + k, got[k], want[k]), TOL.EVAL[k]), k
+    assert torch.equal(got["acc_map"], got["acc_person_list"][:, 0])
