@@ -111,6 +111,10 @@ class Multiply(nn.Module):
         self.mesh_face_vertices_list = [v[0][f] [None] for v, f in zip(self.mesh_v_cano_list, self.mesh_f_cano_list)]
         self.convergence_group = None
         self.obb_inflate = 1.2
+        # cull box (multiply.py:208-214): "pca" = principal-axes box on the device (k_obb; conservative, identical eval pixels),
+        # "hull" = the minimum-volume box trimesh's bounding_box_oriented computes, by the published algorithm on the host
+        # (multiply_amd/obb.py; one device sync + ~10-100 ms of CPU work per person and call, like the reference)
+        self.obb_mode = os.environ.get("MP_OBB_MODE", "pca")
         self.last_stats = {}
         self.profile = False
         self.phase_events = {}
@@ -233,6 +237,7 @@ class Multiply(nn.Module):
                       "mp_knn_build")
             hit_index = torch.empty(R, **i32)
             inv_index = torch.empty(R, **i32)
+            obb = None
             if "hit_index" in input and input["hit_index"] is not None:
                 hi = input["hit_index"][p].to(dev).to(torch.int32).contiguous()
                 if hi.numel() == 0:      # multiply.py:262-263: no ray meets the box -> ray 0
@@ -241,13 +246,17 @@ class Multiply(nn.Module):
                 hip.check(L.mp_ray_hits_from_index(hip.ptr(hit_index), hi.numel(), R, hip.ptr(counts[n:n + 1]),
                                                    hip.ptr(inv_index), st), "mp_ray_hits_from_index")
             else:
-                obb = torch.empty(16, **f32)
-                hip.check(L.mp_obb(hip.ptr(verts), C.c_float(self.obb_inflate), hip.ptr(obb), st), "mp_obb")
+                if self.obb_mode == "hull":
+                    from .obb import obb_record
+                    obb = torch.from_numpy(obb_record(verts.cpu().numpy(), self.obb_inflate)).to(dev)
+                else:
+                    obb = torch.empty(16, **f32)
+                    hip.check(L.mp_obb(hip.ptr(verts), C.c_float(self.obb_inflate), hip.ptr(obb), st), "mp_obb")
                 hip.check(L.mp_ray_cull(hip.ptr(dirs), hip.ptr(pose), hip.ptr(obb), R, group, hip.ptr(hit_index),
                                         hip.ptr(counts[n:n + 1]), hip.ptr(inv_index), hip.ptr(scan_tmp), st),
                           "mp_ray_cull")
             cond = (smpl_pose[0, p, 3:] / np.pi).contiguous()          # multiply.py:270
-            per[p] = dict(verts=verts, tfs=tfs, vsorted=vsorted, cbound=cbound, hit_index=hit_index,
+            per[p] = dict(verts=verts, tfs=tfs, vsorted=vsorted, cbound=cbound, hit_index=hit_index, obb=obb,
                           inv_index=inv_index, count=counts[n:n + 1], cond=cond, prm=prm,
                           rest_joints=server.rest_joints() if self.training else None)
         n_hit = counts.tolist()          # the one host sync of the call: sizes the per-person workspaces

@@ -104,3 +104,35 @@ def test_general_k_weight_query_and_skinning(smpl_tables):
               f"inverse {(xi.cpu() - xi_want).abs().max().item():.2e}")
         assert e < 1e-5 and (xf - xf_want).abs().max() < 1e-5 and (xi.cpu() - xi_want).abs().max() < 1e-5
         assert torch.equal(outl.cpu(), out_want)
+
+
+def test_hull_box_cull_hit_sets_match_the_published_algorithm():
+    """Multiply.obb_mode = "hull": the cull box is the minimum-volume oriented box (what the reference asks trimesh for,
+    multiply.py:208-214, 256-266).  In TRAINING mode (no outlier override: the hit set decides which samples exist) the hit
+    sets equal the brute-force restatement's (oracle/obb_oracle.py, float64) on the oracle's posed vertices -- except rays that
+    graze the box within 1e-4."""
+    import torch
+    from oracle import multiply_oracle as O
+    from oracle.obb_oracle import min_volume_obb_bruteforce, rays_hitting_box
+    from tests.test_render_gpu import build
+    model, oracle, inp = build(H=40, W=40)
+    gin = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inp.items()}
+    model.train()
+    cx_pca = model._setup(gin, -1, False)
+    model.obb_mode = "hull"
+    cx = model._setup(gin, -1, False)
+    torch.cuda.synchronize()
+    dirs, cam = O.get_camera_rays(inp["uv"][0], inp["pose"][0], inp["intrinsics"][0])
+    sp = inp["smpl_params"]
+    for n, p in enumerate(cx["persons"]):
+        got = set(cx["per"][p]["hit_index"][:cx["n_hit"][n]].tolist())
+        so = oracle.servers[p].forward(sp[0, p, 0], inp["smpl_trans"][0, p], inp["smpl_pose"][0, p], inp["smpl_shape"][0, p])
+        c, a, h, vol = min_volume_obb_bruteforce(so["smpl_verts"].numpy())
+        box = cx["per"][p]["obb"].cpu().numpy()
+        assert abs(np.prod(box[12:15]) / 1.2 ** 3 * 8 - vol) < 1e-5 * vol                   # the same minimal volume (fp32 vertices)
+        want, margin = rays_hitting_box(cam.numpy(), dirs.numpy(), c, a, 1.2 * h)
+        diff = got.symmetric_difference(set(want.tolist()))
+        assert all(abs(margin[r]) < 1e-4 for r in diff), (len(diff), [float(margin[r]) for r in list(diff)[:5]])
+        pca = set(cx_pca["per"][p]["hit_index"][:cx_pca["n_hit"][n]].tolist())
+        print(f"[parity] person {p}: hull box {len(got)} rays (oracle {len(want)}, {len(diff)} grazing), PCA box {len(pca)} rays")
+        assert 0 < len(got) < len(pca)            # the minimum-volume box is the tighter of the two (neither contains the other)
