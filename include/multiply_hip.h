@@ -341,6 +341,17 @@ int mp_mc_count(const float* val, int n, float level, const int* tri_table, int*
 int mp_mc_emit(const float* val, int n, float level, const int* tri_table, const long long* offsets, float* verts,
                long long* edge_id, void* stream);
 
+/* ---- per-person mesh z-buffer (code/lib/model/render.py:64-66, 134-157 render_multiple_depth_map over pytorch3d's
+ * MeshRasterizer with blur_radius 0; callers multiply_model.py:396, :634, :875).  verts [n_verts][3] world space, faces
+ * [n_faces][3] ints; cam_host = 16 floats IN HOST MEMORY: R row-major (OpenCV world -> camera), T, fx, fy, cx, cy; a pixel
+ * (row, col) is sampled at (col + 0.5, row + 0.5); faces with a vertex nearer than z_clip are dropped.  keys [H*W] and big
+ * [n_faces + 1] are scratch.  zbuf [H][W] = camera-space depth of the nearest covering face (-1: none), pix_to_face [H][W]
+ * (optional, -1: none), bary [H][W][3] (optional) perspective-correct barycentrics of the winner.  pytorch3d is third
+ * party and unpinned: restated, see csrc/raster.hip. */
+int mp_raster_zbuf(const float* verts, int n_verts, const int* faces, int n_faces, const float* cam_host, float z_clip,
+                   int H, int W, unsigned long long* keys, int* big, float* zbuf, int* pix_to_face, float* bary,
+                   void* stream);
+
 /* library / device info: returns the gfx arch string compiled in, and checks the current device */
 const char* mp_arch(void);
 int mp_device_ok(void);

@@ -1,0 +1,188 @@
+"""Mesh rasteriser wrapper with the reference's `Renderer` surface (code/lib/model/render.py:26-157) over the HIP z-buffer
+(csrc/raster.hip, mp_raster_zbuf).
+
+What the callers of the hot path use (multiply_model.py:553-576 get_renderer, :396 / :634 / :875
+render_multiple_depth_map) is built in full: the constructor from an intrinsic matrix and an image size, `set_camera(R, T)`
+with an OpenCV world->camera pose, and per-mesh depth maps shaped like pytorch3d's `fragments.zbuf` -- (1, H, W, K) with
+the nearest face in slot 0 and -1 where nothing is hit -- that back-propagate into the vertices.  The reference asks
+pytorch3d for the K = 10 nearest faces and reads slot 0 only (multiply_model.py:641, :882); this class returns K = 1.
+
+`render_multiple_meshes` (hard vertex-colour image) is the nearest-face limit of pytorch3d's SoftPhongShader blend: exact
+where a pixel's second face is further than ~0.07 depth units behind the first (its blend weight is
+exp(-dz / (99 * 1e-4))), an approximation at thinner parts.  `softrender_multiple_meshes` (sigma = 5e-5, 100 faces per
+pixel) feeds only the silhouette term whose weight is 0 in every shipped config (confs/model/*.yaml silhouette_weight):
+not built, raises.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import hip
+
+Z_CLIP = 1e-6
+
+
+class Fragments:
+    """the three pytorch3d `Fragments` fields the callers read"""
+
+    def __init__(self, zbuf, pix_to_face, bary_coords):
+        self.zbuf, self.pix_to_face, self.bary_coords = zbuf, pix_to_face, bary_coords
+
+
+def decompose_projection(P):
+    """cv2.decomposeProjectionMatrix as get_renderer uses it (multiply_model.py:565-570): P (3, 4) -> K (upper triangular,
+    K[0,0], K[1,1] > 0, NOT divided by K[2,2]), R (proper rotation), camera centre c with P [c; 1] = 0."""
+    import scipy.linalg
+    P = np.asarray(P, np.float64)
+    K, R = scipy.linalg.rq(P[:, :3])
+    for i in (0, 1):
+        if K[i, i] < 0:
+            K[:, i] *= -1
+            R[i] *= -1
+    if np.linalg.det(R) < 0:
+        K[:, 2] *= -1
+        R[2] *= -1
+    c = np.linalg.svd(P)[2][-1]
+    return K, R, c[:3] / c[3]
+
+
+def get_renderer(inputs):
+    """multiply_model.py:553-576: the camera of the frame, with the SMPL scale folded into the projection (the meshes it
+    renders are divided by that scale)."""
+    img_size = inputs["img_size"]
+    P = inputs["P"][0].detach().cpu().numpy().astype(np.float64)
+    sp = inputs["smpl_params"]
+    if not bool((sp[:, 0, 0] == sp[:, min(1, sp.shape[1] - 1), 0]).all()):
+        raise AssertionError("the persons of a frame share one scale (multiply_model.py:558)")
+    scale = float(sp[0, 0, 0])
+    P_norm = np.eye(4)
+    P_norm[:, :] = P
+    P_norm = P_norm @ np.diag([scale, scale, scale, 1.0])
+    K, R, c = decompose_projection(P_norm[:3])
+    T = -R @ c
+    r = Renderer(img_size=[int(img_size[0]), int(img_size[1])], cam_intrinsic=K)
+    r.set_camera(torch.tensor(R)[None].float(), torch.tensor(T)[None].float())
+    return r
+
+
+class Renderer:
+    def __init__(self, focal_length=None, principal_point=None, img_size=None, cam_intrinsic=None, device="cuda"):
+        hip.require_device()
+        self.device = torch.device(device)
+        self.cam_intrinsic = np.asarray(cam_intrinsic, np.float64)
+        self.image_size = [int(img_size[0]), int(img_size[1])]                  # (H, W)
+        self.render_img_size = int(np.max(self.image_size))
+        k = self.cam_intrinsic.astype(np.float32)
+        self.focal_length = torch.tensor([[k[0, 0], k[1, 1]]], device=self.device)       # render.py:38-42 (no skew, raw K)
+        self.principal_point = torch.tensor([[k[0, 2], k[1, 2]]], device=self.device)
+        self.cam_R = torch.eye(3)[None]          # OpenCV convention here; render.py:44-48 holds the same pose mirrored
+        self.cam_T = torch.zeros(1, 3)
+        self._keys = self._big = None
+
+    def set_camera(self, R, T):
+        """R (1, 3, 3), T (1, 3): OpenCV world -> camera (render.py:69-78 mirrors x / y for pytorch3d, which mirrors them
+        back when it maps to the screen: the image is the plain OpenCV projection)."""
+        self.cam_R = R.detach().float().cpu().reshape(1, 3, 3).clone()
+        self.cam_T = T.detach().float().cpu().reshape(1, 3).clone()
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _cam16(self):
+        fl, pp = self.focal_length[0].cpu(), self.principal_point[0].cpu()
+        v = torch.cat([self.cam_R.reshape(9), self.cam_T.reshape(3), fl, pp]).numpy().astype(np.float32)
+        return (C.c_float * 16)(*v.tolist())
+
+    def rasterize(self, verts, faces):
+        """verts (V, 3) / (1, V, 3) world space, faces (F, 3) / (1, F, 3) -> Fragments with zbuf (1, H, W, 1) [detached],
+        pix_to_face (1, H, W, 1) int64, bary_coords (1, H, W, 1, 3)."""
+        H, W = self.image_size
+        v = verts.detach().reshape(-1, 3).float().contiguous().to(self.device)
+        f = faces.reshape(-1, 3).to(device=self.device, dtype=torch.int32).contiguous()
+        if self._keys is None or self._keys.numel() < H * W:
+            self._keys = torch.empty(H * W, dtype=torch.int64, device=self.device)
+        if self._big is None or self._big.numel() < f.shape[0] + 1:
+            self._big = torch.empty(f.shape[0] + 1, dtype=torch.int32, device=self.device)
+        zbuf = torch.empty(H, W, dtype=torch.float32, device=self.device)
+        p2f = torch.empty(H, W, dtype=torch.int32, device=self.device)
+        bary = torch.empty(H, W, 3, dtype=torch.float32, device=self.device)
+        cam = self._cam16()
+        hip.check(hip.lib().mp_raster_zbuf(hip.ptr(v), v.shape[0], hip.ptr(f), f.shape[0], C.cast(cam, C.c_void_p),
+                                           Z_CLIP, H, W, hip.ptr(self._keys), hip.ptr(self._big), hip.ptr(zbuf),
+                                           hip.ptr(p2f), hip.ptr(bary), hip.stream()), "mp_raster_zbuf")
+        return Fragments(zbuf[None, :, :, None], p2f.long()[None, :, :, None], bary[None, :, :, None, :])
+
+    def _depth_with_grad(self, verts, faces, frag):
+        """the z-buffer again for the covered pixels only, in torch, so that d depth / d vertices exists (pytorch3d's
+        rasteriser back-propagates through the barycentrics and the vertex depths); visibility is the kernel's."""
+        H, W = self.image_size
+        p2f = frag.pix_to_face[0, :, :, 0]
+        hit = (p2f >= 0).nonzero(as_tuple=False)
+        if hit.shape[0] == 0:
+            return frag.zbuf + 0.0 * verts.sum()
+        tri = verts.reshape(-1, 3)[faces.reshape(-1, 3).long()[p2f[hit[:, 0], hit[:, 1]]]]            # (N, 3, 3)
+        R, T = self.cam_R[0].to(verts.device), self.cam_T[0].to(verts.device)
+        cam = tri @ R.t() + T
+        z = cam[..., 2]
+        x = self.focal_length[0, 0] * cam[..., 0] / z + self.principal_point[0, 0]
+        y = self.focal_length[0, 1] * cam[..., 1] / z + self.principal_point[0, 1]
+        px, py = hit[:, 1].float() + 0.5, hit[:, 0].float() + 0.5
+        edge = lambda ax, ay, bx, by: (px - ax) * (by - ay) - (py - ay) * (bx - ax)
+        area = (x[:, 2] - x[:, 0]) * (y[:, 1] - y[:, 0]) - (y[:, 2] - y[:, 0]) * (x[:, 1] - x[:, 0]) + 1e-8
+        w0, w1, w2 = edge(x[:, 1], y[:, 1], x[:, 2], y[:, 2]) / area, edge(x[:, 2], y[:, 2], x[:, 0], y[:, 0]) / area, \
+            edge(x[:, 0], y[:, 0], x[:, 1], y[:, 1]) / area
+        t0, t1, t2 = w0 * z[:, 1] * z[:, 2], z[:, 0] * w1 * z[:, 2], z[:, 0] * z[:, 1] * w2
+        d = (t0 + t1 + t2).clamp(min=1e-8)
+        pz = (t0 * z[:, 0] + t1 * z[:, 1] + t2 * z[:, 2]) / d
+        flat = frag.zbuf.reshape(-1)
+        lin = hit[:, 0] * W + hit[:, 1]
+        return flat.index_add(0, lin, pz - pz.detach()).reshape(1, H, W, 1)      # forward value = the kernel's, bit for bit
+
+    def render_multiple_depth_map(self, verts_list, faces_list, verts_colors_list=None):
+        """render.py:134-157: one z-buffer per mesh, each (1, H, W, 1); depth = camera-space z of the nearest face, -1 = none"""
+        out = []
+        for v, f in zip(verts_list, faces_list):
+            frag = self.rasterize(v, f)
+            out.append(self._depth_with_grad(v, f, frag) if (torch.is_grad_enabled() and v.requires_grad) else frag.zbuf)
+        return out
+
+    def render_multiple_meshes(self, verts_list, faces_list, verts_colors_list):
+        """render.py:107-119: the meshes joined as one scene, vertex colours under white ambient light -> (1, H, W, 4) RGBA
+        over a white background (nearest-face limit of the blend, see the module docstring)."""
+        nv = np.cumsum([0] + [v.reshape(-1, 3).shape[0] for v in verts_list])
+        verts = torch.cat([v.reshape(-1, 3).float() for v in verts_list])
+        faces = torch.cat([f.reshape(-1, 3).long() + int(o) for f, o in zip(faces_list, nv[:-1])])
+        cols = torch.cat([c.reshape(-1, 3).float() for c in verts_colors_list]).to(self.device)
+        frag = self.rasterize(verts, faces)
+        p2f = frag.pix_to_face[0, :, :, 0]
+        hit = p2f >= 0
+        img = torch.ones(*self.image_size, 4, dtype=torch.float32, device=self.device)
+        img[..., 3] = 0.0
+        c3 = cols[faces.to(self.device)[p2f[hit]]]                                   # (N, 3 corners, 3)
+        img[hit] = torch.cat([(frag.bary_coords[0, :, :, 0][hit][:, :, None] * c3).sum(1), torch.ones_like(c3[:, 0, :1])], 1)
+        return img[None]
+
+    def softrender_multiple_meshes(self, verts_list, faces_list, verts_colors_list):
+        raise NotImplementedError("the sigma = 5e-5 / 100-faces-per-pixel soft blend only feeds the silhouette term, whose "
+                                  "weight is 0 in every shipped config (silhouette_weight); not built")
+
+    def render_mesh_recon(self, verts, faces, R=None, T=None, colors=None, mode="npat"):
+        """render.py:161-208: shaded / normal / albedo / textured views side by side (along H), vertex normals as the
+        area-weighted mean of the adjacent face normals (pytorch3d Meshes.verts_normals_list)."""
+        with torch.no_grad():
+            v, f = verts.reshape(-1, 3).float().to(self.device), faces.reshape(-1, 3).long().to(self.device)
+            fn = torch.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]], dim=1)
+            vn = torch.zeros_like(v).index_add_(0, f.reshape(-1), fn.repeat_interleave(3, 0))
+            vn = torch.nn.functional.normalize(vn, eps=1e-6, dim=1)
+            shades = vn[:, 2:3].clamp(min=0).expand(-1, 3)                            # front light (0, 0, 1)
+            res = []
+            if "p" in mode:
+                res.append(self.render_multiple_meshes([v], [f], [shades]))
+            if "n" in mode:
+                res.append(self.render_multiple_meshes([v], [f], [(vn * 0.5 + 0.5)[:, [2, 1, 0]]]))
+            if "a" in mode:
+                assert colors is not None
+                res.append(self.render_multiple_meshes([v], [f], [colors.reshape(-1, 3).to(self.device)]))
+            if "t" in mode:
+                assert colors is not None
+                res.append(self.render_multiple_meshes([v], [f], [colors.reshape(-1, 3).to(self.device) * shades]))
+            return torch.cat(res, dim=1)

@@ -126,6 +126,27 @@ class _SMPLModule(nn.Module):
         self.register_buffer("lbs_weights", tables.lbs_weights)
 
 
+class _PoseTfs(torch.autograd.Function):
+    """smpl_tfs (24,4,4) of the 86 parameters with the hand-written adjoint of csrc/geom.hip (mp_smpl_pose_bwd)"""
+
+    @staticmethod
+    def forward(ctx, server, p, verts, jnts):
+        prm = p.detach().contiguous()
+        tfs = torch.empty(NUM_JOINTS, 4, 4, dtype=torch.float32, device=prm.device)
+        server.pose_into(prm, verts, tfs, jnts)
+        ctx.server, ctx.prm, ctx.rest = server, prm, server.rest_joints().contiguous()
+        return tfs
+
+    @staticmethod
+    def backward(ctx, dtfs):
+        sv, t = ctx.server, ctx.server.tables
+        dprm = torch.empty(86, dtype=torch.float32, device=ctx.prm.device)
+        hip.check(hip.lib().mp_smpl_pose_bwd(hip.ptr(t.parents), hip.ptr(ctx.prm), hip.ptr(sv.tfs_c_inv), hip.ptr(ctx.rest),
+                                             hip.ptr(t.j_shapedirs), hip.ptr(dtfs.reshape(24, 16).float().contiguous()),
+                                             hip.ptr(dprm), hip.stream()), "mp_smpl_pose_bwd")
+        return None, dprm, None, None
+
+
 class SMPLServer(nn.Module):
     def __init__(self, gender="neutral", betas=None, v_template=None, smpl_tables=None, device=None):
         super().__init__()
@@ -169,13 +190,19 @@ class SMPLServer(nn.Module):
         return self._work[3 * NUM_VERTS:3 * NUM_VERTS + 3 * NUM_JOINTS].clone()
 
     def forward(self, scale, transl, thetas, betas, absolute=False):
+        """smpl.py:50-94.  `smpl_tfs` carries gradients to scale / transl / thetas / betas when any of them requires grad
+        (the mesh-space losses back-propagate into BodyModelParams through it, multiply_model.py:586-620, 969-974; betas
+        through the rest joints, as in the training step); vertices and joints are returned detached."""
         dev = self.param_canonical.device
         p = torch.cat([scale.reshape(1, 1), transl.reshape(1, 3), thetas.reshape(1, 72), betas.reshape(1, 10)], 1)
-        p = p.detach().float().reshape(86).contiguous()
+        p = p.float().reshape(86)
         verts = torch.empty(NUM_VERTS, 3, dtype=torch.float32, device=dev)
-        tfs = torch.empty(NUM_JOINTS, 4, 4, dtype=torch.float32, device=dev)
         jnts = torch.empty(NUM_JOINTS, 3, dtype=torch.float32, device=dev)
-        self.pose_into(p, verts, tfs, jnts, absolute=absolute)
+        if torch.is_grad_enabled() and p.requires_grad and not absolute:
+            tfs = _PoseTfs.apply(self, p, verts, jnts)
+        else:
+            tfs = torch.empty(NUM_JOINTS, 4, 4, dtype=torch.float32, device=dev)
+            self.pose_into(p.detach().contiguous(), verts, tfs, jnts, absolute=absolute)
         # smpl_all_jnts: the 24 kinematic joints + the face keypoint vertices (body_models.py:345; smpl.py:83-84) -- the
         # vertices are already scaled / translated exactly like the joints (smpl.py:77-84)
         all_jnts = torch.cat([jnts, verts[self.smpl.vertex_joint_selector.extra_joints_idxs]], 0)

@@ -1,0 +1,229 @@
+"""The HIP z-buffer (csrc/raster.hip through multiply_amd.render.Renderer) against the float64 restatement, the mesh-space
+losses against their restatement, gradients against finite differences, and the rasterised canonical surface against the
+volume renderer's own silhouette."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import raster_oracle as RO
+from tests.test_raster_cpu import uv_sphere
+
+pytestmark = pytest.mark.gpu
+
+
+def make_renderer(K, R, T, H, W):
+    from multiply_amd.render import Renderer
+    r = Renderer(img_size=[H, W], cam_intrinsic=K)
+    r.set_camera(torch.tensor(R)[None].float(), torch.tensor(T)[None].float())
+    return r
+
+
+def stable_pixels(v, f, R, T, K, H, W, delta=2e-3):
+    """pixels whose winning face does not change when the camera's principal point moves by +-delta pixels: away from
+    edges and depth ties, where float32 and float64 must agree on the face"""
+    base = RO.rasterize(v, f, R, T, K[0, 0], K[1, 1], K[0, 2], K[1, 2], H, W)
+    ok = np.ones((H, W), bool)
+    for dx, dy in ((delta, 0), (-delta, 0), (0, delta), (0, -delta)):
+        p = RO.rasterize(v, f, R, T, K[0, 0], K[1, 1], K[0, 2] + dx, K[1, 2] + dy, H, W)[1]
+        ok &= p == base[1]
+    return base, ok
+
+
+def test_zbuffer_matches_the_restatement_on_random_triangle_soup():
+    rs = np.random.RandomState(3)
+    H, W = 40, 56
+    K = np.array([[70.0, 0, 27.3], [0, 64.0, 19.1], [0, 0, 1.0]])
+    ang = 0.2
+    R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.0]])
+    T = np.array([0.05, -0.02, 3.0])
+    ctr = rs.uniform(-1.4, 1.4, (600, 1, 3)) * [1, 1, 0.8]
+    size = np.where(rs.uniform(size=(600, 1, 1)) < 0.05, 1.5, 0.12)                 # a few faces with big pixel boxes
+    v = (ctr + rs.normal(size=(600, 3, 3)) * size).reshape(-1, 3)
+    v[:9, 2] -= 6.0                                                                  # behind / straddling the camera
+    v[9:12] = v[9]                                                                   # degenerate
+    f = np.arange(1800).reshape(600, 3)
+    (zb, p2f, bary), ok = stable_pixels(v, f, R, T, K, H, W)
+    frag = make_renderer(K, R, T, H, W).rasterize(torch.tensor(v).float().cuda(), torch.tensor(f).cuda())
+    torch.cuda.synchronize()
+    gz, gf, gb = frag.zbuf[0, :, :, 0].cpu().numpy(), frag.pix_to_face[0, :, :, 0].cpu().numpy(), frag.bary_coords[0, :, :, 0].cpu().numpy()
+    assert ok.mean() > 0.97 and (p2f >= 0).mean() > 0.5
+    assert (gf[ok] == p2f[ok]).all()
+    hit = ok & (p2f >= 0)
+    ez = np.abs(gz[hit] - zb[hit]).max()
+    eb = np.abs(gb[hit] - bary[hit]).max()
+    print(f"[parity] z-buffer vs float64 restatement: {hit.sum()} stable covered pixels, max |dz| {ez:.2e}, max |dbary| {eb:.2e}; "
+          f"{(~ok).sum()} edge pixels, face differs on {(gf[~ok] != p2f[~ok]).sum()}")
+    assert ez < 2e-5 and eb < 2e-4                                                   # float32 projection of coordinates ~50 px
+    assert (gz[gf < 0] == -1).all() and (gb[gf < 0] == -1).all()
+    # on the unstable (edge / tie) pixels the depth still is that of SOME face through the pixel, close to the restatement's
+    # unless the pixel sits on a silhouette edge
+    assert (gf[~ok] != p2f[~ok]).mean() < 0.5
+
+
+def test_zbuffer_of_a_sphere_at_image_scale_and_its_speed():
+    H, W = 940, 1280                                                                 # Hi4D frame size
+    # off-axis on purpose: with the sphere on the optical axis the 45-degree meridians pass exactly through pixel centres,
+    # which the strict w > 0 rule assigns to neither neighbour
+    K = np.array([[1400.0, 0, 640.3], [0, 1400.0, 469.8], [0, 0, 1.0]])
+    R, T = np.diag([1.0, -1.0, -1.0]), np.array([0.0, 0.0, 3.0])
+    ctr = np.array([0.0137, -0.0071, 0.0])
+    v, f = uv_sphere(ctr, 0.5, 256, 512)                                             # 260 k faces, ~1.5 px each
+    r = make_renderer(K, R, T, H, W)
+    vt, ft = torch.tensor(v).float().cuda(), torch.tensor(f).cuda()
+    frag = r.rasterize(vt, ft)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        frag = r.rasterize(vt, ft)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 100
+    z = frag.zbuf[0, :, :, 0].cpu().numpy()
+    py, px = np.meshgrid(np.arange(H) + 0.5, np.arange(W) + 0.5, indexing="ij")
+    d = np.stack([(px - 640.3) / 1400, (py - 469.8) / 1400, np.ones_like(px)], -1)
+    cc = R @ ctr + T
+    bq, aq = d @ cc, (d * d).sum(-1)
+    disc = bq * bq - aq * (cc @ cc - 0.25)
+    t = (bq - np.sqrt(np.maximum(disc, 0))) / aq
+    inner = disc > 0.01 * aq * 0.25
+    assert (z[inner] > 0).all() and (z[disc < 0] == -1).all()
+    err = np.abs(z[inner] - t[inner]).max()
+    print(f"[perf] z-buffer 940x1280, {f.shape[0]} faces: {ms:.3f} ms per mesh (host-timed, 10 launches); "
+          f"max |depth - analytic| {err:.2e} on {inner.sum()} pixels")
+    assert err < 2e-4                                                                # sagitta r (1 - cos(pi/512)) = 1e-5, slanted
+    # holes: inside the silhouette every pixel is covered (strict w > 0 only loses pixels exactly on an edge)
+    assert (z[disc > 0.001 * aq * 0.25] > 0).mean() > 0.99999
+
+
+def test_depth_maps_back_propagate_into_the_vertices():
+    H, W = 24, 32
+    K = np.array([[40.0, 0, 15.7], [0, 40.0, 12.2], [0, 0, 1.0]])
+    R, T = np.eye(3), np.array([0.0, 0.0, 2.5])
+    v, f = uv_sphere([0.05, 0.0, 0.0], 0.6, 6, 8)
+    r = make_renderer(K, R, T, H, W)
+    vt = torch.tensor(v).float().cuda().requires_grad_(True)
+    ft = torch.tensor(f).cuda()
+    wgt = torch.rand(H, W, generator=torch.Generator().manual_seed(0)).cuda()
+    d = r.render_multiple_depth_map([vt[None]], [ft[None]])[0]
+    assert d.shape == (1, H, W, 1) and d.requires_grad
+    plain = r.rasterize(vt, ft).zbuf
+    assert torch.equal(d.detach(), plain)                                            # forward value = the kernel's
+    hit = (d[0, :, :, 0] > 0)
+    (d[0, :, :, 0] * wgt * hit).sum().backward()
+    g = vt.grad.cpu().double().numpy()
+    # finite differences of the float64 restatement with visibility frozen to the same faces (pytorch3d's gradient also
+    # treats pix_to_face as a constant)
+    zb0, p2f0, _ = RO.rasterize(v, f, R, T, 40.0, 40.0, 15.7, 12.2, H, W)
+    assert (p2f0 == r.rasterize(vt, ft).pix_to_face[0, :, :, 0].cpu().numpy()).mean() > 0.99
+    w = wgt.cpu().double().numpy()
+
+    def loss(vv):
+        s = RO.project(vv, R, T, 40.0, 40.0, 15.7, 12.2)
+        py, px = np.meshgrid(np.arange(H) + 0.5, np.arange(W) + 0.5, indexing="ij")
+        tot = 0.0
+        for (i, j) in zip(*np.nonzero(p2f0 >= 0)):
+            a, b, c = s[f[p2f0[i, j]]]
+            e = lambda p, q: (px[i, j] - p[0]) * (q[1] - p[1]) - (py[i, j] - p[1]) * (q[0] - p[0])
+            w0, w1, w2 = e(b, c), e(c, a), e(a, b)
+            tot += w[i, j] / (w0 / a[2] + w1 / b[2] + w2 / c[2]) * (w0 + w1 + w2)
+        return tot
+    num = np.zeros_like(v)
+    for i in range(0, v.shape[0], 3):
+        for k in range(3):
+            dv = np.zeros_like(v); dv[i, k] = 1e-6
+            num[i, k] = (loss(v + dv) - loss(v - dv)) / 2e-6
+    sel = np.arange(0, v.shape[0], 3)
+    err = np.abs(g[sel] - num[sel]).max() / np.abs(num[sel]).max()
+    print(f"[parity] d depth / d vertices vs finite differences: rel err {err:.2e}")
+    assert err < 2e-3
+
+
+def test_mesh_space_losses_on_the_model_match_the_restatement():
+    """get_depth_order_loss / frame_instance_masks end to end on the synthetic two-person scene: canonical meshes -> posed ->
+    z-buffers -> losses; the loss arithmetic against oracle/raster_oracle.py on the same depth maps, the pose gradient
+    against a finite difference of the whole chain."""
+    from multiply_amd import mesh_losses as ML
+    from multiply_amd.mesh import canonical_mesh
+    from tests.test_render_gpu import build
+    H, W = 60, 80
+    model, _, inp = build(H=H, W=W)
+    gin = {k: (t.cuda() if torch.is_tensor(t) else t) for k, t in inp.items()}
+    Kp = gin["intrinsics"][0].double().clone()
+    Kp[0, 2] += 0.5; Kp[1, 2] += 0.5                      # the volume renderer shoots rays through integer (x, y)
+    gin["P"] = (Kp @ torch.linalg.inv(gin["pose"][0].double()))[None].float()
+    gin["img_size"] = (H, W)
+    rs = np.random.RandomState(0)
+    sam = torch.tensor(rs.normal(0, 4.0, (1, H, W, 2))).float().cuda()
+    gin["org_sam_mask"] = sam
+    meshes = [canonical_mesh(model, p, cond=gin["smpl_pose"][0, p, 3:] / np.pi, res_up=1) for p in range(2)]
+    masks, depth, kps = ML.frame_instance_masks(model, gin, use_smpl_mesh=True)
+    assert masks.shape == (2, H, W) and kps.shape == (2, 27, 2) and kps.dtype == torch.int32
+    assert not bool((masks[0] & masks[1]).any()) and bool(masks[0].any()) and bool(masks[1].any())
+    # SMPL z-buffers against the restatement (6890-vertex body, float64)
+    r = ML.get_renderer(gin)
+    cam = (r.cam_R[0].numpy().astype(np.float64), r.cam_T[0].numpy().astype(np.float64))
+    fx, fy = r.focal_length[0].tolist(); cx, cy = r.principal_point[0].tolist()
+    vs, fs, outs = ML.posed_meshes(model, gin, use_smpl_mesh=True)
+    want = [RO.rasterize(v[0].cpu().numpy(), f[0].cpu().numpy(), *cam, fx, fy, cx, cy, H, W) for v, f in zip(vs, fs)]
+    for p in range(2):
+        same = (want[p][1] >= 0) == (depth[p].cpu().numpy() > 0)
+        dz = np.abs(depth[p].cpu().numpy() - want[p][0])[same & (want[p][1] >= 0)]
+        print(f"[parity] SMPL z-buffer person {p}: coverage differs on {(~same).sum()} of {H * W} pixels, "
+              f"median |dz| {np.median(dz):.1e}, 99.5 % {np.quantile(dz, 0.995):.1e}")
+        assert (~same).sum() <= 3 and np.quantile(dz, 0.995) < 1e-5
+    _, _, wm = RO.front_depth_and_masks([d.cpu().numpy() for d in depth])
+    assert (wm == masks.cpu().numpy()).all()
+    # key points: the projected joints (truncated to ints as astype(np.int32) does)
+    j = outs[0]["smpl_all_jnts"][0, :27].double().cpu().numpy()
+    t = np.concatenate([j, np.ones((27, 1))], 1) @ gin["P"][0].double().cpu().numpy().T
+    assert (kps[0].cpu().numpy() == (t[:, :2] / t[:, 2:3]).astype(np.int32)).all()
+
+    # depth-order loss on the posed canonical meshes, with gradients into the pose
+    pose = gin["smpl_pose"].clone().requires_grad_(True)
+    trans = gin["smpl_trans"].clone().requires_grad_(True)
+    tin = dict(gin, smpl_pose=pose, smpl_trans=trans)
+    draws = [torch.arange(0, m["vertices"].shape[0], 7)[:5120] for m in meshes]
+    opt = {"depth_order_weight": 0.1, "interpenetration_loss_weight": 0.005}
+    order, sil, inter = ML.get_depth_order_loss(model, tin, 100, opt, meshes=meshes, draws=draws)
+    (order + inter.sum()).backward()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        vs, fs, _ = ML.posed_meshes(model, gin, meshes=meshes)
+        dm = [d[0, :, :, 0].cpu().numpy() for d in r.render_multiple_depth_map(vs, fs)]
+    want_order = RO.depth_order_loss(dm, sam[0].cpu().numpy(), 100, 0.1)
+    print(f"[parity] depth-order loss {float(order):.6f} vs restatement {want_order:.6f}; interpenetration {float(inter):.3e}; "
+          f"|d/d pose| {float(pose.grad.abs().max()):.2e}, |d/d trans| {float(trans.grad.abs().max()):.2e}")
+    assert abs(float(order) - want_order) < 1e-5 * max(1.0, want_order) and want_order > 0
+    assert float(sil) == 0.0 and torch.isfinite(pose.grad).all() and float(trans.grad.abs().max()) > 0
+    # finite difference along the camera axis: moving person 0 in z changes its depths one for one where it is the labelled
+    # but hidden surface (d loss / d z = sigmoid(gt - front)) and oppositely where it is the wrongly-front one
+    eps = 1e-3
+
+    def loss_at(dz):
+        with torch.no_grad():
+            t2 = gin["smpl_trans"].clone(); t2[0, 0, 2] += dz
+            o, _, _ = ML.get_depth_order_loss(model, dict(gin, smpl_trans=t2), 100, {"depth_order_weight": 0.1}, meshes=meshes)
+            return float(o)
+    t3 = gin["smpl_trans"].clone().requires_grad_(True)
+    o3, _, _ = ML.get_depth_order_loss(model, dict(gin, smpl_trans=t3), 100, {"depth_order_weight": 0.1}, meshes=meshes)
+    o3.backward()
+    fd = (loss_at(eps) - loss_at(-eps)) / (2 * eps)
+    print(f"[parity] d depth-order / d trans_z(person 0): autograd {float(t3.grad[0, 0, 2]):.5f}, finite difference {fd:.5f}")
+    assert abs(float(t3.grad[0, 0, 2]) - fd) < 0.05 * abs(fd) + 1e-3        # visibility changes at silhouettes are not differentiated
+
+    # the rasterised canonical surfaces against the volume renderer's silhouette of the same frame
+    # (with a sharp density: at the initial beta = 0.1 a ray that passes 0.2 outside the surface still accumulates acc = 0.5)
+    with torch.no_grad():
+        model.density.beta.fill_(0.01)
+    out = model(gin)
+    acc = out["acc_map"].reshape(H, W) > 0.5
+    m2, _, _ = ML.frame_instance_masks(model, gin, use_smpl_mesh=False, res_up=1)
+    cover = m2.any(0)
+    iou = float((acc & cover).sum()) / float((acc | cover).sum())
+    inside = float((acc & cover).sum()) / float(acc.sum())
+    print(f"[parity] volume-rendered acc_map > 0.5 vs mesh z-buffer silhouette: {inside:.3f} of it inside, IoU {iou:.3f} "
+          f"({int(cover.sum())} mesh vs {int(acc.sum())} volume pixels)")
+    # the random-initialised surface is a ~0.6 sphere: the mesh keeps all of it inside the canonical box, the volume renderer
+    # only the part within 0.1 of the posed body (deformer outliers are empty space) -> containment, not equality
+    assert inside > 0.95 and iou > 0.6
