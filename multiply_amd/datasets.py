@@ -63,6 +63,8 @@ class SceneStore:
         img_paths = sorted(glob.glob(os.path.join(root, "image", "*.png")))
         self.img_paths = [img_paths[i] for i in frame_ids]
         folders = sorted(glob.glob(os.path.join(root, "mask", "*")))
+        if folders and all(f.endswith(".png") for f in folders):      # threedpw.py:83-84: one person, mask/*.png
+            folders = [os.path.join(root, "mask")]
         self.mask_paths = [[sorted(glob.glob(os.path.join(f, "*.png")))[i] for i in frame_ids] for f in folders]
         first = read_png_rgb(self.img_paths[0])
         self.img_size = first.shape[:2]
@@ -153,7 +155,7 @@ class Hi4DDataset(torch.utils.data.Dataset):
             self.pose_all.append(torch.from_numpy(pose).float())
         self.num_sample = opt.num_sample
         self.sampling_strategy = "weighted"
-        self.using_SAM = opt.using_SAM
+        self.using_SAM = opt.get("using_SAM", False)       # threedpw.py has no such option
         self.pre_mask_path, self.pre_mask = "", None
         self.smpl_sam_iou = np.ones(self.n_images)
         self.uncertain_thereshold = 0.0
@@ -269,14 +271,122 @@ class Hi4DValDataset(torch.utils.data.Dataset):
         return inputs, images
 
 
+def novel_view_camera(scale_mat, world_mat, gt_cur, gt_tgt):
+    """One frame of the novel-view cameras (Hi4D.py:398-425).  The sequence was trained under the studio camera
+    `current_view`, whose ground-truth calibration is gt_cur = (intrinsics (3,3), extrinsics (3,4)); gt_tgt is the studio
+    camera to render from.  The rigid motion that carries the studio frame onto the training frame is read off the two
+    descriptions of the current camera and applied to the target camera; the target intrinsics are brought to the training
+    image scale (ratio of the two focal lengths of the current camera).  -> P (4,4), C (3,), intrinsics (4,4), pose (4,4)."""
+    _, pose_tr = load_K_Rt_from_P(np.asarray(world_mat)[:3, :4])
+    K_tr, _ = load_K_Rt_from_P(np.asarray(world_mat)[:3, :4])
+    (K_cur, E_cur), (K_tgt, E_tgt) = gt_cur, gt_tgt
+    zoom = K_cur[0, 0] / K_tr[0, 0]
+    R_tr = pose_tr[:3, :3].T                                  # world -> camera of the training description
+    t_tr = -R_tr @ pose_tr[:3, 3]
+    R_rel = R_tr.T @ E_cur[:3, :3]                            # studio frame -> training frame
+    t_rel = R_tr.T @ (E_cur[:3, 3] - t_tr)
+    R_new = E_tgt[:3, :3] @ R_rel.T
+    t_new = E_tgt[:3, 3] - R_new @ t_rel
+    K_new = np.array(K_tgt[:3, :3], dtype=np.float64, copy=True)
+    K_new[[0, 1, 0, 1], [0, 1, 2, 2]] /= zoom                 # fx, fy, cx, cy (the skew entry is left as it is)
+    world_new = np.eye(4)
+    world_new[:3, :4] = K_new @ np.concatenate([R_new, t_new[:, None]], axis=1)
+    P = world_new @ scale_mat
+    K, pose = load_K_Rt_from_P(P[:3, :4])
+    return P, -np.linalg.solve(P[:3, :3], P[:3, 3]), K, pose
+
+
 class Hi4DTestDataset(torch.utils.data.Dataset):
-    """every frame under its training camera (Hi4D.py:365-484; the novel-view branch needs the Hi4D ground-truth camera
-    files and is not part of this producer)"""
+    """every frame under its training camera, or -- with opt.novel_view / current_view / pair / action / GT_DIR -- under
+    another studio camera of the Hi4D ground truth <GT_DIR>/<pair>/<action>/cameras/rgb_cameras.npz (ids, intrinsics,
+    extrinsics)  (Hi4D.py:365-484)"""
 
     def __init__(self, opt, device=None, rng=None):
-        if opt.get("novel_view", None) is not None and opt.get("current_view", None) is not None:
-            raise NotImplementedError("novel-view testing reads the Hi4D ground-truth cameras (Hi4D.py:373-427)")
         self.dataset = Hi4DDataset(opt, device, rng)
+        self.img_size = self.dataset.img_size
+        self.total_pixels = np.prod(self.img_size)
+        self.pixel_per_batch = opt.pixel_per_batch
+        self.novel_view, self.current_view = opt.get("novel_view", None), opt.get("current_view", None)
+        if self.novel_view is not None and self.current_view is not None:
+            cams = dict(np.load(os.path.join(opt.GT_DIR, opt.pair, opt.action, "cameras", "rgb_cameras.npz")))
+            pick = lambda view: int(np.where(cams["ids"] == view)[0][0])
+            cur, tgt = pick(self.current_view), pick(self.novel_view)
+            gt_cur = (cams["intrinsics"][cur], cams["extrinsics"][cur])
+            gt_tgt = (cams["intrinsics"][tgt], cams["extrinsics"][tgt])
+            self.new_P, self.new_C, self.new_intrinsics_all, self.new_pose_all = [], [], [], []
+            for scale_mat, world_mat in zip(self.dataset.scale_mat_all, self.dataset.world_mat_all):
+                P, C, K, pose = novel_view_camera(scale_mat, world_mat, gt_cur, gt_tgt)
+                self.new_P.append(P)
+                self.new_C.append(C)
+                self.new_intrinsics_all.append(torch.from_numpy(K).float())
+                self.new_pose_all.append(torch.from_numpy(pose).float())
+        else:
+            self.novel_view = self.current_view = None
+
+    def __len__(self):
+        return len(self.dataset)
+
+    def __getitem__(self, idx):
+        inputs, images = self.dataset[idx]
+        if self.novel_view is not None:                       # Hi4D.py:433-450
+            new = {"uv": inputs["uv"], "P": self.new_P[idx], "C": self.new_C[idx], "intrinsics": self.new_intrinsics_all[idx],
+                   "pose": self.new_pose_all[idx], "smpl_params": inputs["smpl_params"], "idx": inputs["idx"],
+                   "novel_view": self.novel_view}
+            return new, {"rgb": images["rgb"], "img_size": images["img_size"]}, self.pixel_per_batch, self.total_pixels, idx
+        new = {k: inputs[k] for k in ("uv", "P", "C", "intrinsics", "pose", "smpl_params", "idx")}
+        new["img_size"] = torch.from_numpy(np.array(inputs["img_size"]))
+        images = {"rgb": images["rgb"], "img_size": images["img_size"], "org_uv": inputs["org_uv"],
+                  "org_img": inputs["org_img"], "org_object_mask": inputs["org_object_mask"]}
+        if "org_sam_mask" in inputs:
+            new["org_sam_mask"] = inputs["org_sam_mask"]
+            images["org_sam_mask"] = inputs["org_sam_mask"]
+        return new, images, self.pixel_per_batch, self.total_pixels, idx
+
+
+class ThreeDPWDataset(Hi4DDataset):
+    """The single-person sequence layout (code/lib/datasets/threedpw.py:60-178): mask/*.png without person folders,
+    poses.npy (F,72), normalize_trans.npy (F,3), mean_shape.npy (10,); items carry a flat smpl_params (86,) and none of
+    the SAM / uncertainty keys."""
+
+    def __init__(self, opt, device=None, rng=None):
+        super().__init__(opt, device, rng)
+        self.num_person, self.using_SAM = 1, False
+
+    def smpl_params(self, idx):
+        p = torch.zeros([86]).float()
+        p[0] = torch.from_numpy(np.asarray(self.scale)).float()
+        p[1:4] = torch.from_numpy(self.trans[idx]).float()
+        p[4:76] = torch.from_numpy(self.poses[idx]).float()
+        p[76:] = torch.from_numpy(self.shape).float()
+        return p
+
+    def __getitem__(self, idx):
+        st, (H, W) = self.store, self.img_size
+        base = {"P": self.P[idx], "C": self.C[idx], "intrinsics": self.intrinsics_all[idx], "pose": self.pose_all[idx],
+                "smpl_params": self.smpl_params(idx)}
+        if self.num_sample > 0:
+            pos, index_outside = draw_positions(st.bbox[idx, 0], st.bbox[idx, 1], (H, W), self.num_sample, self.rng)
+            rgb, uv, _, _ = st.sample(idx, pos)
+            return {"uv": uv, **base, "index_outside": index_outside, "idx": idx}, {"rgb": rgb}
+        return ({"uv": self.full_uv().reshape(-1, 2), **base, "idx": idx},
+                {"rgb": (st.images[idx].float() / 255).reshape(-1, 3), "img_size": self.img_size})
+
+
+class ThreeDPWValDataset(Hi4DValDataset):
+    """threedpw.py:180-211"""
+
+    def __init__(self, opt, device=None, rng=None):
+        self.dataset = ThreeDPWDataset(opt, device, rng)
+        self.img_size = self.dataset.img_size
+        self.total_pixels = np.prod(self.img_size)
+        self.pixel_per_batch = opt.pixel_per_batch
+
+
+class ThreeDPWTestDataset(torch.utils.data.Dataset):
+    """threedpw.py:213-243"""
+
+    def __init__(self, opt, device=None, rng=None):
+        self.dataset = ThreeDPWDataset(opt, device, rng)
         self.img_size = self.dataset.img_size
         self.total_pixels = np.prod(self.img_size)
         self.pixel_per_batch = opt.pixel_per_batch
@@ -286,11 +396,22 @@ class Hi4DTestDataset(torch.utils.data.Dataset):
 
     def __getitem__(self, idx):
         inputs, images = self.dataset[idx]
-        new = {k: inputs[k] for k in ("uv", "P", "C", "intrinsics", "pose", "smpl_params", "idx")}
-        new["img_size"] = torch.from_numpy(np.array(inputs["img_size"]))
-        images = {"rgb": images["rgb"], "img_size": images["img_size"], "org_uv": inputs["org_uv"],
-                  "org_img": inputs["org_img"], "org_object_mask": inputs["org_object_mask"]}
-        if "org_sam_mask" in inputs:
-            new["org_sam_mask"] = inputs["org_sam_mask"]
-            images["org_sam_mask"] = inputs["org_sam_mask"]
-        return new, images, self.pixel_per_batch, self.total_pixels, idx
+        inputs = {k: inputs[k] for k in ("uv", "P", "C", "intrinsics", "pose", "smpl_params", "idx")}
+        return inputs, {"rgb": images["rgb"], "img_size": images["img_size"]}, self.pixel_per_batch, self.total_pixels, idx
+
+
+def find_dataset_using_name(name):
+    """code/lib/datasets/__init__.py:5-17"""
+    mapping = {"ThreeDPW": ThreeDPWDataset, "ThreeDPWVal": ThreeDPWValDataset, "ThreeDPWTest": ThreeDPWTestDataset,
+               "Hi4D": Hi4DDataset, "Hi4DVal": Hi4DValDataset, "Hi4DTest": Hi4DTestDataset}
+    if name not in mapping:
+        raise ValueError(f"Fail to find dataset {name}")
+    return mapping[name]
+
+
+def create_dataset(opt, device=None):
+    """code/lib/datasets/__init__.py:20-44: a DataLoader over the named dataset; always num_workers = 0 -- the frames are
+    resident in device memory and an item is one kernel launch, there is nothing for worker processes to do."""
+    dataset = find_dataset_using_name(opt.dataset)(opt, device)
+    return torch.utils.data.DataLoader(dataset, batch_size=opt.batch_size, drop_last=opt.drop_last, shuffle=opt.shuffle,
+                                       num_workers=0)

@@ -148,3 +148,29 @@ class Hi4DDatasetOracle:
                   "intrinsics": self.intrinsics_all[i], "pose": self.pose_all[i], "smpl_params": smpl_params, "idx": i,
                   "org_object_mask": mask, "img_size": (H, W)}
         return inputs, {"rgb": img.reshape(-1, 3).astype(np.float32), "img_size": (H, W)}
+
+
+def novel_view_camera(scale_mat, world_mat, gt_intr_cur, gt_extr_cur, gt_intr_tgt, gt_extr_tgt):
+    """Hi4DTestDataset.__init__'s per-frame body (Hi4D.py:398-425), step for step: the training description of the current
+    studio camera (R3, t3) and its ground-truth description (R1, t1) give the studio -> training rigid motion (Rab, tab);
+    the target studio camera (R2, t2) seen from the training frame is (R4, t4); its intrinsics are divided by the focal
+    ratio of the two descriptions of the current camera.  -> P (4,4), C (3,), intrinsics (4,4), pose (4,4)."""
+    intr_tr, pose_tr = load_K_Rt_from_P(np.asarray(world_mat)[:3, :4])
+    scale_factor = gt_intr_cur[0, 0] / intr_tr[0, 0]
+    R3 = pose_tr[:3, :3].transpose()
+    t3 = -R3 @ pose_tr[:3, 3]
+    R1, t1 = gt_extr_cur[:3, :3], gt_extr_cur[:3, 3]
+    Rab = R3.transpose() @ R1
+    tab = R3.transpose() @ (t1 - t3)
+    R2, t2 = gt_extr_tgt[:3, :3], gt_extr_tgt[:3, 3]
+    R4 = R2 @ Rab.transpose()
+    t4 = t2 - R4 @ tab
+    Kt = gt_intr_tgt[:3, :3].copy()
+    for (i, j) in ((0, 0), (1, 1), (0, 2), (1, 2)):
+        Kt[i, j] = Kt[i, j] / scale_factor
+    novel = np.eye(4)
+    novel[:3, :4] = Kt @ np.concatenate((R4, t4.reshape(3, 1)), axis=1)
+    P = novel @ scale_mat
+    C = -np.linalg.solve(P[:3, :3], P[:3, 3])
+    intr, pose = load_K_Rt_from_P(P[:3, :4])
+    return P, C, intr, pose

@@ -83,3 +83,42 @@ def test_oracle_dataset_on_a_written_sequence(tmp_path):
     assert np.abs(inputs["intrinsics"] - w["intrinsics"]).max() < 1e-4 and np.abs(inputs["pose"] - w["pose"]).max() < 1e-6
     full = Hi4DDatasetOracle(str(tmp_path), 0, 3, 0)[2]
     assert full[0]["uv"].shape == (40 * 48, 2) and np.array_equal(full[0]["uv"][49], [1, 1])
+
+
+def test_novel_view_cameras_match_the_restatement_and_a_directly_built_camera():
+    """Hi4D.py:398-425.  Studio frame = a rigid motion of the training frame; the novel camera must image a point exactly
+    like the target studio camera images the same physical point, at the training image scale."""
+    from multiply_amd.datasets import novel_view_camera
+    from oracle.dataset_oracle import novel_view_camera as want_fn
+    rs = np.random.RandomState(5)
+
+    def rot():
+        q, _ = np.linalg.qr(rs.normal(size=(3, 3)))
+        return q * np.sign(np.linalg.det(q))
+    K_tr = np.array([[800.0, 0, 310.0], [0, 800.0, 250.0], [0, 0, 1.0]])
+    R_tr, t_tr = rot(), rs.normal(size=3) + [0, 0, 4.0]
+    world = np.eye(4); world[:3, :4] = K_tr @ np.concatenate([R_tr, t_tr[:, None]], 1)
+    scale_mat = np.diag([1.3, 1.3, 1.3, 1.0]); scale_mat[:3, 3] = [0.1, -0.2, 0.05]
+    # studio coordinates x_s = A x_w + b ; studio cameras are 2x larger images (zoom = 2)
+    A, b = rot(), rs.normal(size=3)
+    K_cur = np.diag([2.0, 2.0, 1.0]) @ K_tr
+    E_cur = np.concatenate([R_tr @ A.T, (t_tr - R_tr @ A.T @ b)[:, None]], 1)            # same physical camera
+    K_tgt = np.array([[1700.0, 0, 600.0], [0, 1650.0, 520.0], [0, 0, 1.0]])
+    R_t, t_t = rot(), rs.normal(size=3) + [0, 0, 5.0]
+    E_tgt = np.concatenate([R_t, t_t[:, None]], 1)
+    got = novel_view_camera(scale_mat, world, (K_cur, E_cur), (K_tgt, E_tgt))
+    want = want_fn(scale_mat, world, K_cur, E_cur, K_tgt, E_tgt)
+    for g, w, name in zip(got, want, ("P", "C", "intrinsics", "pose")):
+        assert np.allclose(g, w, rtol=1e-9, atol=1e-9), name
+    # a point in normalised coordinates x_n -> training world x_w = scale_mat x_n -> studio -> target pixel / zoom
+    xn = rs.normal(size=(5, 3)) * 0.3
+    xw = xn @ scale_mat[:3, :3].T + scale_mat[:3, 3]
+    xs = xw @ A.T + b
+    pix = (xs @ R_t.T + t_t) @ K_tgt.T
+    pix = pix[:, :2] / pix[:, 2:3] / 2.0
+    mine = np.concatenate([xn, np.ones((5, 1))], 1) @ got[0][:3].T
+    assert np.allclose(mine[:, :2] / mine[:, 2:3], pix, atol=1e-8)
+    # novel view == current view: the training camera itself
+    same = novel_view_camera(scale_mat, world, (K_cur, E_cur), (K_cur, E_cur))
+    P0 = world @ scale_mat
+    assert np.allclose(same[0][:3] / same[0][2, 3], P0[:3] / P0[2, 3], atol=1e-8)

@@ -144,3 +144,63 @@ def test_sequence_on_disk_to_training_step(tmp_path):
     g = model.foreground_implicit_network_list[0].lin0.weight_v.grad
     assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
     assert out["index_outside"] is not None
+
+
+def test_novel_view_test_items_and_the_single_person_layout(tmp_path):
+    """Hi4DTestDataset's novel-view branch (Hi4D.py:373-450) on a written sequence + a written studio-camera file, and the
+    ThreeDPW* variants (threedpw.py:60-243) on the same frames stored in the single-person layout; create_dataset's factory."""
+    import shutil
+    from multiply_amd.datasets import (Hi4DDataset, Hi4DTestDataset, ThreeDPWDataset, ThreeDPWTestDataset, ThreeDPWValDataset,
+                                       create_dataset, find_dataset_using_name)
+    from multiply_amd.synthetic import write_sequence
+    from oracle.dataset_oracle import Hi4DDatasetOracle, novel_view_camera
+    root = str(tmp_path / "seq")
+    write_sequence(root, n_frames=3, H=48, W=64, num_person=1)
+    gt = tmp_path / "gt" / "pair00" / "dance" / "cameras"
+    gt.mkdir(parents=True)
+    rs = np.random.RandomState(1)
+    K = np.stack([np.array([[190.0 + 10 * i, 0, 60.0], [0, 190.0, 50.0 + i], [0, 0, 1.0]]) for i in range(3)])
+    E = []
+    for i in range(3):
+        q, _ = np.linalg.qr(rs.normal(size=(3, 3)))
+        E.append(np.concatenate([q * np.sign(np.linalg.det(q)), rs.normal(size=(3, 1)) + [[0], [0], [3.0]]], 1))
+    np.savez(str(gt / "rgb_cameras.npz"), ids=np.array([4, 16, 28]), intrinsics=K, extrinsics=np.stack(E))
+    test = Hi4DTestDataset(_opt(root, num_sample=0, novel_view=28, current_view=4, pair="pair00", action="dance",
+                                GT_DIR=str(tmp_path / "gt")))
+    tin, tim, ppb, total, i = test[1]
+    cams = np.load(os.path.join(root, "cameras_normalize.npz"))
+    P, C, intr, pose = novel_view_camera(cams["scale_mat_1"].astype(np.float32), cams["world_mat_1"].astype(np.float32),
+                                         K[0], E[0], K[2], E[2])
+    assert np.allclose(tin["P"], P) and np.allclose(tin["C"], C) and tin["novel_view"] == 28 and set(tim) == {"rgb", "img_size"}
+    assert np.abs(tin["intrinsics"].numpy() - intr).max() < 1e-4 and np.abs(tin["pose"].numpy() - pose).max() < 1e-6
+    assert (ppb, total, i) == (512, 48 * 64, 1) and tin["uv"].shape == (48 * 64, 2)
+    plain = Hi4DTestDataset(_opt(root, num_sample=0))
+    assert plain.novel_view is None and "org_img" in plain[1][1]
+    # single-person layout: mask/*.png, (F,72) poses, (F,3) translations, (10,) shape
+    root1 = str(tmp_path / "seq1")
+    shutil.copytree(root, root1)
+    for f in sorted(os.listdir(os.path.join(root1, "mask", "0"))):
+        shutil.move(os.path.join(root1, "mask", "0", f), os.path.join(root1, "mask", f))
+    os.rmdir(os.path.join(root1, "mask", "0"))
+    for name in ("poses", "normalize_trans"):
+        np.save(os.path.join(root1, name + ".npy"), np.load(os.path.join(root1, name + ".npy"))[:, 0])
+    np.save(os.path.join(root1, "mean_shape.npy"), np.load(os.path.join(root1, "mean_shape.npy"))[0])
+    ds = ThreeDPWDataset(_opt(root1), rng=np.random.RandomState(4))
+    ref = Hi4DDataset(_opt(root), rng=np.random.RandomState(4))
+    (i1, t1), (i2, t2) = ds[2], ref[2]
+    torch.cuda.synchronize()
+    assert torch.equal(i1["uv"], i2["uv"]) and torch.equal(t1["rgb"], t2["rgb"])            # same draws, same frame
+    assert i1["smpl_params"].shape == (86,) and torch.equal(i1["smpl_params"], i2["smpl_params"][0])
+    assert set(i1) == {"uv", "P", "C", "intrinsics", "pose", "smpl_params", "index_outside", "idx"} and set(t1) == {"rgb"}
+    want_in, want_im = Hi4DDatasetOracle(root, 0, 3, 64).__getitem__(2, rng=np.random.RandomState(4))
+    assert np.abs(t1["rgb"].cpu().numpy() - want_im["rgb"]).max() <= 1.2e-7
+    v_in, v_im = ThreeDPWValDataset(_opt(root1, num_sample=0), rng=np.random.RandomState(0))[0]
+    assert v_in["uv"].shape == (48 * 64, 2) and v_im["total_pixels"] == 48 * 64 and "image_id" in v_in
+    t_in, t_im, ppb, total, i = ThreeDPWTestDataset(_opt(root1, num_sample=0))[0]
+    assert set(t_in) == {"uv", "P", "C", "intrinsics", "pose", "smpl_params", "idx"} and set(t_im) == {"rgb", "img_size"}
+    assert find_dataset_using_name("Hi4DVal").__name__ == "Hi4DValDataset"
+    with pytest.raises(ValueError):
+        find_dataset_using_name("nope")
+    loader = create_dataset(_opt(root1, dataset="ThreeDPW", batch_size=1, drop_last=False, shuffle=False, worker=0))
+    b_in, b_im = next(iter(loader))
+    assert b_in["uv"].shape == (1, 64, 2) and b_in["smpl_params"].shape == (1, 86) and b_im["rgb"].is_cuda
