@@ -141,14 +141,18 @@ int mp_ray_hits_from_index(const int* hit_index, int n_hit, int n_rays, int* hit
 /* ---- canonical warp ---------------------------------------------------------------------------
  * SMPLDeformer.forward(inverse=True) (deformer.py:19-50, 72-88): nearest posed vertex -> its skinning weights ->
  * x_c = (sum_j w_j T_j)^-1 x ; outlier = dist > 0.1.
+ * The blended transform only depends on the nearest vertex: mp_blend_table evaluates it once per pose for every vertex,
+ * table [n_verts][3][4] fp32, row r = (I[r][0..2], T[r][3] / T[3][3]) with T = sum_j skin_w[v][j] tfs[j], I = T[:3,:3]^-1
+ * (skin_w [n_verts][24], tfs [24][16]); the warp kernels read x_c = I (x - c) and jinv = I from it (`blend_table`).
  * Points are either explicit (pts [max_rays][3], dirs, pose, hit_index, hit_count and z unused) or implicit samples of hit rays:
  * point id = k*n_s + s, x = cam + z[k*z_stride + s] * dirs[hit_index[k]], cam = pose[:3,3].
  *   mode 0 (training): every point is written to xc and appended to worklist.
  *   mode 1 (eval): outliers get sdf_out = 4 (multiply.py:142-143) and are NOT appended.
  *   ray_active [max_rays] per-ray flag or NULL; launch_active: device int, 0 = nothing to do (kernel exits), or NULL.  Outputs: xc [n][3], worklist, *work_count (atomic, must be 0). */
+int mp_blend_table(const float* skin_w, const float* tfs, int n_verts, float* table, void* stream);
 int mp_warp_inverse(const float* pts, const float* dirs, const float* pose, const int* hit_index, const int* hit_count,
                     const float* z, int z_stride, int n_s, int max_rays, const float* vsorted, const float* cbound,
-                    const float* skin_w, const float* tfs, int mode, const int* ray_active, const int* launch_active,
+                    const float* blend_table, int mode, const int* ray_active, const int* launch_active,
                     float* xc, unsigned char* outlier, float* sdf_out, int* worklist, int* work_count, void* stream);
 /* The same for the final samples of the shading pass (z rows hold n_s+1 depths).  eval_mode: outliers get sdf 4 and are
  * dropped from the worklist only when their compositing alpha 1-exp(-sigma(4) dt) is exactly 0 in fp32.
@@ -156,7 +160,7 @@ int mp_warp_inverse(const float* pts, const float* dirs, const float* pose, cons
  * whose skinning weights were used (the training backward needs it: deformer.py:47 detaches the weights). */
 int mp_warp_inverse_shade(const float* dirs, const float* pose, const int* hit_index, const int* hit_count,
                           const float* z, int z_stride, int n_s, int max_rays, const float* vsorted, const float* cbound,
-                          const float* skin_w, const float* tfs, int eval_mode, const float* beta, float* xc,
+                          const float* blend_table, int eval_mode, const float* beta, float* xc,
                           unsigned char* outlier, unsigned char* need_flag, float* sdf_out, int* worklist,
                           int* work_count, int* nn_index, void* stream);
 /* Jacobian of forward skinning at canonical points (deformer.py:31-35 + multiply.py:625-641): nearest CANONICAL
@@ -166,7 +170,7 @@ int mp_warp_inverse_shade(const float* dirs, const float* pose, const int* hit_i
  * seed [id] (optional, with verts_c [V][3] = the canonical vertices in original order): a vertex id per point whose
  * canonical distance bounds the search (the posed nearest vertex from mp_warp_inverse_shade); the result stays exact. */
 int mp_warp_jacobian(const float* xc, const unsigned char* need, const int* hit_count, int max_rays, int n_s, int n_pts,
-                     const float* vsorted_c, const float* cbound_c, const float* skin_w, const float* tfs, float* jinv,
+                     const float* vsorted_c, const float* cbound_c, const float* blend_table, float* jinv,
                      int* nn_index, const int* seed, const float* verts_c, void* stream);
 
 /* ---- VolSDF error-bound sampler (ray_sampler.py:66-220), split at the SDF queries ---------------

@@ -6,6 +6,8 @@
 #include "../../include/multiply_hip.h"
 #include "common.hpp"
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 namespace {
 
 constexpr int V = MP_SMPL_V, NJ = MP_SMPL_J, NC = MP_KNN_NC, CL = MP_KNN_CLUSTER;
@@ -205,6 +207,28 @@ __global__ __launch_bounds__(64) void k_knn_build(const float* __restrict__ vert
     if (l == 0) cbound[c] = make_float4(cx, cy, cz, r * 1.00001f + 1e-7f);
 }
 
+// -DMP_GEOM_PROF: cycle / event counters of the warp kernels, summed over waves (tools/geom_prof.py reads them):
+//  [0] slabs  [1] cycles total  [2] cycles in knn cull (reductions + sphere tests)  [3] cycles in cluster scans
+//  [4] clusters that passed the box cull  [5] clusters scanned  [6] cycles in loads  [7] cycles in the epilogue
+#ifdef MP_GEOM_PROF
+__device__ unsigned long long g_geom_prof[16];
+#define GP_T() __builtin_readcyclecounter()
+__shared__ unsigned long long gp_lds[16][8];   // per-wave accumulators: one global atomic per wave and counter at exit
+#define GP_ADD(i, v) do { if ((threadIdx.x & 63) == 0) gp_lds[threadIdx.x >> 6][i] += (unsigned long long)(v); } while (0)
+#define GP_BEGIN() do { if ((threadIdx.x & 63) < 8) gp_lds[threadIdx.x >> 6][threadIdx.x & 63] = 0; } while (0)
+#define GP_END() do { if ((threadIdx.x & 63) < 8) atomicAdd(&g_geom_prof[threadIdx.x & 63], gp_lds[threadIdx.x >> 6][threadIdx.x & 63]); } while (0)
+extern "C" int mp_geom_prof_read(unsigned long long* host16, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_geom_prof), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_geom_prof), z, sizeof(z)); }
+    return (int)e;
+}
+#else
+#define GP_T() 0ull
+#define GP_ADD(i, v) do { } while (0)
+#define GP_BEGIN() do { } while (0)
+#define GP_END() do { } while (0)
+#endif
+
 // Exact nearest vertex among the clustered set held in LDS (vs, cb), for the 64 points of one wave at once.
 // The wave's points are spatially coherent (neighbouring rays at the same sample index), so clusters are culled ONCE per
 // wave against the bounding box of its points: lane c tests clusters c and c+64 in parallel (two LDS reads instead of a
@@ -216,6 +240,7 @@ __device__ __forceinline__ void knn_capped(const float4* vs, const float4* cb, f
                                            float& best, int& bi) {
     const int lane = threadIdx.x & 63;
     const bool on = cap2 >= 0.0f;
+    const unsigned long long gp0 = GP_T();
     const float lx = wave_min(on ? px : FLT_MAX), ly = wave_min(on ? py : FLT_MAX), lz = wave_min(on ? pz : FLT_MAX);
     const float hx = wave_max(on ? px : -FLT_MAX), hy = wave_max(on ? py : -FLT_MAX), hz = wave_max(on ? pz : -FLT_MAX);
     const float capr = sqrtf(wave_max(on ? cap2 : 0.0f));
@@ -233,8 +258,15 @@ __device__ __forceinline__ void knn_capped(const float4* vs, const float4* cb, f
         }
         cand[h] = __ballot(hit);
     }
-    best = cap2;
-    bi = INT_MAX;
+    // running minimum as ONE 64-bit key (distance bits << 32 | vertex id): distances are >= 0, so their bit patterns order
+    // like the values, and a tie in distance falls through to the lower vertex id (the argmin order of the reference's
+    // brute-force search) -- one v_cmp_lt_u64 and two selects per vertex, no branch in the scan.  Lanes that are off
+    // hold key 0, which nothing undercuts.
+    unsigned long long key = on ? (((unsigned long long)__float_as_uint(cap2) << 32) | (unsigned)INT_MAX) : 0ull;
+    const f32x2 PX = {px, px}, PY = {py, py}, PZ = {pz, pz};
+    const unsigned long long gp1 = GP_T();
+    GP_ADD(2, gp1 - gp0);
+    GP_ADD(4, __popcll(cand[0]) + __popcll(cand[1]));
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         unsigned long long m = cand[h];
@@ -244,20 +276,26 @@ __device__ __forceinline__ void knn_capped(const float4* vs, const float4* cb, f
             const float4 b = cb[c];
             const float ex = px - b.x, ey = py - b.y, ez = pz - b.z;
             const float lb = fmaxf(sqrtf(ex * ex + ey * ey + ez * ez) - b.w, 0.0f);
-            if (!__any(lb * lb * 0.9999f <= best)) continue;   // no lane can improve inside this sphere
+            if (!__any(on && lb * lb * 0.9999f <= __uint_as_float((unsigned)(key >> 32)))) continue;   // no lane can improve here
+            GP_ADD(5, 1);
+            // two vertices per step in packed fp32 (v_pk_add / v_pk_mul / v_pk_fma_f32): the cluster is stored as pairs
+            // (xa xb ya yb)(za zb ida idb), see load_knn_lds
             const float4* cv = vs + c * CL;
 #pragma unroll 8
-            for (int k = 0; k < CL; ++k) {
-                const float4 v = cv[k];
-                const float fx = px - v.x, fy = py - v.y, fz = pz - v.z;
-                const float d2 = fx * fx + fy * fy + fz * fz;
-                const int id = __float_as_int(v.w);
-                const bool upd = d2 < best || (d2 == best && id < bi);
-                best = upd ? d2 : best;
-                bi = upd ? id : bi;
+            for (int k = 0; k < CL / 2; ++k) {
+                const float4 A = cv[2 * k], B = cv[2 * k + 1];
+                const f32x2 fx = PX - (f32x2){A.x, A.y}, fy = PY - (f32x2){A.z, A.w}, fz = PZ - (f32x2){B.x, B.y};
+                const f32x2 d2 = __builtin_elementwise_fma(fz, fz, __builtin_elementwise_fma(fy, fy, fx * fx));
+                const unsigned long long ka = ((unsigned long long)__float_as_uint(d2.x) << 32) | __float_as_uint(B.z);
+                const unsigned long long kb = ((unsigned long long)__float_as_uint(d2.y) << 32) | __float_as_uint(B.w);
+                key = ka < key ? ka : key;
+                key = kb < key ? kb : key;
             }
         }
     }
+    best = on ? __uint_as_float((unsigned)(key >> 32)) : cap2;
+    bi = on ? (int)(unsigned)(key & 0xffffffffull) : INT_MAX;
+    GP_ADD(3, GP_T() - gp1);
 }
 
 // Unbounded exact search.  An upper bound of the nearest-vertex distance is cheap: every cluster's bounding sphere
@@ -296,7 +334,11 @@ __device__ __forceinline__ void knn_unbounded(const float4* vs, const float4* cb
 __device__ __forceinline__ void load_knn_lds(float4* vs, float4* cb, const float* vsorted, const float* cbound) {
     const float4* gv = (const float4*)vsorted;
     const float4* gc = (const float4*)cbound;
-    for (int i = threadIdx.x; i < NC * CL; i += blockDim.x) vs[i] = gv[i];
+    for (int i = threadIdx.x; i < NC * CL / 2; i += blockDim.x) {      // vertex pair (2i, 2i+1) -> (xa xb ya yb)(za zb ida idb)
+        const float4 a = gv[2 * i], b = gv[2 * i + 1];
+        vs[2 * i] = make_float4(a.x, b.x, a.y, b.y);
+        vs[2 * i + 1] = make_float4(a.z, b.z, a.w, b.w);
+    }
     for (int i = threadIdx.x; i < NC; i += blockDim.x) cb[i] = gc[i];
 }
 
@@ -325,8 +367,27 @@ __device__ __forceinline__ void inv3(const float (&T)[12], float (&I)[9]) {
     I[6] = c2 * r; I[7] = (b * g - a * h) * r; I[8] = (a * e - b * d) * r;
 }
 
+// Per-vertex inverse blended transform of one pose: row r of vertex v = (I[3r], I[3r+1], I[3r+2], T[r][3] / T[3][3]) with
+// T = sum_j w[v][j] tfs[j] and I = inverse of its 3x3 block.  The warp kernels map a point whose nearest vertex is v with
+// x_c = I (x - c): one 48-byte gather per point instead of 24 scattered weight loads, 312 FMAs and a 3x3 inversion, with
+// the same operations in the same order (the table is what every point with that neighbour computed for itself before).
+__global__ void k_blend_table(const float* __restrict__ skin_w, const float* __restrict__ tfs, int n_verts,
+                              float4* __restrict__ table) {
+    __shared__ float tl[NJ * 16];
+    for (int i = threadIdx.x; i < NJ * 16; i += blockDim.x) tl[i] = tfs[i];
+    __syncthreads();
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_verts) return;
+    float T[12], s33, I[9];
+    blend_tf(skin_w, tl, v, T, s33);
+    inv3(T, I);
+    table[3 * v] = make_float4(I[0], I[1], I[2], T[3] / s33);
+    table[3 * v + 1] = make_float4(I[3], I[4], I[5], T[7] / s33);
+    table[3 * v + 2] = make_float4(I[6], I[7], I[8], T[11] / s33);
+}
+
 constexpr int WARP_THREADS = 1024;
-constexpr int WARP_LDS = NC * CL * 16 + NC * 16 + NJ * 16 * 4 + 32;
+constexpr int WARP_LDS = NC * CL * 16 + NC * 16 + 32;
 
 // mode 0: all points -> xc + worklist; mode 1: eval, outliers get sdf 4 and are skipped;
 // mode 2: eval shading, outliers get sdf 4 and are skipped only when their alpha is exactly 0 in fp32
@@ -334,7 +395,7 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
     const float* __restrict__ pts, const float* __restrict__ dirs, const float* __restrict__ pose,
     const int* __restrict__ hit_index, const int* __restrict__ hit_count, const float* __restrict__ z, int z_stride,
     int n_s, int max_rays, int n_pts, const float* __restrict__ vsorted, const float* __restrict__ cbound,
-    const float* __restrict__ skin_w, const float* __restrict__ tfs, int mode, const int* __restrict__ ray_active,
+    const float4* __restrict__ btab, int mode, const int* __restrict__ ray_active,
     const float* __restrict__ beta_p, const int* __restrict__ launch_active, float* __restrict__ xc,
     unsigned char* __restrict__ outlier, unsigned char* __restrict__ need_flag, float* __restrict__ sdf_out,
     int* __restrict__ worklist, int* __restrict__ work_count, int* __restrict__ nn_index) {
@@ -342,10 +403,8 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
     if (launch_active && *launch_active == 0) return;  // no ray of this launch is still being sampled
     float4* vs = (float4*)smem;
     float4* cb = vs + NC * CL;
-    float* tl = (float*)(cb + NC);
-    float* box = tl + NJ * 16;  // [6] conservative bounds of the vertex set (from the cluster spheres)
+    float* box = (float*)(cb + NC);  // [6] conservative bounds of the vertex set (from the cluster spheres)
     load_knn_lds(vs, cb, vsorted, cbound);
-    for (int i = threadIdx.x; i < NJ * 16; i += blockDim.x) tl[i] = tfs[i];
     __syncthreads();
     if (threadIdx.x < 64) {
         float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
@@ -359,6 +418,7 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    GP_BEGIN();
     const bool rays = pts == nullptr;
     const int n_rays = rays ? min(*hit_count, max_rays) : 0;
     const int n_slab = rays ? ((n_rays + 63) / 64) * n_s : (n_pts + 63) / 64;
@@ -368,6 +428,8 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
     for (int slab = blockIdx.x * nw + wave; slab < n_slab; slab += gridDim.x * nw) {
         int pid = -1;
         float x = 0.f, y = 0.f, zz = 0.f, dt = 0.f;
+        const unsigned long long gs0 = GP_T();
+        GP_ADD(0, 1);
         if (rays) {
             const int k = (slab / n_s) * 64 + lane, s = slab % n_s;
             if (k < n_rays && (!ray_active || ray_active[k])) {
@@ -386,6 +448,11 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
                                             zz <= box[5]);
         float best = -1.0f;
         int bi = INT_MAX;
+#ifdef MP_GEOM_PROF
+        x += __int_as_float(__float_as_int(x) & 0);   // keep the loads ahead of the stamp
+        const unsigned long long gs1 = GP_T();
+        GP_ADD(6, gs1 - gs0);
+#endif
         if (mode == 0) knn_unbounded<false>(vs, cb, x, y, zz, pid >= 0, best, bi);
         else if (__any(pid >= 0 && near_box))
             knn_capped(vs, cb, x, y, zz, (pid >= 0 && near_box) ? cap2 : -1.0f, best, bi);  // idle lanes open no cluster
@@ -409,16 +476,15 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
             knn_unbounded<false>(vs, cb, x, y, zz, need_far, b2, i2);
             if (need_far) { best = b2; bi = i2; }
         }
+        const unsigned long long gs2 = GP_T();
         if (pid >= 0) {
             if (need_flag) need_flag[pid] = need ? 1 : 0;
             if (need) {
-                float T[12], s33, I[9];
-                blend_tf(skin_w, tl, bi, T, s33);
-                inv3(T, I);
-                const float qx = x - T[3] / s33, qy = y - T[7] / s33, qz = zz - T[11] / s33;
-                xc[3 * (size_t)pid] = I[0] * qx + I[1] * qy + I[2] * qz;
-                xc[3 * (size_t)pid + 1] = I[3] * qx + I[4] * qy + I[5] * qz;
-                xc[3 * (size_t)pid + 2] = I[6] * qx + I[7] * qy + I[8] * qz;
+                const float4 r0 = btab[3 * bi], r1 = btab[3 * bi + 1], r2 = btab[3 * bi + 2];
+                const float qx = x - r0.w, qy = y - r1.w, qz = zz - r2.w;
+                xc[3 * (size_t)pid] = r0.x * qx + r0.y * qy + r0.z * qz;
+                xc[3 * (size_t)pid + 1] = r1.x * qx + r1.y * qy + r1.z * qz;
+                xc[3 * (size_t)pid + 2] = r2.x * qx + r2.y * qy + r2.z * qz;
                 if (nn_index) nn_index[pid] = bi;
                 append = worklist != nullptr;
             }
@@ -432,7 +498,14 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
                 if (append) worklist[base + __popcll(m & ((1ull << lane) - 1ull))] = pid;
             }
         }
+#ifdef MP_GEOM_PROF
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long gs3 = GP_T();
+        GP_ADD(7, gs3 - gs2);
+        GP_ADD(1, gs3 - gs0);
+#endif
     }
+    GP_END();
 }
 
 // Points are addressed like in k_warp_inverse (slab = 64 neighbouring hit rays x one sample index, so the 64 canonical
@@ -443,19 +516,18 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_jacobian(const float* __r
                                                                 const int* __restrict__ hit_count, int max_rays, int n_s,
                                                                 int n_pts, const float* __restrict__ vsorted_c,
                                                                 const float* __restrict__ cbound_c,
-                                                                const float* __restrict__ skin_w,
-                                                                const float* __restrict__ tfs, float* __restrict__ jinv,
+                                                                const float4* __restrict__ btab,
+                                                                float* __restrict__ jinv,
                                                                 int* __restrict__ nn_index,
                                                                 const int* __restrict__ seed,
                                                                 const float* __restrict__ verts_c) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* vs = (float4*)smem;
     float4* cb = vs + NC * CL;
-    float* tl = (float*)(cb + NC);
     load_knn_lds(vs, cb, vsorted_c, cbound_c);
-    for (int i = threadIdx.x; i < NJ * 16; i += blockDim.x) tl[i] = tfs[i];
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    GP_BEGIN();
     const bool rays = n_s > 0;
     const int n_rays = rays ? min(*hit_count, max_rays) : 0;
     const int n_slab = rays ? ((n_rays + 63) / 64) * n_s : (n_pts + 63) / 64;
@@ -469,6 +541,8 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_jacobian(const float* __r
             if (i < n_pts) id = i;
         }
         if (!__any(id >= 0)) continue;
+        const unsigned long long gs0 = GP_T();
+        GP_ADD(0, 1);
         float x = 0.f, y = 0.f, z = 0.f;
         if (id >= 0) { x = xc[3 * (size_t)id]; y = xc[3 * (size_t)id + 1]; z = xc[3 * (size_t)id + 2]; }
         float best; int bi;
@@ -486,14 +560,17 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_jacobian(const float* __r
             knn_unbounded<true>(vs, cb, x, y, z, id >= 0, best, bi);
         }
         if (id >= 0) {
-            float T[12], s33, I[9];
-            blend_tf(skin_w, tl, bi, T, s33);
-            inv3(T, I);
-#pragma unroll
-            for (int i = 0; i < 9; ++i) jinv[9 * (size_t)id + i] = I[i];
+            const float4 r0 = btab[3 * bi], r1 = btab[3 * bi + 1], r2 = btab[3 * bi + 2];
+            float* o = jinv + 9 * (size_t)id;
+            o[0] = r0.x; o[1] = r0.y; o[2] = r0.z; o[3] = r1.x; o[4] = r1.y; o[5] = r1.z; o[6] = r2.x; o[7] = r2.y; o[8] = r2.z;
             if (nn_index) nn_index[id] = bi;
         }
+#ifdef MP_GEOM_PROF
+        __builtin_amdgcn_s_waitcnt(0);
+        GP_ADD(1, GP_T() - gs0);
+#endif
     }
+    GP_END();
 }
 
 // ------------------------------------------------------------------------------------------------ oriented box (PCA)
@@ -763,9 +840,16 @@ extern "C" int mp_ray_hits_from_index(const int* hit_index, int n_hit, int n_ray
     return (int)hipGetLastError();
 }
 
+extern "C" int mp_blend_table(const float* skin_w, const float* tfs, int n_verts, float* table, void* stream) {
+    if (n_verts <= 0) return 0;
+    hipLaunchKernelGGL(k_blend_table, dim3((n_verts + 255) / 256), dim3(256), 0, (hipStream_t)stream, skin_w, tfs, n_verts,
+                       (float4*)table);
+    return (int)hipGetLastError();
+}
+
 extern "C" int mp_warp_inverse(const float* pts, const float* dirs, const float* pose, const int* hit_index,
                                const int* hit_count, const float* z, int z_stride, int n_s, int max_rays,
-                               const float* vsorted, const float* cbound, const float* skin_w, const float* tfs,
+                               const float* vsorted, const float* cbound, const float* blend_table,
                                int mode, const int* ray_active, const int* launch_active, float* xc,
                                unsigned char* outlier, float* sdf_out, int* worklist, int* work_count, void* stream) {
     // when pts != NULL, max_rays carries the number of explicit points and sdf_out may carry beta for mode 2 (unused)
@@ -777,8 +861,8 @@ extern "C" int mp_warp_inverse(const float* pts, const float* dirs, const float*
     const int n_slab = pts ? (max_rays + 63) / 64 : ((max_rays + 63) / 64) * n_s;
     const int threads = warp_threads(n_slab), nw = threads / 64;
     hipLaunchKernelGGL(k_warp_inverse, dim3(warp_grid(n_slab, nw)), dim3(threads), WARP_LDS, st, pts, dirs, pose,
-                       hit_index, hit_count, z, z_stride, n_s, max_rays, pts ? max_rays : 0, vsorted, cbound, skin_w, tfs,
-                       mode & 3, ray_active, (const float*)nullptr, launch_active, xc, outlier, (unsigned char*)nullptr, sdf_out,
+                       hit_index, hit_count, z, z_stride, n_s, max_rays, pts ? max_rays : 0, vsorted, cbound,
+                       (const float4*)blend_table, mode & 3, ray_active, (const float*)nullptr, launch_active, xc, outlier, (unsigned char*)nullptr, sdf_out,
                        worklist, work_count, (int*)nullptr);
     return (int)hipGetLastError();
 }
@@ -786,7 +870,7 @@ extern "C" int mp_warp_inverse(const float* pts, const float* dirs, const float*
 // eval-shading variant (mode 2) needs beta; exported separately to keep mp_warp_inverse's signature small
 extern "C" int mp_warp_inverse_shade(const float* dirs, const float* pose, const int* hit_index, const int* hit_count,
                                      const float* z, int z_stride, int n_s, int max_rays, const float* vsorted,
-                                     const float* cbound, const float* skin_w, const float* tfs, int eval_mode,
+                                     const float* cbound, const float* blend_table, int eval_mode,
                                      const float* beta, float* xc, unsigned char* outlier, unsigned char* need_flag,
                                      float* sdf_out, int* worklist, int* work_count, int* nn_index, void* stream) {
     if (max_rays <= 0) return 0;
@@ -798,14 +882,14 @@ extern "C" int mp_warp_inverse_shade(const float* dirs, const float* pose, const
     const int threads = warp_threads(n_slab), nw = threads / 64;
     hipLaunchKernelGGL(k_warp_inverse, dim3(warp_grid(n_slab, nw)), dim3(threads), WARP_LDS, st,
                        (const float*)nullptr, dirs, pose, hit_index, hit_count, z, z_stride, n_s, max_rays, 0, vsorted,
-                       cbound, skin_w, tfs, eval_mode ? 2 : 0, (const int*)nullptr, beta, (const int*)nullptr, xc, outlier,
+                       cbound, (const float4*)blend_table, eval_mode ? 2 : 0, (const int*)nullptr, beta, (const int*)nullptr, xc, outlier,
                        need_flag, sdf_out, worklist, work_count, nn_index);
     return (int)hipGetLastError();
 }
 
 extern "C" int mp_warp_jacobian(const float* xc, const unsigned char* need, const int* hit_count, int max_rays, int n_s,
-                                int n_pts, const float* vsorted_c, const float* cbound_c, const float* skin_w,
-                                const float* tfs, float* jinv, int* nn_index, const int* seed, const float* verts_c,
+                                int n_pts, const float* vsorted_c, const float* cbound_c, const float* blend_table,
+                                float* jinv, int* nn_index, const int* seed, const float* verts_c,
                                 void* stream) {
     if ((n_s > 0 ? max_rays : n_pts) <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
@@ -815,6 +899,6 @@ extern "C" int mp_warp_jacobian(const float* xc, const unsigned char* need, cons
     const int n_slab = n_s > 0 ? ((max_rays + 63) / 64) * n_s : (n_pts + 63) / 64;
     const int threads = warp_threads(n_slab), nw = threads / 64;
     hipLaunchKernelGGL(k_warp_jacobian, dim3(warp_grid(n_slab, nw)), dim3(threads), WARP_LDS, st, xc, need, hit_count,
-                       max_rays, n_s, n_pts, vsorted_c, cbound_c, skin_w, tfs, jinv, nn_index, seed, verts_c);
+                       max_rays, n_s, n_pts, vsorted_c, cbound_c, (const float4*)blend_table, jinv, nn_index, seed, verts_c);
     return (int)hipGetLastError();
 }

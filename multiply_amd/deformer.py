@@ -61,11 +61,18 @@ class SMPLDeformer(nn.Module):
                   "mp_knn_build")
         xc = torch.empty(n, 3, dtype=torch.float32, device=dev)
         outl = torch.empty(n, dtype=torch.uint8, device=dev)
-        tfs = smpl_tfs.detach().float().reshape(24, 16).contiguous()
         hip.check(L.mp_warp_inverse(hip.ptr(x), None, None, None, None, None, 0, 1, n, hip.ptr(vs), hip.ptr(cb),
-                                    hip.ptr(self.smpl_weights[0].contiguous()), hip.ptr(tfs), 0, None, None, hip.ptr(xc),
+                                    hip.ptr(self._blend_table(smpl_tfs)), 0, None, None, hip.ptr(xc),
                                     hip.ptr(outl), None, None, None, hip.stream()), "mp_warp_inverse")
         return xc, outl.bool()
+
+    def _blend_table(self, smpl_tfs):
+        """per-vertex inverse blended transforms of one pose (mp_blend_table), (V,12)"""
+        tfs = smpl_tfs.detach().float().reshape(24, 16).contiguous()
+        w = self.smpl_weights[0].contiguous()
+        tab = torch.empty(w.shape[0], 12, dtype=torch.float32, device=w.device)
+        hip.check(hip.lib().mp_blend_table(hip.ptr(w), hip.ptr(tfs), w.shape[0], hip.ptr(tab), hip.stream()), "mp_blend_table")
+        return tab
 
     def _query(self, x, verts):
         n = x.shape[0]
@@ -100,8 +107,7 @@ class SMPLDeformer(nn.Module):
         xc = xc.detach().float().contiguous()
         n = xc.shape[0]
         jinv = torch.empty(n, 9, dtype=torch.float32, device=xc.device)
-        tfs = smpl_tfs.detach().float().reshape(24, 16).contiguous()
         hip.check(hip.lib().mp_warp_jacobian(hip.ptr(xc), None, None, 0, 0, n, hip.ptr(self.vsorted_c),
-                                             hip.ptr(self.cbound_c), hip.ptr(self.smpl_weights[0].contiguous()),
-                                             hip.ptr(tfs), hip.ptr(jinv), None, None, None, hip.stream()), "mp_warp_jacobian")
+                                             hip.ptr(self.cbound_c), hip.ptr(self._blend_table(smpl_tfs)),
+                                             hip.ptr(jinv), None, None, None, hip.stream()), "mp_warp_jacobian")
         return jinv.reshape(n, 3, 3)

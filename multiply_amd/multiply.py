@@ -235,6 +235,9 @@ class Multiply(nn.Module):
             cbound = torch.empty(hip.KNN_NC, 4, **f32)
             hip.check(L.mp_knn_build(hip.ptr(verts), hip.ptr(d.knn_perm), hip.ptr(vsorted), hip.ptr(cbound), st),
                       "mp_knn_build")
+            btab = torch.empty(NUM_VERTS, 12, **f32)        # per-vertex inverse blended transform of this pose
+            hip.check(L.mp_blend_table(hip.ptr(server.tables.lbs_weights), hip.ptr(tfs), NUM_VERTS, hip.ptr(btab), st),
+                      "mp_blend_table")
             hit_index = torch.empty(R, **i32)
             inv_index = torch.empty(R, **i32)
             obb = None
@@ -256,7 +259,7 @@ class Multiply(nn.Module):
                                         hip.ptr(counts[n:n + 1]), hip.ptr(inv_index), hip.ptr(scan_tmp), st),
                           "mp_ray_cull")
             cond = (smpl_pose[0, p, 3:] / np.pi).contiguous()          # multiply.py:270
-            per[p] = dict(verts=verts, tfs=tfs, vsorted=vsorted, cbound=cbound, hit_index=hit_index, obb=obb,
+            per[p] = dict(verts=verts, tfs=tfs, btab=btab, vsorted=vsorted, cbound=cbound, hit_index=hit_index, obb=obb,
                           inv_index=inv_index, count=counts[n:n + 1], cond=cond, prm=prm,
                           rest_joints=server.rest_joints() if self.training else None)
         n_hit = counts.tolist()          # the one host sync of the call: sizes the per-person workspaces
@@ -308,8 +311,7 @@ class Multiply(nn.Module):
             with self._ph("sampler_warp"):
                 hip.check(L.mp_warp_inverse(None, hip.ptr(dirs), hip.ptr(pose), hip.ptr(pp["hit_index"]),
                                             hip.ptr(pp["count"]), hip.ptr(znew), NE, NE, Rp, hip.ptr(pp["vsorted"]),
-                                            hip.ptr(pp["cbound"]), hip.ptr(skin_w), hip.ptr(pp["tfs"]),
-                                            0 if train else 1,
+                                            hip.ptr(pp["cbound"]), hip.ptr(pp["btab"]), 0 if train else 1,
                                             hip.ptr(active), hip.ptr(any_active[it:it + 1]), hip.ptr(xc_new), None,
                                             hip.ptr(sdfnew), hip.ptr(work),
                                             hip.ptr(wcount[it:it + 1]), st), "mp_warp_inverse")
@@ -362,14 +364,14 @@ class Multiply(nn.Module):
             ph = self._ph("shade_warp"); ph.__enter__()
             hip.check(L.mp_warp_inverse_shade(hip.ptr(dirs), hip.ptr(pose), hip.ptr(pp["hit_index"]), hip.ptr(pp["count"]),
                                               hip.ptr(zfinal), NZ, S, Rp, hip.ptr(pp["vsorted"]), hip.ptr(pp["cbound"]),
-                                              hip.ptr(skin_w), hip.ptr(pp["tfs"]), 1, hip.ptr(beta), hip.ptr(xc), None,
+                                              hip.ptr(pp["btab"]), 1, hip.ptr(beta), hip.ptr(xc), None,
                                               hip.ptr(need), hip.ptr(sdf), hip.ptr(work2), hip.ptr(wc2), hip.ptr(nn_posed), st),
                       "mp_warp_inverse_shade")
             ph.__exit__()
             jinv = torch.empty(npts, 9, **f32)
             ph = self._ph("shade_jacobian"); ph.__enter__()
             hip.check(L.mp_warp_jacobian(hip.ptr(xc), hip.ptr(need), hip.ptr(pp["count"]), Rp, S, 0,
-                                         hip.ptr(dfm.vsorted_c), hip.ptr(dfm.cbound_c), hip.ptr(skin_w), hip.ptr(pp["tfs"]),
+                                         hip.ptr(dfm.vsorted_c), hip.ptr(dfm.cbound_c), hip.ptr(pp["btab"]),
                                          hip.ptr(jinv), None, hip.ptr(nn_posed), hip.ptr(dfm.verts_c_flat), st), "mp_warp_jacobian")
             ph.__exit__()
             pk_full = hip.packed(imp, "full", 2)
