@@ -245,6 +245,11 @@ __device__ __forceinline__ void knn_capped(const float4* vs, const float4* cb, f
     const float hx = wave_max(on ? px : -FLT_MAX), hy = wave_max(on ? py : -FLT_MAX), hz = wave_max(on ? pz : -FLT_MAX);
     const float capr = sqrtf(wave_max(on ? cap2 : 0.0f));
     unsigned long long cand[2];
+    // the candidate sphere closest to the middle of the wave's points is scanned first: it usually holds the neighbour of
+    // most lanes, and with that distance in hand the per-cluster bound below rejects most of the other candidates
+    const float mx = 0.5f * (lx + hx), my = 0.5f * (ly + hy), mz = 0.5f * (lz + hz);
+    float nearest = FLT_MAX;
+    int nearest_c = -1;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int c = lane + 64 * h;
@@ -255,8 +260,18 @@ __device__ __forceinline__ void knn_capped(const float4* vs, const float4* cb, f
                         dz = b.z - fminf(fmaxf(b.z, lz), hz);
             const float reach = (b.w + capr) * 1.0001f;
             hit = dx * dx + dy * dy + dz * dz <= reach * reach;
+            const float ex = b.x - mx, ey = b.y - my, ez = b.z - mz;
+            const float gap = sqrtf(ex * ex + ey * ey + ez * ez) - b.w;
+            if (hit && gap < nearest) { nearest = gap; nearest_c = c; }
         }
         cand[h] = __ballot(hit);
+    }
+    int first_c = -1;
+    if (cand[0] | cand[1]) {
+        const float wm = wave_min(nearest);
+        const unsigned long long who = __ballot(nearest_c >= 0 && nearest == wm);
+        first_c = __shfl(nearest_c, __builtin_ctzll(who));
+        cand[first_c >> 6] &= ~(1ull << (first_c & 63));
     }
     // running minimum as ONE 64-bit key (distance bits << 32 | vertex id): distances are >= 0, so their bit patterns order
     // like the values, and a tie in distance falls through to the lower vertex id (the argmin order of the reference's
@@ -270,9 +285,10 @@ __device__ __forceinline__ void knn_capped(const float4* vs, const float4* cb, f
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         unsigned long long m = cand[h];
-        while (m) {
-            const int c = __builtin_ctzll(m) + 64 * h;
-            m &= m - 1;
+        while (m || (h == 0 && first_c >= 0)) {
+            int c;
+            if (h == 0 && first_c >= 0) { c = first_c; first_c = -1; }
+            else { c = __builtin_ctzll(m) + 64 * h; m &= m - 1; }
             const float4 b = cb[c];
             const float ex = px - b.x, ey = py - b.y, ez = pz - b.z;
             const float lb = fmaxf(sqrtf(ex * ex + ey * ey + ez * ez) - b.w, 0.0f);

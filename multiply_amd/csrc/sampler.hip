@@ -65,8 +65,62 @@ __device__ __forceinline__ float d_star(const float* Z, const float* S, int i) {
 
 __device__ __forceinline__ float nan_max(float m, float v) { return (m != m || v != v) ? NAN : fmaxf(m, v); }
 
-// get_error_bound (ray_sampler.py:222-230): max over the n-1 intervals; wave-uniform result
-__device__ float error_bound(const Arr& r, int n, float beta) {
+// get_error_bound (ray_sampler.py:222-230): max over the n-1 intervals; wave-uniform result.
+// Lane l owns the intervals [l*ch, l*ch + cnt); their (dist, sdf, d*) do not change over the beta line search, so the caller
+// loads them into registers once (ChunkRegs) and every evaluation works from there: per interval one density and one
+// exponential, each computed once and used by both the prefix sums and the running bound.
+constexpr int MAXCH = 10;   // 640 samples / 64 lanes
+
+struct ChunkRegs {
+    float dist[MAXCH], s[MAXCH], d[MAXCH];
+    int cnt;
+};
+
+__device__ __forceinline__ void load_chunk(const Arr& r, int n, ChunkRegs& c) {
+    const int lane = threadIdx.x & 63, ni = n - 1;
+    const int ch = (ni + 63) / 64, i0 = min(lane * ch, ni), i1 = min(i0 + ch, ni);
+    c.cnt = i1 - i0;
+#pragma unroll
+    for (int j = 0; j < MAXCH; ++j) {
+        const bool on = j < c.cnt;
+        const int i = on ? i0 + j : 0;
+        c.dist[j] = on ? r.Z[i + 1] - r.Z[i] : 0.f;
+        c.s[j] = on ? r.S[i] : 0.f;
+        c.d[j] = on ? r.D[i] : 0.f;
+    }
+}
+
+__device__ float error_bound(const ChunkRegs& c, float beta) {
+    const float inv4b2 = 1.0f / (4.0f * beta * beta);
+    float fe[MAXCH], ee[MAXCH];
+    float sfe = 0.f, serr = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXCH; ++j)
+        if (j < c.cnt) {
+            fe[j] = c.dist[j] * laplace_density(c.s[j], beta);
+            ee[j] = expf(-c.d[j] / beta) * (c.dist[j] * c.dist[j]) * inv4b2;
+            sfe += fe[j];
+            serr += ee[j];
+        }
+    float tot;
+    float integ = wave_excl_scan(sfe, tot);
+    float errint = wave_excl_scan(serr, tot);
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < MAXCH; ++j)
+        if (j < c.cnt) {
+            errint += ee[j];
+            const float bound = (fminf(expf(errint), 1.0e6f) - 1.0f) * expf(-integ);
+            m = nan_max(m, bound);
+            integ += fe[j];
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = nan_max(m, __shfl_xor(m, o));
+    return m;
+}
+
+// the same from LDS, for sample counts beyond MAXCH * 64
+__device__ float error_bound_lds(const Arr& r, int n, float beta) {
     const int lane = threadIdx.x & 63, ni = n - 1;
     const int ch = (ni + 63) / 64, i0 = min(lane * ch, ni), i1 = min(i0 + ch, ni);
     const float inv4b2 = 1.0f / (4.0f * beta * beta);
@@ -176,12 +230,15 @@ __global__ __launch_bounds__(256) void k_sampler_bound(MpSamplerCfg cfg, MpSampl
     wave_sync();
     // line search on beta (ray_sampler.py:113-122)
     float beta = st.beta[k];
-    float curr = error_bound(r, n, beta0);
+    const bool in_regs = n - 1 <= MAXCH * 64;      // wave-uniform
+    ChunkRegs cr;
+    if (in_regs) load_chunk(r, n, cr);
+    float curr = in_regs ? error_bound(cr, beta0) : error_bound_lds(r, n, beta0);
     if (curr <= cfg.eps) beta = beta0;
     float bmin = beta0, bmax = beta;
     for (int j = 0; j < cfg.beta_iters; ++j) {
         const float mid = (bmin + bmax) / 2.0f;
-        curr = error_bound(r, n, mid);
+        curr = in_regs ? error_bound(cr, mid) : error_bound_lds(r, n, mid);
         if (curr <= cfg.eps) bmax = mid;
         if (curr > cfg.eps) bmin = mid;
     }
@@ -218,32 +275,61 @@ __global__ __launch_bounds__(256) void k_sampler_resample(MpSamplerCfg cfg, MpSa
     // chunked scans over the n samples: free energy -> transmittance (ray_sampler.py:126-133)
     const int ch = (n + 63) / 64, i0 = min(lane * ch, n), i1 = min(i0 + ch, n);
     const float inv4b2 = 1.0f / (4.0f * beta * beta);
+    // per-sample free energy and error term: computed once, kept in registers when the lane's chunk fits (ch <= MAXCH),
+    // otherwise recomputed in the second sweep
+    const bool in_regs = ch <= MAXCH;   // wave-uniform
+    float fe_r[MAXCH], ee_r[MAXCH];
     float sfe = 0.f, serr = 0.f;
-    for (int i = i0; i < i1; ++i) {
-        const float dist = i < ni ? r.Z[i + 1] - r.Z[i] : 1e10f;
-        sfe += dist * laplace_density(r.S[i], beta);
-        if (more && i < ni) {
-            r.D[i] = d_star(r.Z, r.S, i);
-            serr += expf(-r.D[i] / beta) * (dist * dist) * inv4b2;
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < MAXCH; ++j) {
+            const int i = i0 + j;
+            fe_r[j] = 0.f; ee_r[j] = 0.f;
+            if (i < i1) {
+                const float dist = i < ni ? r.Z[i + 1] - r.Z[i] : 1e10f;
+                fe_r[j] = dist * laplace_density(r.S[i], beta);
+                sfe += fe_r[j];
+                if (more && i < ni) {
+                    ee_r[j] = expf(-d_star(r.Z, r.S, i) / beta) * (dist * dist) * inv4b2;
+                    serr += ee_r[j];
+                }
+            }
+        }
+    } else {
+        for (int i = i0; i < i1; ++i) {
+            const float dist = i < ni ? r.Z[i + 1] - r.Z[i] : 1e10f;
+            sfe += dist * laplace_density(r.S[i], beta);
+            if (more && i < ni) {
+                r.D[i] = d_star(r.Z, r.S, i);
+                serr += expf(-r.D[i] / beta) * (dist * dist) * inv4b2;
+            }
         }
     }
     float tot;
     float integ = wave_excl_scan(sfe, tot);
     float errint = wave_excl_scan(serr, tot);
     float psum = 0.f;
-    for (int i = i0; i < i1; ++i) {
-        const float dist = i < ni ? r.Z[i + 1] - r.Z[i] : 1e10f;
-        const float fe = dist * laplace_density(r.S[i], beta);
+    auto emit = [&](int i, float fe, float ee) {
         const float trans = expf(-integ);
         float pdf;
         if (more) {  // error-bound pdf (ray_sampler.py:142-149)
-            if (i < ni) errint += expf(-r.D[i] / beta) * (dist * dist) * inv4b2;
+            if (i < ni) errint += ee;
             pdf = (fminf(expf(errint), 1.0e6f) - 1.0f) * trans + cfg.add_tiny;
         } else {     // final pdf from the weights (ray_sampler.py:157-161)
             pdf = (1.0f - expf(-fe)) * trans + 1e-5f;
         }
         if (i < ni) { r.A[i] = pdf; psum += pdf; }
         integ += fe;
+    };
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < MAXCH; ++j)
+            if (i0 + j < i1) emit(i0 + j, fe_r[j], ee_r[j]);
+    } else {
+        for (int i = i0; i < i1; ++i) {
+            const float dist = i < ni ? r.Z[i + 1] - r.Z[i] : 1e10f;
+            emit(i, dist * laplace_density(r.S[i], beta), (more && i < ni) ? expf(-r.D[i] / beta) * (dist * dist) * inv4b2 : 0.f);
+        }
     }
     const float total = wsum(psum);
     wave_sync();
