@@ -273,7 +273,13 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dZ, in
     if (threadIdx.x == 0) db[c] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-// ---- compositing backward (one thread per ray; forward: composite.hip)
+// ---- compositing backward.  Like the forward (composite.hip) ONE WAVE owns one ray and nothing is merged: with fe the free
+// energy sigma dt of a sample, E its exclusive sum in the merged order, T = exp(-E), w = (1 - exp(-fe)) T and
+// dw = dC . rgb + dA + dA_p, the adjoint of fe_j is
+//     dw_j T_j exp(-fe_j)  -  sum_{i behind j} dw_i w_i  -  [j is not the very last sample] dT_bg T_bg
+// "In front of / behind (p, j)" in another person q's sorted list is a rank (binary search on t_end; ties: lower person
+// first, the order of the reference's stable sorts), so E and the suffix sum are per-person prefix sums looked up at those
+// ranks.  (The first version walked the merged list with one THREAD per ray: 512 threads on the whole device, ~1 ms.)
 constexpr int MAX_P = 8;
 __global__ __launch_bounds__(256) void k_composite_bwd(
     int n_rays, int P, int n_z, const int* const* __restrict__ inv_index, const float* const* __restrict__ z,
@@ -281,87 +287,157 @@ __global__ __launch_bounds__(256) void k_composite_bwd(
     const float* __restrict__ bg_rgb, const float* __restrict__ d_rgb_values, const float* __restrict__ d_acc,
     const float* __restrict__ d_acc_person, float* const* __restrict__ d_sdf, float* const* __restrict__ d_rgb,
     float* __restrict__ d_bg_rgb, float* __restrict__ d_beta) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    const int r = blockIdx.x * wpb + wave;
+    const int S = n_z - 1;
+    // per wave, per person: te [S], fe [S], pf [S+1] (prefix of fe), w [S], gp [S+1] (prefix of dw w)
+    const int per_person = 5 * S + 2;
+    float* base = smem + (size_t)wave * P * per_person;
+    const float beta = *beta_p;
+    const bool live = r < n_rays;
+    int k[MAX_P];
+#pragma unroll
+    for (int p = 0; p < MAX_P; ++p) k[p] = (live && p < P) ? inv_index[p][r] : -1;
+    float dC[3] = {0.f, 0.f, 0.f}, dA = 0.f;
+    if (live) {
+        for (int a = 0; a < 3; ++a) dC[a] = d_rgb_values[3 * r + a];
+        dA = d_acc ? d_acc[r] : 0.0f;
+    }
+    // ---- phase 1: free energies and their per-person prefix sums
+#pragma unroll
+    for (int p = 0; p < MAX_P; ++p) {
+        if (p < P && k[p] >= 0) {
+            float* te_l = base + p * per_person;
+            float* fe_l = te_l + S;
+            float* pf_l = fe_l + S;
+            const float* zr = z[p] + (size_t)k[p] * n_z;
+            const float* sr = sdf[p] + (size_t)k[p] * S;
+            float carry = 0.f;
+            if (lane == 0) pf_l[0] = 0.f;
+            for (int i0 = 0; i0 < S; i0 += 64) {
+                const int i = i0 + lane;
+                float fe = 0.f;
+                if (i < S) {
+                    const float ts = zr[i], te = zr[i + 1];
+                    fe = mp::laplace_density(sr[i], beta) * (te - ts);
+                    te_l[i] = te;
+                    fe_l[i] = fe;
+                }
+                float tot;
+                const float ex = mp::wave_excl_scan(fe, tot);
+                if (i < S) pf_l[i + 1] = carry + ex + fe;
+                carry += tot;
+            }
+        }
+    }
+    __syncthreads();
+    // rank of t_end `te` of person p's sample among person q's samples (q != p)
+    auto rank_in = [&](int q, int p, float te) {
+        const float* te_q = base + q * per_person;
+        int lo = 0, hi = S;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const float t = te_q[mid];
+            const bool before = q < p ? t <= te : t < te;
+            if (before) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    // ---- phase 2: weights, dw w and its per-person prefix sums
+#pragma unroll
+    for (int p = 0; p < MAX_P; ++p) {
+        if (p < P && k[p] >= 0) {
+            float* te_l = base + p * per_person;
+            float* fe_l = te_l + S;
+            float* pf_l = fe_l + S;
+            float* w_l = pf_l + S + 1;
+            float* gp_l = w_l + S;
+            const float dAp = d_acc_person ? d_acc_person[(size_t)r * P + p] : 0.0f;
+            float carry = 0.f;
+            if (lane == 0) gp_l[0] = 0.f;
+            for (int i0 = 0; i0 < S; i0 += 64) {
+                const int i = i0 + lane;
+                float g = 0.f;
+                if (i < S) {
+                    const float te = te_l[i];
+                    float E = pf_l[i];
+#pragma unroll
+                    for (int q = 0; q < MAX_P; ++q)
+                        if (q < P && q != p && k[q] >= 0) E += (base + q * per_person + 2 * S)[rank_in(q, p, te)];
+                    const float T = expf(-E);
+                    const float w = (1.0f - expf(-fe_l[i])) * T;
+                    const size_t qi = (size_t)k[p] * S + i;
+                    const float dw = dC[0] * rgb[p][3 * qi] + dC[1] * rgb[p][3 * qi + 1] + dC[2] * rgb[p][3 * qi + 2] + dA + dAp;
+                    w_l[i] = w;
+                    g = dw * w;
+                    d_rgb[p][3 * qi] = w * dC[0]; d_rgb[p][3 * qi + 1] = w * dC[1]; d_rgb[p][3 * qi + 2] = w * dC[2];
+                }
+                float tot;
+                const float ex = mp::wave_excl_scan(g, tot);
+                if (i < S) gp_l[i + 1] = carry + ex + g;
+                carry += tot;
+            }
+        }
+    }
+    __syncthreads();
+    // the very last sample of the merged order, and T_bg = its exclusive transmittance (multiply.py:457-463)
+    int p_last = -1;
+    float tm = -FLT_MAX;
+    for (int p = 0; p < P; ++p)
+        if (k[p] >= 0 && (base + p * per_person)[S - 1] >= tm) { tm = (base + p * per_person)[S - 1]; p_last = p; }
+    float E_front = 0.f;
+    for (int p = 0; p < P; ++p)
+        if (k[p] >= 0) E_front += (base + p * per_person + 2 * S)[p == p_last ? S - 1 : S];
+    const float Tbg = p_last >= 0 ? expf(-E_front) : 1.0f;
+    float dTbg = 0.f;
+    for (int a = 0; a < 3; ++a) dTbg += dC[a] * (bg_rgb && live ? bg_rgb[3 * r + a] : 1.0f);
+    if (live && lane < 3 && d_bg_rgb) d_bg_rgb[3 * r + lane] = dC[lane] * Tbg;
+    // ---- phase 3: adjoints of the free energies -> sdf and beta
     float dbeta_local = 0.0f;
-    if (r < n_rays) {
-        const int S = n_z - 1;
-        const float beta = *beta_p;
-        int k[MAX_P], cur[MAX_P];
-        for (int p = 0; p < MAX_P; ++p) { k[p] = p < P ? inv_index[p][r] : -1; cur[p] = 0; }
-        const float dC[3] = {d_rgb_values[3 * r], d_rgb_values[3 * r + 1], d_rgb_values[3 * r + 2]};
-        const float dA = d_acc ? d_acc[r] : 0.0f;
-        // pass 1 (ascending t_end): total free energy before the last sample, and T_bg
-        float E = 0.f, fe_last = 0.f;
-        int n_s = 0;
-        for (;;) {
-            int best = -1; float te = FLT_MAX;
-            for (int p = 0; p < MAX_P; ++p)
-                if (k[p] >= 0 && cur[p] < S) {
-                    const float t = z[p][(size_t)k[p] * n_z + cur[p] + 1];
-                    if (t < te) { te = t; best = p; }
-                }
-            if (best < 0) break;
-            const int i = cur[best];
-            const float ts = z[best][(size_t)k[best] * n_z + i];
-            fe_last = mp::laplace_density(sdf[best][(size_t)k[best] * S + i], beta) * (te - ts);
-            E += fe_last;
-            cur[best] = i + 1;
-            ++n_s;
-        }
-        const float E_excl_last = E - fe_last;          // exponent of T_bg (exclusive transmittance of the last sample)
-        const float Tbg = n_s ? expf(-E_excl_last) : 1.0f;
-        float dTbg = 0.f;
-        for (int a = 0; a < 3; ++a) {
-            const float bg = bg_rgb ? bg_rgb[3 * r + a] : 1.0f;
-            dTbg += dC[a] * bg;
-            if (d_bg_rgb) d_bg_rgb[3 * r + a] = dC[a] * Tbg;
-        }
-        // pass 2 (descending t_end): suffix sums
-        float Eafter = E;       // sum of fe over samples processed so far from the end, subtracted progressively
-        float suffix = 0.f;     // sum_{i > j} dw_i w_i
-        bool first = true;      // the very last sample
-        for (;;) {
-            int best = -1; float te = -FLT_MAX;
-            for (int p = MAX_P - 1; p >= 0; --p)   // ties: higher person last in ascending order -> first here
-                if (k[p] >= 0 && cur[p] > 0) {
-                    const float t = z[p][(size_t)k[p] * n_z + cur[p]];
-                    if (t > te) { te = t; best = p; }
-                }
-            if (best < 0) break;
-            const int p = best, i = cur[p] - 1;
-            const size_t q = (size_t)k[p] * S + i;
-            const float ts = z[p][(size_t)k[p] * n_z + i];
-            const float s = sdf[p][q];
-            const float dt = te - ts;
-            const float sig = mp::laplace_density(s, beta);
-            const float fe = sig * dt;
-            Eafter -= fe;                                // exclusive cumulative free energy of this sample
-            const float T = expf(-Eafter);
-            const float ex = expf(-fe);
-            const float alpha = 1.0f - ex;
-            const float w = alpha * T;
-            const float dw = dC[0] * rgb[p][3 * q] + dC[1] * rgb[p][3 * q + 1] + dC[2] * rgb[p][3 * q + 2] + dA +
-                             (d_acc_person ? d_acc_person[(size_t)r * P + p] : 0.0f);
-            float dfe = dw * T * ex - suffix;
-            if (!first) dfe -= dTbg * Tbg;              // T_bg depends on every sample but the last
-            const float dsig = dfe * dt;
-            // d sigma / d sdf and d sigma / d beta (density.py:20-29)
-            const float eab = expf(-fabsf(s) / beta);
-            const float dsdf = -(0.5f / (beta * beta)) * eab;
-            float dbe;
-            if (s > 0.f) dbe = (0.5f / (beta * beta)) * eab * (s / beta - 1.0f);
-            else if (s < 0.f) dbe = -1.0f / (beta * beta) + (0.5f / (beta * beta)) * eab * (1.0f + s / beta);
-            else dbe = -0.5f / (beta * beta);
-            d_sdf[p][q] = dsig * dsdf;
-            dbeta_local += dsig * dbe;
-            d_rgb[p][3 * q] = w * dC[0]; d_rgb[p][3 * q + 1] = w * dC[1]; d_rgb[p][3 * q + 2] = w * dC[2];
-            suffix += dw * w;
-            first = false;
-            cur[p] = i;
+#pragma unroll
+    for (int p = 0; p < MAX_P; ++p) {
+        if (p < P && k[p] >= 0) {
+            const float* te_l = base + p * per_person;
+            const float* fe_l = te_l + S;
+            const float* pf_l = fe_l + S;
+            const float* w_l = pf_l + S + 1;
+            const float* gp_l = w_l + S;
+            const float* zr = z[p] + (size_t)k[p] * n_z;
+            for (int i = lane; i < S; i += 64) {
+                const float te = te_l[i], fe = fe_l[i];
+                float E = pf_l[i];
+                float suffix = gp_l[S] - gp_l[i + 1];
+#pragma unroll
+                for (int q = 0; q < MAX_P; ++q)
+                    if (q < P && q != p && k[q] >= 0) {
+                        const int lo = rank_in(q, p, te);
+                        const float* pq = base + q * per_person + 2 * S;
+                        E += pq[lo];
+                        suffix += (pq + 2 * S + 1)[S] - (pq + 2 * S + 1)[lo];
+                    }
+                const float T = expf(-E), ex = expf(-fe);
+                const size_t qi = (size_t)k[p] * S + i;
+                const float dw = dC[0] * rgb[p][3 * qi] + dC[1] * rgb[p][3 * qi + 1] + dC[2] * rgb[p][3 * qi + 2] + dA +
+                                 (d_acc_person ? d_acc_person[(size_t)r * P + p] : 0.0f);
+                float dfe = dw * T * ex - suffix;
+                if (!(p == p_last && i == S - 1)) dfe -= dTbg * Tbg;   // T_bg depends on every sample but the last
+                const float s = sdf[p][qi];
+                const float dsig = dfe * (te - zr[i]);
+                // d sigma / d sdf and d sigma / d beta (density.py:20-29)
+                const float eab = expf(-fabsf(s) / beta);
+                const float dsdf = -(0.5f / (beta * beta)) * eab;
+                float dbe;
+                if (s > 0.f) dbe = (0.5f / (beta * beta)) * eab * (s / beta - 1.0f);
+                else if (s < 0.f) dbe = -1.0f / (beta * beta) + (0.5f / (beta * beta)) * eab * (1.0f + s / beta);
+                else dbe = -0.5f / (beta * beta);
+                d_sdf[p][qi] = dsig * dsdf;
+                dbeta_local += dsig * dbe;
+            }
         }
     }
     dbeta_local = mp::wsum(dbeta_local);
-    if ((threadIdx.x & 63) == 0 && dbeta_local != 0.0f) atomicAdd(d_beta, dbeta_local);
+    if (lane == 0 && dbeta_local != 0.0f) atomicAdd(d_beta, dbeta_local);
 }
 
 // ---- background compositing (multiply.py:682-696) forward with stash-free backward; one thread per ray
@@ -861,8 +937,14 @@ int mp_tr_composite_bwd(int n_rays, int n_person, int n_z, const int* const* inv
                         float* const* d_rgb, float* d_bg_rgb, float* d_beta, void* stream) {
     if (n_person > MAX_P) return -1;
     if (n_rays <= 0) return 0;
-    hipLaunchKernelGGL(k_composite_bwd, grid1(n_rays), dim3(TB), 0, ST, n_rays, n_person, n_z, inv_index, z, sdf, rgb, beta,
-                       bg_rgb, d_rgb_values, d_acc, d_acc_person, d_sdf, d_rgb, d_bg_rgb, d_beta);
+    const int per_wave = n_person * (5 * (n_z - 1) + 2) * (int)sizeof(float);
+    if (per_wave > 160 * 1024) return -2;
+    int wpb = 4;
+    while (wpb > 1 && wpb * per_wave > 160 * 1024) wpb >>= 1;
+    static int once = (int)hipFuncSetAttribute((const void*)k_composite_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)once;
+    hipLaunchKernelGGL(k_composite_bwd, dim3((n_rays + wpb - 1) / wpb), dim3(64 * wpb), wpb * per_wave, ST, n_rays, n_person, n_z,
+                       inv_index, z, sdf, rgb, beta, bg_rgb, d_rgb_values, d_acc, d_acc_person, d_sdf, d_rgb, d_bg_rgb, d_beta);
     return (int)hipGetLastError();
 }
 int mp_tr_bg_points(const float* dirs, const float* cam, const float* zbg, int R, int NBG, float radius, float* pts,
