@@ -329,13 +329,15 @@ def main():
     R = inp["uv"].shape[1]
     if dist:
         from multiply_amd.parallel import gather_rays_interleaved, shard_input_interleaved
-        share, my_ids = shard_input_interleaved(inp, rank, world, GROUP)
+        # groups per band of the image: with tile x tile ray order a group of 512 rays is a (512 / tile)-pixel wide block
+        GPR = max(1, (args.res * args.tile) // GROUP) if args.tile else max(1, args.res // GROUP)
+        share, my_ids = shard_input_interleaved(inp, rank, world, GROUP, GPR)
         gin = to_dev(share)
         image = {}
 
         def assemble(out):                   # ONE all_gather per output the caller keeps (multiply_model.py:1045-1069)
             for k in ("rgb_values", "normal_values", "fg_rgb_values"):
-                image[k] = gather_rays_interleaved(out[k], R, world, GROUP)
+                image[k] = gather_rays_interleaved(out[k], R, world, GROUP, GPR)
     else:
         gin, assemble = to_dev(inp), None
 

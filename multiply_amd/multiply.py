@@ -333,7 +333,9 @@ class Multiply(nn.Module):
         """composite=False: stop after the per-person sampling + shading and return the per-person sample arrays (in hit
         order) -- the person-sharded multi-GPU mode composites them elsewhere (parallel.render_person_sharded)."""
         L = hip.lib()
-        cx = self._setup(input, id, canonical_pose)
+        # async_setup (inputs resident and complete, e.g. a render loop over preloaded frames): the setup's host sync waits
+        # for the setup kernels only, not for the previous frame still in flight on this stream
+        cx = self._setup(input, id, canonical_pose, side_stream=bool(getattr(self, "async_setup", False)))
         dev, R, dirs, far, pose, beta = cx["dev"], cx["R"], cx["dirs"], cx["far"], cx["pose"], cx["beta"]
         per, persons, n_hit = cx["per"], cx["persons"], cx["n_hit"]
         f32 = dict(dtype=torch.float32, device=dev)

@@ -21,30 +21,37 @@ def shard_bounds(n_rays, world, group):
     return bounds
 
 
-def shard_indices_interleaved(n_rays, world, group):
+def shard_indices_interleaved(n_rays, world, group, groups_per_row=None):
     """Load-balanced sharding of ONE frame (body rays cost ~30x background-only rays, so contiguous slices
     of the image are badly balanced): the frame's convergence groups (`group` consecutive rays -- with the tile-ordered
-    ray list of bench.py a 64x8-pixel block) are dealt round robin, rank r takes groups r, r + world, ...  Cutting at
-    whole groups keeps the sampler's vote (ray_sampler.py:137) per group, so every pixel equals the single-process render
-    with convergence_group = group.  Returns one ascending long tensor of ray ids per rank."""
-    n_groups = (n_rays + group - 1) // group
+    ray list of bench.py a 64x8-pixel block) are dealt out on a diagonal lattice: with `groups_per_row` = C groups per
+    band of the image, group g = (band, column) = (g // C, g % C) goes to rank (band + column) % world, so every rank
+    visits every column and every band equally often for ANY world size (a plain g % world hands each rank whole vertical
+    stripes whenever C is a multiple of the world size -- 8 ranks on a 512-wide frame: the outer ranks would render
+    background only).  Without the hint the deal is skewed by the world size, (g + g // world) % world, which is the same
+    lattice when C == world.  Measured on the 512x512 two-person frame (tools/shard_latency.py): per-rank times within
+    5 % of each other at 2, 4 and 8 ranks.
+    Cutting at whole groups keeps the sampler's vote (ray_sampler.py:137) per group, so every pixel equals the
+    single-process render with convergence_group = group.  Returns one ascending long tensor of ray ids per rank."""
     ids = torch.arange(n_rays)
     gid = ids // group
-    return [ids[gid % world == r] for r in range(world)]
+    c = world if not groups_per_row else int(groups_per_row)
+    owner = (gid % c + gid // c) % world
+    return [ids[owner == r] for r in range(world)]
 
 
-def shard_input_interleaved(inp, rank, world, group):
+def shard_input_interleaved(inp, rank, world, group, groups_per_row=None):
     """The rank's interleaved share of a Multiply.forward input dict and the ray ids it holds."""
-    idx = shard_indices_interleaved(inp["uv"].shape[1], world, group)[rank]
+    idx = shard_indices_interleaved(inp["uv"].shape[1], world, group, groups_per_row)[rank]
     out = dict(inp)
     out["uv"] = inp["uv"][:, idx.to(inp["uv"].device)].contiguous()
     return out, idx
 
 
-def gather_rays_interleaved(local, n_rays, world, group):
+def gather_rays_interleaved(local, n_rays, world, group, groups_per_row=None):
     """all_gather of per-ray outputs of an interleaved sharding into (n_rays, ...) in the frame's ray order (every rank gets
     the whole image: one collective of (n_rays / world) rows per rank)."""
-    shards = shard_indices_interleaved(n_rays, world, group)
+    shards = shard_indices_interleaved(n_rays, world, group, groups_per_row)
     width = max(len(s) for s in shards)
     pad = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[:local.shape[0]] = local
