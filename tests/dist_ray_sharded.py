@@ -1,7 +1,7 @@
 """2-rank check of the ray-sharded data-parallel path (BASELINE.json configs[2]) against the CPU ORACLE
 (run by tests/test_parallel_gpu.py through torch.distributed.run; the ranks may share one GPU: backend gloo).
 
-Render: the frame's convergence groups are dealt round robin (parallel.shard_input_interleaved); every rank renders its share
+Render: the frame's convergence groups are dealt on a diagonal lattice (parallel.shard_input_interleaved); every rank renders its share
 through the HIP path, compares it with the oracle's render of the SAME rays, and the all_gather'ed image equals the
 single-process render bit for bit.  Training: every rank runs forward + loss + backward on its own pixels, ONE flat gradient
 all-reduce (parallel.GradientAllReduce); the averaged gradient of every parameter is compared with the average of the
@@ -29,7 +29,8 @@ def main():
     dev = lambda d: {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in d.items()}
     model.convergence_group = GROUP
     share, ids = parallel.shard_input_interleaved(inp, rank, world, GROUP)
-    assert len(ids) == R // world and int(ids[GROUP]) == GROUP * world + rank * GROUP      # round robin over groups
+    mine = [g for g in range(R // GROUP) if (g % world + g // world) % world == rank]        # diagonal-lattice deal of the groups
+    assert len(ids) == R // world and [int(ids[i * GROUP]) for i in range(len(mine))] == [g * GROUP for g in mine]
     ok = True
 
     def check(cond, what):
