@@ -15,7 +15,7 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(rank % torch.cuda.device_count())
-    model, oracle, inp = build(H=16, W=16)
+    model, oracle, inp = build(P=int(os.environ.get("MP_TEST_PERSONS", "2")), H=16, W=16)
     R = inp["uv"].shape[1]
     gin = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inp.items()}
     model.convergence_group = R // world                      # groups must not straddle the ray slices

@@ -9,11 +9,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _run_two_ranks(script, port_base):
+def _run_two_ranks(script, port_base, ranks=2, env=None):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port_base + os.getpid() % 300), os.path.join(root, "tests", script)]
-    r = subprocess.run(cmd, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
+           "127.0.0.1", "--master-port", str(port_base + os.getpid() % 300), os.path.join(root, "tests", script)]
+    r = subprocess.run(cmd, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
+                       env=dict(os.environ, **(env or {})))
     print(r.stdout[-3000:])
     assert r.returncode == 0
 
@@ -27,6 +28,11 @@ def test_ray_sharded_render_and_dp_training_match_the_oracle():
 
 def test_person_sharded_render_matches_single_process():
     _run_two_ranks("dist_person_sharded.py", 29600)
+
+
+def test_person_sharded_render_four_persons_on_four_ranks():
+    """BASELINE.json configs[3] at its own shape: 4 persons, one per rank (the ranks share the box's GPUs over gloo)"""
+    _run_two_ranks("dist_person_sharded.py", 30300, ranks=4, env={"MP_TEST_PERSONS": "4"})
 
 
 def test_person_sharded_training_matches_single_process():
