@@ -168,3 +168,72 @@ def frame_instance_masks(model, inputs, use_smpl_mesh, res_up=2):
             t = torch.cat([j, torch.ones_like(j[:, :1])], 1) @ Pm.t()
             kps.append((t[:, :2] / t[:, 2:3]).to(torch.int32))                      # astype(np.int32): truncation
         return instance_masks(depth), depth, torch.stack(kps, 0)
+
+
+def body_model_inputs(body_model_list, frame_idx):
+    """multiply_model.py:162-168 / 264-274: the per-frame rows of every person's BodyModelParams stacked into the model's
+    smpl_trans (1,P,3), smpl_shape (1,P,10), smpl_pose (1,P,72) inputs (they carry the embeddings' gradients)."""
+    rows = [bm(frame_idx) for bm in body_model_list]
+    trans = torch.stack([r["transl"] for r in rows], dim=1)
+    shape = torch.stack([r["betas"] for r in rows], dim=1)
+    pose = torch.cat((torch.stack([r["global_orient"] for r in rows], dim=1),
+                      torch.stack([r["body_pose"] for r in rows], dim=1)), dim=2)
+    return trans, shape, pose
+
+
+def opt_depth_frame(model, body_model_list, loss_fn, inputs, sample_fn, epoch, it_per_loop, lr, loss_opt=None, depth_pose=False,
+                    depth_cond_zero=False, res_up=2):
+    """One frame of the trainer's depth-refinement stage (multiply_model.py:230-486): the persons' canonical meshes are
+    extracted once, then `it_per_loop` Adam steps on the frame's body-model rows -- the translations only, or every body
+    parameter with depth_pose -- minimise  render loss (a 512-ray training forward of the scene model) + depth-order loss
+    + interpenetration loss  of the meshes re-posed with the current rows.
+
+    inputs: the frame's test item on the device (P, C, intrinsics, pose, smpl_params, idx, img_size, org_sam_mask), batch
+    dimension 1.  sample_fn() -> (dict with uv (1,n,2), index_outside, sam_mask (1,n,P); dict with rgb (1,n,3)): the frame's
+    pixel samples of one iteration (the reference draws them with weighted_sampling; datasets.SceneStore.sample does the
+    same from the resident frame).  Returns the per-iteration {'render_loss','depth_order_loss','interpenetration_loss'}."""
+    from .mesh import canonical_mesh
+    loss_opt = loss_opt or {}
+    params = list(p for bm in body_model_list for p in bm.parameters()) if depth_pose else [bm.transl.weight for bm in body_model_list]
+    saved = [p.requires_grad for p in params]
+    for p in params:
+        p.requires_grad_(True)
+    opt = torch.optim.Adam([{"params": params, "lr": lr}], lr=lr, eps=1e-8)
+    frame = inputs["idx"].reshape(-1).long()
+    scale = inputs["smpl_params"][:, :, 0]
+    renderer = get_renderer(inputs)
+    with torch.no_grad():
+        _, _, pose0 = body_model_inputs(body_model_list, frame)
+        meshes = []
+        for p in range(len(model.smpl_server_list)):
+            cond = pose0[0, p, 3:] * 0.0 if depth_cond_zero else pose0[0, p, 3:] / np.pi
+            meshes.append(canonical_mesh(model, p, cond=cond, res_up=res_up))
+    faces = [m["faces"][None] for m in meshes]
+    fade = 1 - min(DEPTH_LOSS_MILESTONE, epoch) / DEPTH_LOSS_MILESTONE
+    was_training = model.training
+    model.train()
+    history = []
+    for _ in range(it_per_loop):
+        smp_in, smp_tg = sample_fn()
+        opt.zero_grad()
+        trans, shape, pose = body_model_inputs(body_model_list, frame)
+        minp = dict(smpl_trans=trans, smpl_shape=shape, smpl_pose=pose, smpl_pose_last=pose,       # temporal loss disabled (:361)
+                    idx=inputs["idx"], P=inputs["P"], C=inputs["C"], intrinsics=inputs["intrinsics"], pose=inputs["pose"],
+                    smpl_params=inputs["smpl_params"], current_epoch=epoch, **smp_in)
+        out = model(minp, cond_zero_shit=True) if depth_cond_zero else model(minp)
+        render = loss_fn(out, smp_tg)["loss"]
+        verts = []
+        for p, server in enumerate(model.smpl_server_list):
+            so = server(scale[:, p], trans[:, p], pose[:, p], shape[:, p])
+            verts.append((1 / scale[:, p].squeeze()) * deformed_mesh_vertices(model, meshes[p]["vertices"][None], so["smpl_tfs"], p))
+        depth = [d[0, :, :, 0] for d in renderer.render_multiple_depth_map(verts, faces)]
+        inter = loss_opt.get("interpenetration_loss_weight", 0.0) * fade * interpenetration_loss(verts, faces)
+        order = depth_order_loss(depth, inputs["org_sam_mask"], epoch, loss_opt.get("depth_order_weight", 0.005))
+        (inter.sum() + order + render.sum()).backward()
+        opt.step()
+        history.append({"render_loss": render.detach().reshape(()), "depth_order_loss": order.detach().reshape(()),
+                        "interpenetration_loss": inter.detach().reshape(())})
+    for p, r in zip(params, saved):
+        p.requires_grad_(r)
+    model.train(was_training)
+    return history
