@@ -291,3 +291,34 @@ def test_depth_refinement_stage_on_a_written_sequence(tmp_path):
     dz = [float(bml[p].transl.weight[0, 2] - t0[p][0, 2]) for p in range(2)]
     print(f"[info] translation change along the camera axis: person 0 {dz[0]:+.4f}, person 1 {dz[1]:+.4f}")
     assert dz[0] > 0 > dz[1]                                                            # person 0 back, person 1 forward
+
+
+def test_vertex_colour_renders_of_a_scene():
+    """render_multiple_meshes / render_mesh_recon (render.py:107-119, 161-208): two coloured spheres joined as one scene ->
+    RGBA over white; the nearer sphere hides the farther one; normal / shaded views stack along the height."""
+    H, W = 48, 64
+    K = np.array([[60.0, 0, 31.7], [0, 60.0, 24.2], [0, 0, 1.0]])
+    r = make_renderer(K, np.eye(3), np.array([0.0, 0.0, 3.0]), H, W)
+    va, fa = uv_sphere([-0.15, 0.0, 0.0], 0.5, 24, 48)
+    vb, fb = uv_sphere([0.35, 0.05, 0.8], 0.5, 24, 48)
+    t = lambda a: torch.tensor(a).float().cuda()
+    red, blue = torch.tensor([1.0, 0, 0]).cuda().expand(va.shape[0], 3), torch.tensor([0, 0, 1.0]).cuda().expand(vb.shape[0], 3)
+    img = r.render_multiple_meshes([t(va)[None], t(vb)[None]], [torch.tensor(fa).cuda()[None], torch.tensor(fb).cuda()[None]],
+                                   [red[None], blue[None]])
+    torch.cuda.synchronize()
+    assert img.shape == (1, H, W, 4)
+    za = r.rasterize(t(va), torch.tensor(fa).cuda()).zbuf[0, :, :, 0]
+    zb = r.rasterize(t(vb), torch.tensor(fb).cuda()).zbuf[0, :, :, 0]
+    is_a = (za > 0) & ((zb < 0) | (za < zb))
+    is_b = (zb > 0) & ~is_a
+    empty = (za < 0) & (zb < 0)
+    assert bool(is_a.any()) and bool(is_b.any()) and bool(((za > 0) & (zb > 0)).any())       # they overlap in the image
+    assert torch.allclose(img[0][is_a], torch.tensor([1.0, 0, 0, 1]).cuda(), atol=1e-5)
+    assert torch.allclose(img[0][is_b], torch.tensor([0, 0, 1.0, 1]).cuda(), atol=1e-5)
+    assert torch.equal(img[0][empty], torch.tensor([1.0, 1, 1, 0]).cuda().expand(int(empty.sum()), 4))
+    views = r.render_mesh_recon(t(va)[None], torch.tensor(fa).cuda()[None], colors=red[None], mode="npa")
+    assert views.shape == (1, 3 * H, W, 4)
+    nrm = views[0, H:2 * H][za > 0][:, [2, 1, 0]] * 2 - 1         # stack = [phong | normal | albedo]; normals stored as (z, y, x) * 0.5 + 0.5
+    assert float((nrm.norm(dim=1) - 1).abs().max()) < 0.05         # interpolated unit vertex normals
+    centre = views[0, H:2 * H][int(24.2), int(31.7 - 0.15 * 60 / 2.5)]
+    assert float(centre[0]) < 0.1                                  # facing the camera: normal z = -1 -> channel 0 (z) ~ 0
