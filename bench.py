@@ -382,7 +382,7 @@ def main():
         tflop = (6 * (hit_rows + eik_rows) * 2 * M_IMP + 3 * hit_rows * 2 * M_REN + 3 * 32 * rays_rank * 2 * (M_BGIMP + M_BGREN))
         train = {"metric": "ms/train-iter (forward + loss + backward + gradient all-reduce + Adam step)",
                  "ms_per_iter": 1e3 * tdt / args.train_steps, "steps": args.train_steps, "warmup": args.train_warmup,
-                 "rays_per_iter_per_gpu": rays_rank, "rays_per_iter": rays_rank * world, "scaling": "strong" if dist else "weak",
+                 "rays_per_iter_per_gpu": rays_rank, "rays_per_iter": rays_rank * world, "scaling": "strong",
                  "dtype": "f32",
                  "gpu_ms": {"forward+loss": tph[0], "backward": tph[1], "allreduce": tph[2], "adam": tph[3]},
                  "hit_rays": tstats["n_hit"], "last_loss": tloss,
@@ -437,13 +437,13 @@ def main():
             "metric": "rays/sec rendering full 512x512 frames (eval forward, all persons, with background)",
             "value": R * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "strong" if dist else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"2-person synthetic SMPL scene, {args.res}x{args.res} rays/frame, N_samples="
                                    f"{args.samples} (+32 extra +2 bounds = {args.samples + 33} composited samples/ray/"
                                    f"person), N_samples_eval={max(128, args.samples)}, 32 background samples, "
                                    f"convergence groups of 512 rays (reference pixel_per_batch), geometric-init weights",
                        "rays_per_step": R, "frames": args.steps,
-                       "parallelism": (f"ray-sharded dp{world}: one frame per step, convergence groups dealt round robin, "
+                       "parallelism": (f"ray-sharded dp{world}: one frame per step, convergence groups dealt on a diagonal lattice, "
                                        f"all_gather of the image on every rank") if dist else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": dom + " = " + " + ".join(kernels), "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
