@@ -119,7 +119,7 @@ class Renderer:
         hit = (p2f >= 0).nonzero(as_tuple=False)
         if hit.shape[0] == 0:
             return frag.zbuf + 0.0 * verts.sum()
-        tri = verts.reshape(-1, 3)[faces.reshape(-1, 3).long()[p2f[hit[:, 0], hit[:, 1]]]]            # (N, 3, 3)
+        tri = verts.reshape(-1, 3)[faces.reshape(-1, 3).long().to(verts.device)[p2f[hit[:, 0], hit[:, 1]]]]   # (N, 3, 3)
         R, T = self.cam_R[0].to(verts.device), self.cam_T[0].to(verts.device)
         cam = tri @ R.t() + T
         z = cam[..., 2]
