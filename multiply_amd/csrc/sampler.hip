@@ -19,6 +19,18 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// The sampler's exponentials and densities in the hardware's own precision: v_exp_f32 of x * log2(e) (relative error about
+// |x| * 6e-8, i.e. < 6e-6 for the arguments that matter) and a multiplication by 1 / beta instead of three IEEE
+// divisions.  The sampler decides where to put samples from f16 SDF queries (its depths are compared with the oracle at
+// 3e-4): libm's last-ulp exp / expm1 and correctly rounded divisions were most of the instructions of these VALU-bound
+// kernels.  The compositing kernels, whose outputs are compared at 1e-6, keep the exact forms of common.hpp.
+__device__ __forceinline__ float fexp(float x) { return __expf(x); }
+// LaplaceDensity (density.py:20-29): (1/beta) (0.5 + 0.5 sign(s) expm1(-|s|/beta)) = (1/beta) * {0.5 e, 1 - 0.5 e, 0.5}
+__device__ __forceinline__ float density(float sdf, float inv_beta) {
+    const float e = fexp(-fabsf(sdf) * inv_beta);
+    return inv_beta * (sdf > 0.0f ? 0.5f * e : (sdf < 0.0f ? 1.0f - 0.5f * e : 0.5f));
+}
+
 struct Arr {
     float *Z, *S, *D, *A, *B;
 };
@@ -91,14 +103,14 @@ __device__ __forceinline__ void load_chunk(const Arr& r, int n, ChunkRegs& c) {
 }
 
 __device__ float error_bound(const ChunkRegs& c, float beta) {
-    const float inv4b2 = 1.0f / (4.0f * beta * beta);
+    const float ib = 1.0f / beta, inv4b2 = 0.25f * ib * ib;
     float fe[MAXCH], ee[MAXCH];
     float sfe = 0.f, serr = 0.f;
 #pragma unroll
     for (int j = 0; j < MAXCH; ++j)
         if (j < c.cnt) {
-            fe[j] = c.dist[j] * laplace_density(c.s[j], beta);
-            ee[j] = expf(-c.d[j] / beta) * (c.dist[j] * c.dist[j]) * inv4b2;
+            fe[j] = c.dist[j] * density(c.s[j], ib);
+            ee[j] = fexp(-c.d[j] * ib) * (c.dist[j] * c.dist[j]) * inv4b2;
             sfe += fe[j];
             serr += ee[j];
         }
@@ -110,7 +122,7 @@ __device__ float error_bound(const ChunkRegs& c, float beta) {
     for (int j = 0; j < MAXCH; ++j)
         if (j < c.cnt) {
             errint += ee[j];
-            const float bound = (fminf(expf(errint), 1.0e6f) - 1.0f) * expf(-integ);
+            const float bound = (fminf(fexp(errint), 1.0e6f) - 1.0f) * fexp(-integ);
             m = nan_max(m, bound);
             integ += fe[j];
         }
@@ -123,12 +135,12 @@ __device__ float error_bound(const ChunkRegs& c, float beta) {
 __device__ float error_bound_lds(const Arr& r, int n, float beta) {
     const int lane = threadIdx.x & 63, ni = n - 1;
     const int ch = (ni + 63) / 64, i0 = min(lane * ch, ni), i1 = min(i0 + ch, ni);
-    const float inv4b2 = 1.0f / (4.0f * beta * beta);
+    const float ib = 1.0f / beta, inv4b2 = 0.25f * ib * ib;
     float sfe = 0.f, serr = 0.f;
     for (int i = i0; i < i1; ++i) {
         const float dist = r.Z[i + 1] - r.Z[i];
-        sfe += dist * laplace_density(r.S[i], beta);
-        serr += expf(-r.D[i] / beta) * (dist * dist) * inv4b2;
+        sfe += dist * density(r.S[i], ib);
+        serr += fexp(-r.D[i] * ib) * (dist * dist) * inv4b2;
     }
     float tot;
     float integ = wave_excl_scan(sfe, tot);
@@ -136,10 +148,10 @@ __device__ float error_bound_lds(const Arr& r, int n, float beta) {
     float m = -INFINITY;
     for (int i = i0; i < i1; ++i) {
         const float dist = r.Z[i + 1] - r.Z[i];
-        errint += expf(-r.D[i] / beta) * (dist * dist) * inv4b2;
-        const float bound = (fminf(expf(errint), 1.0e6f) - 1.0f) * expf(-integ);
+        errint += fexp(-r.D[i] * ib) * (dist * dist) * inv4b2;
+        const float bound = (fminf(fexp(errint), 1.0e6f) - 1.0f) * fexp(-integ);
         m = nan_max(m, bound);
-        integ += dist * laplace_density(r.S[i], beta);
+        integ += dist * density(r.S[i], ib);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = nan_max(m, __shfl_xor(m, o));
@@ -274,7 +286,7 @@ __global__ __launch_bounds__(256) void k_sampler_resample(MpSamplerCfg cfg, MpSa
     wave_sync();
     // chunked scans over the n samples: free energy -> transmittance (ray_sampler.py:126-133)
     const int ch = (n + 63) / 64, i0 = min(lane * ch, n), i1 = min(i0 + ch, n);
-    const float inv4b2 = 1.0f / (4.0f * beta * beta);
+    const float ib = 1.0f / beta, inv4b2 = 0.25f * ib * ib;
     // per-sample free energy and error term: computed once, kept in registers when the lane's chunk fits (ch <= MAXCH),
     // otherwise recomputed in the second sweep
     const bool in_regs = ch <= MAXCH;   // wave-uniform
@@ -287,10 +299,10 @@ __global__ __launch_bounds__(256) void k_sampler_resample(MpSamplerCfg cfg, MpSa
             fe_r[j] = 0.f; ee_r[j] = 0.f;
             if (i < i1) {
                 const float dist = i < ni ? r.Z[i + 1] - r.Z[i] : 1e10f;
-                fe_r[j] = dist * laplace_density(r.S[i], beta);
+                fe_r[j] = dist * density(r.S[i], ib);
                 sfe += fe_r[j];
                 if (more && i < ni) {
-                    ee_r[j] = expf(-d_star(r.Z, r.S, i) / beta) * (dist * dist) * inv4b2;
+                    ee_r[j] = fexp(-d_star(r.Z, r.S, i) * ib) * (dist * dist) * inv4b2;
                     serr += ee_r[j];
                 }
             }
@@ -298,10 +310,10 @@ __global__ __launch_bounds__(256) void k_sampler_resample(MpSamplerCfg cfg, MpSa
     } else {
         for (int i = i0; i < i1; ++i) {
             const float dist = i < ni ? r.Z[i + 1] - r.Z[i] : 1e10f;
-            sfe += dist * laplace_density(r.S[i], beta);
+            sfe += dist * density(r.S[i], ib);
             if (more && i < ni) {
                 r.D[i] = d_star(r.Z, r.S, i);
-                serr += expf(-r.D[i] / beta) * (dist * dist) * inv4b2;
+                serr += fexp(-r.D[i] * ib) * (dist * dist) * inv4b2;
             }
         }
     }
@@ -310,13 +322,13 @@ __global__ __launch_bounds__(256) void k_sampler_resample(MpSamplerCfg cfg, MpSa
     float errint = wave_excl_scan(serr, tot);
     float psum = 0.f;
     auto emit = [&](int i, float fe, float ee) {
-        const float trans = expf(-integ);
+        const float trans = fexp(-integ);
         float pdf;
         if (more) {  // error-bound pdf (ray_sampler.py:142-149)
             if (i < ni) errint += ee;
-            pdf = (fminf(expf(errint), 1.0e6f) - 1.0f) * trans + cfg.add_tiny;
+            pdf = (fminf(fexp(errint), 1.0e6f) - 1.0f) * trans + cfg.add_tiny;
         } else {     // final pdf from the weights (ray_sampler.py:157-161)
-            pdf = (1.0f - expf(-fe)) * trans + 1e-5f;
+            pdf = (1.0f - fexp(-fe)) * trans + 1e-5f;
         }
         if (i < ni) { r.A[i] = pdf; psum += pdf; }
         integ += fe;
@@ -328,7 +340,7 @@ __global__ __launch_bounds__(256) void k_sampler_resample(MpSamplerCfg cfg, MpSa
     } else {
         for (int i = i0; i < i1; ++i) {
             const float dist = i < ni ? r.Z[i + 1] - r.Z[i] : 1e10f;
-            emit(i, dist * laplace_density(r.S[i], beta), (more && i < ni) ? expf(-r.D[i] / beta) * (dist * dist) * inv4b2 : 0.f);
+            emit(i, dist * density(r.S[i], ib), (more && i < ni) ? fexp(-r.D[i] * ib) * (dist * dist) * inv4b2 : 0.f);
         }
     }
     const float total = wsum(psum);
@@ -369,14 +381,40 @@ __global__ __launch_bounds__(256) void k_sampler_resample(MpSamplerCfg cfg, MpSa
         outv[NS + 2 + j] = r.Z[min(max(idx, 0), n - 1)];
     }
     wave_sync();
-    for (int j = lane; j < NF; j += 64) {  // rank sort (stable)
-        const float v = outv[j];
-        int rank = 0;
-        for (int q = 0; q < NF; ++q) {
-            const float w = outv[q];
-            rank += (w < v || (w == v && q < j)) ? 1 : 0;
+    // Stable sort of [samples | near | far | extras] (ray_sampler.py:208-209).  In eval mode the samples (ascending u) and the
+    // extras (ascending indices into the sorted depths) are sorted runs already: an element's rank is its index in its own
+    // run plus binary-search counts in the others (ties: the earlier run first, like the stable sort), 2 searches instead
+    // of NF comparisons per element.  Random draws (training), or a run that rounding left out of order, take the rank sort.
+    bool runs_sorted = !u_final && !extra_idx;
+    if (runs_sorted) {
+        bool ok = true;
+        for (int j = lane; j < NF - 1; j += 64)
+            if (j != NS - 1 && j != NS && j != NS + 1) ok = ok && outv[j] <= outv[j + 1];
+        runs_sorted = __all(ok);
+    }
+    if (runs_sorted) {
+        const float* Sr = outv;            // [NS]
+        const float* Er = outv + NS + 2;   // [NX]
+        const float vn = outv[NS], vf = outv[NS + 1];
+        for (int j = lane; j < NF; j += 64) {
+            const float v = outv[j];
+            int rank;
+            if (j < NS) rank = j + (vn < v ? 1 : 0) + (vf < v ? 1 : 0) + count_less(Er, NX, v, false);
+            else if (j == NS) rank = count_less(Sr, NS, v, true) + (vf < v ? 1 : 0) + count_less(Er, NX, v, false);
+            else if (j == NS + 1) rank = count_less(Sr, NS, v, true) + (vn <= v ? 1 : 0) + count_less(Er, NX, v, false);
+            else rank = (j - NS - 2) + count_less(Sr, NS, v, true) + (vn <= v ? 1 : 0) + (vf <= v ? 1 : 0);
+            st.zfinal[(size_t)k * NF + rank] = v;
         }
-        st.zfinal[(size_t)k * NF + rank] = v;
+    } else {
+        for (int j = lane; j < NF; j += 64) {  // rank sort (stable)
+            const float v = outv[j];
+            int rank = 0;
+            for (int q = 0; q < NF; ++q) {
+                const float w = outv[q];
+                rank += (w < v || (w == v && q < j)) ? 1 : 0;
+            }
+            st.zfinal[(size_t)k * NF + rank] = v;
+        }
     }
     if (lane == 0) {
         st.ray_active[k] = 0;
