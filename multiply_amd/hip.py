@@ -274,7 +274,11 @@ def implicit_grad_plans(net):
     (rows = that layer's inputs, K = its outputs in K-slot order, outputs multiplied by the stored sigmoid of the layer
     below), then the input-fed part of layer 0 transposed.  The skip layer's transpose also carries the 39 rows of the
     re-injected encoding (captured as gradient rows, capture id 2); layer 0's rows are captured with id 1."""
-    assert net.d_in == 3 and net.multires == 6 and list(net.skip_in) == [4] and net.num_layers - 1 == 9
+    if not (net.d_in == 3 and net.multires == 6 and list(net.skip_in) == [4] and net.num_layers - 1 == 9):
+        # the shipped configs' foreground network (confs/model/*.yaml: dims 8 x 256, skip_in [4], multires 6); other depths /
+        # skip positions still render through the forward-mode kernel
+        raise NotImplementedError("reverse-mode shading is specialised for the 9-layer, skip-at-4, multires-6 ImplicitNet of the "
+                                  "shipped configs; set model.shade_mode = 'forward' (MP_SHADE_MODE=forward) for other shapes")
     E, K = net.embed_dim, SOFTPLUS_K
     lins = list(net.layers())
     r2 = 1.0 / math.sqrt(2.0)
@@ -536,7 +540,9 @@ def background(bg_imp, bg_ren, dirs, cam, z_bg, frame_code, radius=3.0):
     pkr = packed(bg_ren, "color", 3)
     pkr.refresh(code)
     R = dirs.shape[0]
-    assert z_bg.shape[-1] == 32, "the background kernel is specialised for 32 inverse-sphere samples"
+    if z_bg.shape[-1] != 32:
+        raise NotImplementedError("the fused background kernel is specialised for the 32 inverse-sphere samples of the shipped "
+                                  f"configs (N_samples_inverse_sphere), got {z_bg.shape[-1]}")
     out = torch.empty(R, 3, dtype=torch.float32, device=dirs.device)
     check(lib().mp_background(C.byref(pki.net), ptr(pki.wpack), ptr(pki.bias), C.byref(pkr.net), ptr(pkr.wpack),
                               ptr(pkr.bias), ptr(dirs), ptr(cam), ptr(z_bg), int(z_bg.dim() == 2), R,
