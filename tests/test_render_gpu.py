@@ -150,6 +150,39 @@ def test_forward_eval_four_persons_256_samples():
     assert TOL.within(report("4p normal_values", got["normal_values"], want["normal_values"]), TOL.EVAL["normal_values"])
 
 
+def test_forward_eval_eight_persons_is_the_compositing_limit():
+    """The P-way depth merge of the compositing kernels is written for up to MAX_P = 8 persons (csrc/composite.hip): the limit
+    itself against the oracle, and a ninth person refused with an error instead of a wrong image."""
+    import warnings
+    warnings.filterwarnings("ignore")
+    from multiply_amd.config import load_config
+    from multiply_amd.multiply import Multiply
+    from multiply_amd.synthetic import make_scene, make_smpl_tables
+    tables = make_smpl_tables(0)
+
+    def scene(P):
+        sc = make_scene(P, seed=2, H=8, W=10)
+        torch.manual_seed(0)
+        model = Multiply(load_config(), sc["smpl_params"][0, :, 76:], smpl_tables=tables).eval()
+        sp = t32(sc["smpl_params"])
+        inp = dict(uv=t32(sc["uv"]), intrinsics=t32(sc["intrinsics"]), pose=t32(sc["pose"]), smpl_params=sp,
+                   smpl_pose=sp[:, :, 4:76], smpl_shape=sp[:, :, 76:], smpl_trans=sp[:, :, 1:4], idx=torch.tensor([2]))
+        return sc, model, inp
+    sc, model, inp = scene(8)
+    got = model({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inp.items()})
+    torch.cuda.synchronize()
+    hit = [model._last["per"][p]["hit_index"][:n].long().cpu() for p, n in zip(range(8), model.last_stats["n_hit"])]
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    want = O.MultiplyOracle(sd, tables, sc["smpl_params"][0, :, 76:]).forward_eval(inp, hit)
+    print("[info] 8 persons, hit rays", model.last_stats["n_hit"])
+    assert got["acc_person_list"].shape == (80, 8)
+    for k in ("rgb_values", "acc_map", "acc_person_list", "normal_values"):
+        assert TOL.within(report(f"8p {k}", got[k], want[k]), TOL.EVAL[k]), k
+    _, model9, inp9 = scene(9)
+    with pytest.raises(RuntimeError, match="mp_composite"):
+        model9({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inp9.items()})
+
+
 def _gpu(inp):
     return {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inp.items()}
 
