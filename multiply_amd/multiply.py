@@ -329,6 +329,46 @@ class Multiply(nn.Module):
         pp["_sampler_keep"] = (zs, sdfs, nz, znew, sdfnew, betar, active, gflag, any_active, xc_new, work, draws)
         return zfinal, iters, wcount
 
+    def sample_rays(self, ray_dirs, cam_loc, cond, smpl_tfs, smpl_verts, person_id):
+        """The sampler on explicit rays, outside forward(): what ErrorBoundSampler.get_z_vals(ray_dirs, cam_loc, model, cond,
+        smpl_tfs, eval_mode, smpl_verts, person_id) does in the reference (ray_sampler.py:66-220) for ONE person, eval mode:
+        every ray is sampled (no box cull), the convergence vote spans the call.  ray_dirs (R,3) unit vectors, cam_loc (3,)
+        or (R,3) with equal rows, cond the pose conditioning (69,) / {'smpl': (1,69)}, smpl_tfs (1,24,4,4), smpl_verts
+        (1,6890,3) posed vertices.  -> z_vals (R, N_samples + N_samples_extra + 2) sorted depths."""
+        L = hip.lib()
+        st = hip.stream()
+        dev = self.density.beta.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        dirs = ray_dirs.detach().to(dev).float().reshape(-1, 3).contiguous()
+        R = dirs.shape[0]
+        cam = cam_loc.detach().to(dev).float().reshape(-1, 3)[0].contiguous()
+        pose = torch.eye(4, **f32)
+        pose[:3, 3] = cam
+        # far end: the ray / bounding-sphere intersection (rend_util.get_sphere_intersections, rend_util.py:131-147)
+        od = (dirs * cam).sum(-1)
+        far = (-od + torch.sqrt((od * od - (cam @ cam - self.sdf_bounding_sphere ** 2)).clamp_min(0.0))).contiguous()
+        verts = smpl_verts.detach().to(dev).float().reshape(-1, 3).contiguous()
+        tfs = smpl_tfs.detach().to(dev).float().reshape(24, 16).contiguous()
+        d = self.deformer_list[person_id]
+        vsorted = torch.empty(hip.KNN_NC * hip.KNN_CLUSTER, 4, **f32)
+        cbound = torch.empty(hip.KNN_NC, 4, **f32)
+        hip.check(L.mp_knn_build(hip.ptr(verts), hip.ptr(d.knn_perm), hip.ptr(vsorted), hip.ptr(cbound), st), "mp_knn_build")
+        btab = torch.empty(verts.shape[0], 12, **f32)
+        hip.check(L.mp_blend_table(hip.ptr(self.smpl_server_list[person_id].tables.lbs_weights), hip.ptr(tfs), verts.shape[0],
+                                   hip.ptr(btab), st), "mp_blend_table")
+        if isinstance(cond, dict):
+            cond = cond["smpl"]
+        cvec = cond.detach().to(dev).float().reshape(-1).contiguous()
+        beta = (self.density.beta.detach().abs() + self.density.beta_min).reshape(1).float().contiguous()
+        per = {person_id: dict(verts=verts, tfs=tfs, btab=btab, vsorted=vsorted, cbound=cbound,
+                               hit_index=torch.arange(R, **i32), count=torch.full((1,), R, **i32), cond=cvec)}
+        cx = dict(dev=dev, R=R, pose=pose.reshape(16).contiguous(), dirs=dirs, far=far, per=per, persons=[person_id], n_hit=[R],
+                  group=R, beta=beta)
+        with torch.no_grad():
+            zfinal, _, _ = self._sample_person(cx, 0, person_id)
+        return zfinal
+
     def _forward_eval(self, input, id, canonical_pose, composite=True):
         """composite=False: stop after the per-person sampling + shading and return the per-person sample arrays (in hit
         order) -- the person-sharded multi-GPU mode composites them elsewhere (parallel.render_person_sharded)."""

@@ -1,6 +1,8 @@
 """Sampler configuration objects with the reference's names and constructor arguments
 (code/lib/model/ray_sampler.py:14-64).  The algorithm itself (VolSDF Algorithm 1) runs in csrc/sampler.hip, driven by
-Multiply.forward; these classes only carry the hyper-parameters."""
+Multiply.forward; these classes carry the hyper-parameters, and ErrorBoundSampler.get_z_vals keeps the reference's public
+entry point for callers outside forward()."""
+import torch
 
 
 class RaySampler:
@@ -38,3 +40,18 @@ class ErrorBoundSampler(RaySampler):
             self.inverse_sphere_sampler = UniformSampler(1.0, 0.0, 32, False, far=1.0)
         if not inverse_sphere_bg:
             raise NotImplementedError("the shipped configs always render with the inverted-sphere background")
+
+    def get_z_vals(self, ray_dirs, cam_loc, model, cond, smpl_tfs, eval_mode, smpl_verts, person_id):
+        """ray_sampler.py:66-220 for explicit rays (eval mode): -> ((z_vals (R, N + N_extra + 2), z_vals_inverse_sphere
+        (R, 32)), z_samples_eik (R, 1)) like the reference.  The depths come from the same device kernels Multiply.forward
+        drives (Multiply.sample_rays); training-mode sampling consumes torch random draws in the reference's order and lives in
+        multiply_amd.train (forward_train / make_draws)."""
+        if model.training or not eval_mode:
+            raise NotImplementedError("training-mode draws are taken inside multiply_amd.train.forward_train; call the model in "
+                                      "eval mode for stand-alone sampling")
+        z_vals = model.sample_rays(ray_dirs, cam_loc, cond, smpl_tfs, smpl_verts, person_id)
+        idx = torch.randint(z_vals.shape[-1], (z_vals.shape[0],), device=z_vals.device)          # ray_sampler.py:212-213
+        z_eik = torch.gather(z_vals, 1, idx.unsqueeze(-1))
+        t = torch.linspace(0.0, 1.0, steps=self.inverse_sphere_sampler.N_samples, device=z_vals.device)   # near 0, far 1
+        z_bg = t[None].expand(z_vals.shape[0], -1) * (1.0 / self.scene_bounding_sphere)
+        return (z_vals, z_bg), z_eik

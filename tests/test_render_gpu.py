@@ -355,3 +355,32 @@ def test_single_person_model_betas_1d():
     for k in ("rgb_values", "acc_map", "normal_values"):
         assert TOL.within(report("single person " + k, got[k], want[k]), TOL.EVAL[k]), k
     assert torch.equal(got["acc_map"], got["acc_person_list"][:, 0])
+
+
+def test_error_bound_sampler_public_entry_point():
+    """ErrorBoundSampler.get_z_vals (ray_sampler.py:66) outside forward(): same depths as the forward pass draws for the same
+    rays when every ray is sampled and the vote spans the call; also against the oracle's sampler."""
+    model, oracle, inp = build(H=12, W=12)
+    R = inp["uv"].shape[1]
+    hit = [torch.arange(R), torch.arange(R)]
+    gin = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inp.items()}
+    model({**gin, "hit_index": hit})
+    torch.cuda.synchronize()
+    want = oracle.forward_eval(inp, hit)
+    last = model._last
+    for p in range(2):
+        pp = last["per"][p]
+        cam = gin["pose"][0, :3, 3]
+        (z, z_bg), z_eik = model.ray_sampler.get_z_vals(last["dirs"], cam[None].expand(R, 3), model, {"smpl": pp["cond"][None]},
+                                                         pp["tfs"][None], True, pp["verts"][None], p)
+        torch.cuda.synchronize()
+        assert z.shape == pp["zfinal"].shape and z_bg.shape == (R, 32) and z_eik.shape == (R, 1)
+        d = float((z - pp["zfinal"]).abs().max())
+        print(f"[parity] get_z_vals person {p}: max |stand-alone - forward| {d:.2e}")
+        assert d < 1e-5                                                     # far end computed in torch vs in mp_ray_setup
+        ref = torch.cat([want["z_vals"][p], want["z_max"][p][:, None]], 1)
+        assert TOL.within(report(f"get_z_vals person {p} vs oracle", z, ref), TOL.Z_VALS)
+        assert bool((z_eik >= z.min(1, keepdim=True).values).all()) and float(z_bg[0, -1]) == pytest.approx(1 / 3.0)
+    model.train()
+    with pytest.raises(NotImplementedError):
+        model.ray_sampler.get_z_vals(last["dirs"], cam[None], model, None, None, False, None, 0)
