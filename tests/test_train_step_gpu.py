@@ -83,8 +83,10 @@ def test_training_forward_loss_and_all_parameter_gradients():
             v.requires_grad_(True)
     z_given = [graph.fg[p]["zfinal"].cpu() for p in range(2)]
     want = oracle.forward_train(inp, hit, z_given, _cpu(graph.draws))
+    # multiply.py:242-243, from the INPUTS (not from the device's output): mean((smpl_pose_last - smpl_pose)^2)
+    tl = torch.mean(torch.square((inp["smpl_pose"] + 0.01) - inp["smpl_pose"]))
     want.update(fg_rgb_values_each_person_list=[], index_in_surface=None, epoch=301,
-                temporal_loss=out["temporal_loss"].detach().cpu(), smpl_surface_loss=torch.zeros(1),
+                temporal_loss=tl.reshape(()), smpl_surface_loss=torch.zeros(1),
                 zero_pose_loss=torch.zeros(1), sam_mask=gin["sam_mask"].squeeze().cpu())
     lw = loss_fn(want, gt)
     names = [k for k, v in oracle.sd.items() if v.requires_grad]
