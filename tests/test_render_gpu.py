@@ -384,3 +384,49 @@ def test_error_bound_sampler_public_entry_point():
     model.train()
     with pytest.raises(NotImplementedError):
         model.ray_sampler.get_z_vals(last["dirs"], cam[None], model, None, None, False, None, 0)
+
+
+def test_full_size_frame_properties():
+    """BASELINE.json's full size (512x512 rays, 2 persons, N_samples 128), where the oracle cannot follow in test time:
+    size-independent properties of the outputs -- sorted depths, per-person opacities summing to the total, compositing
+    identities between rgb / fg_rgb / the background, empty rays, and a render of a sub-block of the frame's convergence
+    groups reproducing the same pixels bit for bit (sharding invariance at full size)."""
+    import bench
+    model, inp, _, _ = bench.build_model(128, seed=0, H=512, W=512, tile=8)
+    model.convergence_group = 512
+    gin = _gpu(inp)
+    out = model(gin)
+    torch.cuda.synchronize()
+    R = 512 * 512
+    rgb, fg, acc, accp, nrm = (out[k] for k in ("rgb_values", "fg_rgb_values", "acc_map", "acc_person_list", "normal_values"))
+    assert rgb.shape == (R, 3) and accp.shape == (R, 2)
+    fin = torch.isfinite(rgb).all(dim=1)
+    assert int((~fin).sum()) <= 1                                   # at most the one ray through the sphere centre (multiply.py:712-713)
+    assert float((acc - accp.sum(1)).abs().max()) < 2e-6
+    assert float(acc.min()) >= 0.0 and float(acc.max()) <= 1.0 + 1e-5
+    last = model._last
+    T, bg = last["bg_T"], last["bg_rgb"]
+    # rgb = fg_part + T_bg * bg  and  fg_rgb = fg_part + T_bg * 1   (multiply.py:544-545, :590)
+    assert float(((rgb - fg) - T[:, None] * (bg - 1.0))[fin].abs().max()) < 2e-6
+    nobody = torch.ones(R, dtype=torch.bool, device=rgb.device)
+    n_hit_full = list(model.last_stats["n_hit"])
+    for p, n in zip(last["persons"], n_hit_full):
+        pp = last["per"][p]
+        z = pp["zfinal"][:n]
+        assert bool((z[:, 1:] >= z[:, :-1]).all()) and z.shape[1] == 162          # sorted depths
+        nobody[pp["hit_index"][:n].long()] = False
+    # rays that meet nobody's box carry the background only; so do the rays of a person whose samples are all outliers
+    empty = nobody | (acc == 0.0)
+    assert int(empty.sum()) > 1000
+    assert float((rgb - bg)[empty & fin].abs().max()) == 0.0 and float(nrm[empty].abs().max()) == 0.0
+    assert float((fg - 1.0)[empty].abs().max()) == 0.0
+    # the same pixels from a quarter of the frame's convergence groups rendered on their own
+    from multiply_amd.parallel import shard_input_interleaved
+    share, ids = shard_input_interleaved(inp, 1, 4, 512, 8)
+    part = model(_gpu(share))
+    torch.cuda.synchronize()
+    ids = ids.cuda()
+    for k in ("rgb_values", "acc_map", "normal_values"):
+        assert torch.equal(torch.nan_to_num(part[k]), torch.nan_to_num(out[k][ids])), k
+    print(f"[parity] full frame: rays through the persons' boxes {n_hit_full}, {int(nobody.sum())} rays outside every box, "
+          f"{int(empty.sum())} with zero opacity, shard of 4 bit-identical")
