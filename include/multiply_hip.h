@@ -135,6 +135,14 @@ int mp_ray_setup(const float* uv, const float* intrinsics, const float* pose, in
  * first ray as fallback (multiply.py:262-263 applied per chunk). scan_tmp: >= R+1 ints. */
 int mp_ray_cull(const float* dirs, const float* pose, const float* obb, int n_rays, int group_size, int* hit_index,
                 int* hit_count, int* inv_index, int* scan_tmp, void* stream);
+/* The same, refined for eval-mode rendering without changing a pixel: a ray that passes the box but stays further than the
+ * outlier radius 0.1 (deformer.py:49) from every vertex on [near, far[r]] carries only sdf = 4 samples (multiply.py:142-143);
+ * when 1 - exp(-sigma(4) (far - near)) is exactly 0 in fp32 its pixel is the background's, exactly like a ray outside the
+ * box, and it is dropped here.  cbound [108][4] = the bounding spheres of the posed vertex clusters (mp_knn_build), far [R]
+ * from mp_ray_setup, beta = device scalar (density), near_ = the sampler's near bound. */
+int mp_ray_cull_near(const float* dirs, const float* pose, const float* obb, const float* cbound, const float* far,
+                     const float* beta, float near_, int n_rays, int group_size, int* hit_index, int* hit_count,
+                     int* inv_index, int* scan_tmp, void* stream);
 /* Explicit hit set (parity tests): fills hit_count / inv_index from a given ascending hit_index [n_hit]. */
 int mp_ray_hits_from_index(const int* hit_index, int n_hit, int n_rays, int* hit_count, int* inv_index, void* stream);
 

@@ -718,6 +718,38 @@ __global__ void k_ray_box(const float* __restrict__ dirs, const float* __restric
     flag[i] = (hit && tmax >= fmaxf(tmin, 0.0f)) ? 1 : 0;
 }
 
+// Eval-mode refinement of the box test, exact by construction: a ray that stays further than the outlier radius (0.1,
+// deformer.py:49) from every vertex between `near` and its far end has only outlier samples, i.e. sdf = 4 on all of them
+// (multiply.py:142-143); if moreover alpha = 1 - exp(-sigma(4) (far - near)) is exactly 0 in fp32 (it is for every beta
+// below ~0.25: sigma(4) = e^(-4/beta) / (2 beta)) the ray's weights are exactly 0, its transmittance exactly 1, and its
+// pixel is the background's -- bit for bit what a ray outside the box gets, and its beta converges in the first sampler
+// iteration without touching its group's vote.  Such rays are dropped before they reach the sampler.  The test is
+// conservative: the vertex set is covered by the cluster spheres (cbound), inflated by the radius plus a margin for the
+// fp32 distance evaluation of the search kernels.
+__global__ void k_ray_near_body(const float* __restrict__ dirs, const float* __restrict__ P, const float* __restrict__ cbound,
+                                const float* __restrict__ far, const float* __restrict__ beta_p, float near_, int n,
+                                int* __restrict__ flag) {
+    __shared__ float4 cb[NC];
+    for (int c = threadIdx.x; c < NC; c += blockDim.x) cb[c] = ((const float4*)cbound)[c];
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    const float tf = far[i];
+    if (mp::alpha_of(4.0f, *beta_p, tf - near_) != 0.0f) return;   // outliers would still weigh in: keep the ray
+    const float ox = P[3], oy = P[7], oz = P[11];
+    const float dx = dirs[3 * i], dy = dirs[3 * i + 1], dz = dirs[3 * i + 2];
+    bool near_body = false;
+    for (int c = 0; c < NC && !near_body; ++c) {
+        const float4 b = cb[c];
+        const float ex = b.x - ox, ey = b.y - oy, ez = b.z - oz;
+        const float t = fminf(fmaxf(ex * dx + ey * dy + ez * dz, near_), tf);   // closest approach inside [near, far]
+        const float qx = ex - t * dx, qy = ey - t * dy, qz = ez - t * dz;
+        const float reach = b.w + 0.1005f;
+        near_body = qx * qx + qy * qy + qz * qz <= reach * reach;
+    }
+    if (!near_body) flag[i] = 0;
+}
+
 // a convergence group without any hit gets its first ray (multiply.py:262-263 applied per group)
 __global__ __launch_bounds__(256) void k_group_fallback(int* __restrict__ flag, int n, int group_size) {
     __shared__ int any;
@@ -828,8 +860,9 @@ extern "C" int mp_ray_setup(const float* uv, const float* intrinsics, const floa
     return (int)hipGetLastError();
 }
 
-extern "C" int mp_ray_cull(const float* dirs, const float* pose, const float* obb, int n_rays, int group_size,
-                           int* hit_index, int* hit_count, int* inv_index, int* scan_tmp, void* stream) {
+static int ray_cull(const float* dirs, const float* pose, const float* obb, const float* cbound, const float* far,
+                    const float* beta, float near_, int n_rays, int group_size, int* hit_index, int* hit_count, int* inv_index,
+                    int* scan_tmp, void* stream) {
     if (n_rays <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     int* flag = scan_tmp;                 // [n_rays]
@@ -837,12 +870,29 @@ extern "C" int mp_ray_cull(const float* dirs, const float* pose, const float* ob
     const int nb = (n_rays + SCAN_BLOCK - 1) / SCAN_BLOCK;
     if (group_size <= 0) group_size = n_rays;
     hipLaunchKernelGGL(k_ray_box, dim3((n_rays + 255) / 256), dim3(256), 0, st, dirs, pose, obb, n_rays, flag);
+    if (cbound)
+        hipLaunchKernelGGL(k_ray_near_body, dim3((n_rays + 255) / 256), dim3(256), 0, st, dirs, pose, cbound, far, beta, near_,
+                           n_rays, flag);
     hipLaunchKernelGGL(k_group_fallback, dim3((n_rays + group_size - 1) / group_size), dim3(256), 0, st, flag, n_rays,
                        group_size);
     hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(SCAN_BLOCK), 0, st, flag, n_rays, bsum);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(64), 0, st, bsum, nb, hit_count);
     hipLaunchKernelGGL(k_scan_scatter, dim3(nb), dim3(SCAN_BLOCK), 0, st, flag, n_rays, bsum, hit_index, inv_index);
     return (int)hipGetLastError();
+}
+
+extern "C" int mp_ray_cull(const float* dirs, const float* pose, const float* obb, int n_rays, int group_size,
+                           int* hit_index, int* hit_count, int* inv_index, int* scan_tmp, void* stream) {
+    return ray_cull(dirs, pose, obb, nullptr, nullptr, nullptr, 0.0f, n_rays, group_size, hit_index, hit_count, inv_index,
+                    scan_tmp, stream);
+}
+
+extern "C" int mp_ray_cull_near(const float* dirs, const float* pose, const float* obb, const float* cbound, const float* far,
+                                const float* beta, float near_, int n_rays, int group_size, int* hit_index, int* hit_count,
+                                int* inv_index, int* scan_tmp, void* stream) {
+    if (!cbound || !far || !beta) return -1;
+    return ray_cull(dirs, pose, obb, cbound, far, beta, near_, n_rays, group_size, hit_index, hit_count, inv_index, scan_tmp,
+                    stream);
 }
 
 extern "C" int mp_ray_hits_from_index(const int* hit_index, int n_hit, int n_rays, int* hit_count, int* inv_index,

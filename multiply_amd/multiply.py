@@ -115,6 +115,8 @@ class Multiply(nn.Module):
         # "hull" = the minimum-volume box trimesh's bounding_box_oriented computes, by the published algorithm on the host
         # (multiply_amd/obb.py; one device sync + ~10-100 ms of CPU work per person and call, like the reference)
         self.obb_mode = os.environ.get("MP_OBB_MODE", "pca")
+        # eval-mode refinement of the box cull that provably leaves every pixel unchanged (mp_ray_cull_near); 0 = box only
+        self.near_cull = os.environ.get("MP_NEAR_CULL", "1") != "0"
         self.last_stats = {}
         self.profile = False
         self.phase_events = {}
@@ -255,9 +257,17 @@ class Multiply(nn.Module):
                 else:
                     obb = torch.empty(16, **f32)
                     hip.check(L.mp_obb(hip.ptr(verts), C.c_float(self.obb_inflate), hip.ptr(obb), st), "mp_obb")
-                hip.check(L.mp_ray_cull(hip.ptr(dirs), hip.ptr(pose), hip.ptr(obb), R, group, hip.ptr(hit_index),
-                                        hip.ptr(counts[n:n + 1]), hip.ptr(inv_index), hip.ptr(scan_tmp), st),
-                          "mp_ray_cull")
+                if self.near_cull and not self.training:
+                    # eval: rays of the box that never come within the outlier radius of the body are background, bit for bit
+                    # (csrc/geom.hip k_ray_near_body); they are dropped before the sampler
+                    hip.check(L.mp_ray_cull_near(hip.ptr(dirs), hip.ptr(pose), hip.ptr(obb), hip.ptr(cbound), hip.ptr(far),
+                                                 hip.ptr(beta), C.c_float(rs.near), R, group, hip.ptr(hit_index),
+                                                 hip.ptr(counts[n:n + 1]), hip.ptr(inv_index), hip.ptr(scan_tmp), st),
+                              "mp_ray_cull_near")
+                else:
+                    hip.check(L.mp_ray_cull(hip.ptr(dirs), hip.ptr(pose), hip.ptr(obb), R, group, hip.ptr(hit_index),
+                                            hip.ptr(counts[n:n + 1]), hip.ptr(inv_index), hip.ptr(scan_tmp), st),
+                              "mp_ray_cull")
             cond = (smpl_pose[0, p, 3:] / np.pi).contiguous()          # multiply.py:270
             per[p] = dict(verts=verts, tfs=tfs, btab=btab, vsorted=vsorted, cbound=cbound, hit_index=hit_index, obb=obb,
                           inv_index=inv_index, count=counts[n:n + 1], cond=cond, prm=prm,

@@ -116,6 +116,20 @@ def test_forward_eval_box_cull_is_conservative():
     assert all(c < a for c, a in zip(n_cull, n_all))
     for k in ["rgb_values", "acc_map", "normal_values", "acc_person_list"]:
         assert report("cull vs all: " + k, cull[k], full[k].cpu())[0] < 1e-5
+    # the eval-mode refinement (rays of the box that never come within the outlier radius of the body, mp_ray_cull_near)
+    # against the plain box cull: fewer rays sampled, opacities and normals identical, pixels within one fp32 ulp (which
+    # sample is the LAST of a ray's merged list -- the reference's exclusive background transmittance, multiply.py:457-463 --
+    # changes when another person's all-outlier samples disappear from the list)
+    assert model.near_cull
+    model.near_cull = False
+    box = model(gin)
+    n_box = model.last_stats["n_hit"]
+    model.near_cull = True
+    print("[info] hit rays box / box + near-body", n_box, n_cull)
+    assert all(c <= b for c, b in zip(n_cull, n_box)) and sum(n_cull) < sum(n_box)
+    for k in ["acc_map", "normal_values", "acc_person_list"]:
+        assert torch.equal(torch.nan_to_num(cull[k]), torch.nan_to_num(box[k])), k
+    assert report("near-body cull vs box cull: rgb_values", cull["rgb_values"], box["rgb_values"].cpu())[0] <= 1.2e-7
 
 
 def test_forward_eval_four_persons_256_samples():
@@ -420,6 +434,15 @@ def test_full_size_frame_properties():
     assert int(empty.sum()) > 1000
     assert float((rgb - bg)[empty & fin].abs().max()) == 0.0 and float(nrm[empty].abs().max()) == 0.0
     assert float((fg - 1.0)[empty].abs().max()) == 0.0
+    # the plain box cull (no near-body refinement) renders the same frame: identical opacities / normals, pixels within one ulp
+    model.near_cull = False
+    box = model(gin)
+    torch.cuda.synchronize()
+    n_box = list(model.last_stats["n_hit"])
+    model.near_cull = True
+    assert torch.equal(torch.nan_to_num(box["acc_map"]), torch.nan_to_num(acc)) and torch.equal(torch.nan_to_num(box["normal_values"]), torch.nan_to_num(nrm))
+    assert float((box["rgb_values"] - rgb)[fin].abs().max()) <= 1.2e-7
+    print(f"[parity] full frame: rays sampled with the box cull {n_box}, with the near-body refinement {n_hit_full}")
     # the same pixels from a quarter of the frame's convergence groups rendered on their own
     from multiply_amd.parallel import shard_input_interleaved
     share, ids = shard_input_interleaved(inp, 1, 4, 512, 8)
