@@ -101,8 +101,12 @@ def cpu_baseline(model, inp, tables, sc, n_samples, n_rays=2048):
     sel = sel[torch.argsort(uvy[sel] * W + uvx[sel])]
     sub = dict(inp)
     sub["uv"] = inp["uv"][:, sel]
+    # the CPU path does the REFERENCE's work: every ray that meets a person's box is sampled (multiply.py:256-266), without
+    # the eval-mode near-body refinement of the device path (which leaves the pixels unchanged)
+    near_cull, model.near_cull = model.near_cull, False
     got = model(to_dev(sub))
     torch.cuda.synchronize()
+    model.near_cull = near_cull
     hit = [model._last["per"][p]["hit_index"][:n].long().cpu() for p, n in zip(model._last["persons"], model.last_stats["n_hit"])]
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     cfg = O.SamplerCfg(N_samples=n_samples, N_samples_eval=max(128, n_samples))
