@@ -93,3 +93,38 @@ def test_marching_cubes_table_closes_the_surface():
     assert closed and V - E + Fc == 2
     area = 0.5 * np.linalg.norm(np.cross(tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 0]), axis=1).sum()
     assert abs(area / (4 * np.pi * 4.3 ** 2) - 1) < 0.03
+
+
+def test_extracted_mesh_object_on_the_host():
+    """the trimesh-like surface of generate_mesh's return value (lib/utils/mesh.py:117-131 callers), with host tensors: two
+    tetrahedra in one vertex / face list -> components, areas, watertightness, PLY round trip"""
+    import torch
+    from multiply_amd.mesh import ExtractedMesh
+    tet = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], dtype=np.float32)
+    tf = np.array([[0, 2, 1], [0, 1, 3], [0, 3, 2], [1, 2, 3]])
+    v = np.concatenate([tet, 2.0 * tet + 5.0])
+    f = np.concatenate([tf, tf + 4])
+    m = ExtractedMesh(torch.tensor(v), torch.tensor(f), resolution=7)
+    assert m.vertices.dtype == np.float32 and m.faces.dtype == np.int64 and m.resolution == 7 and m["faces"].shape == (8, 3)
+    assert m.is_watertight
+    a1 = 1.5 + np.sqrt(3) / 2
+    assert abs(m.area - 5 * a1) < 1e-5
+    parts = m.split(only_watertight=False)
+    assert len(parts) == 2 and sorted(p.vertices.shape[0] for p in parts) == [4, 4]
+    big = max(parts, key=lambda p: p.area)
+    assert abs(big.area - 4 * a1) < 1e-5 and big.faces.max() == 3 and np.allclose(big.vertices.min(0), 5.0)
+    open_mesh = ExtractedMesh(torch.tensor(v), torch.tensor(f[:-1]))
+    assert not open_mesh.is_watertight and len(open_mesh.split(only_watertight=True)) == 1
+    import os, tempfile
+    path = m.export(os.path.join(tempfile.mkdtemp(), "two.ply"))
+    raw = open(path, "rb").read()
+    head, body = raw.split(b"end_header\n")
+    assert b"element vertex 8" in head and b"element face 8" in head
+    vv = np.frombuffer(body[:8 * 12], dtype="<f4").reshape(8, 3)
+    ff = np.frombuffer(body[8 * 12:], dtype=[("n", "u1"), ("i", "<i4", (3,))])
+    assert np.array_equal(vv, v) and np.array_equal(ff["i"], f) and (ff["n"] == 3).all()
+    try:
+        m.nonexistent
+        assert False
+    except AttributeError:
+        pass
