@@ -339,9 +339,12 @@ def main():
         gin = to_dev(share)
         image = {}
 
-        def assemble(out):                   # ONE all_gather per output the caller keeps (multiply_model.py:1045-1069)
-            for k in ("rgb_values", "normal_values", "fg_rgb_values"):
-                image[k] = gather_rays_interleaved(out[k], R, world, GROUP, GPR)
+        KEEP = ("rgb_values", "normal_values", "fg_rgb_values")
+
+        def assemble(out):                   # ONE all_gather of the outputs the caller keeps (multiply_model.py:1045-1069)
+            full = gather_rays_interleaved(torch.cat([out[k] for k in KEEP], dim=1), R, world, GROUP, GPR)
+            for k, part in zip(KEEP, full.split([out[k].shape[1] for k in KEEP], dim=1)):
+                image[k] = part
     else:
         gin, assemble = to_dev(inp), None
 

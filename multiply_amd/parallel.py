@@ -21,6 +21,32 @@ def shard_bounds(n_rays, world, group):
     return bounds
 
 
+_PLANS = {}
+
+
+def _interleaved_plan(n_rays, world, group, groups_per_row, device="cpu"):
+    """Cached per (frame size, world, group, hint, device): the ascending ray ids of every rank, and for the gather the map
+    ray -> row of the concatenated padded per-rank buffers.  Built once -- the frame loop calls this every frame, and a
+    quarter-million-ray index computation per call costs more host time than an eighth of a frame costs GPU time."""
+    key = (int(n_rays), int(world), int(group), int(groups_per_row or 0), str(device))
+    plan = _PLANS.get(key)
+    if plan is None:
+        ids = torch.arange(n_rays)
+        gid = ids // group
+        c = world if not groups_per_row else int(groups_per_row)
+        owner = (gid % c + gid // c) % world
+        order = torch.argsort(owner, stable=True)                      # ranks one after the other, ray ids ascending inside
+        counts = torch.bincount(owner, minlength=world).tolist()
+        shards = list(torch.split(order, counts))
+        width = max(counts) if counts else 0
+        row_of_ray = torch.empty(n_rays, dtype=torch.long)
+        for r, sh in enumerate(shards):
+            row_of_ray[sh] = r * width + torch.arange(len(sh))
+        plan = dict(shards=[sh.to(device) for sh in shards], width=width, row_of_ray=row_of_ray.to(device))
+        _PLANS[key] = plan
+    return plan
+
+
 def shard_indices_interleaved(n_rays, world, group, groups_per_row=None):
     """Load-balanced sharding of ONE frame (body rays cost ~30x background-only rays, so contiguous slices
     of the image are badly balanced): the frame's convergence groups (`group` consecutive rays -- with the tile-ordered
@@ -32,12 +58,8 @@ def shard_indices_interleaved(n_rays, world, group, groups_per_row=None):
     lattice when C == world.  Measured on the 512x512 two-person frame (tools/shard_latency.py): per-rank times within
     5 % of each other at 2, 4 and 8 ranks.
     Cutting at whole groups keeps the sampler's vote (ray_sampler.py:137) per group, so every pixel equals the
-    single-process render with convergence_group = group.  Returns one ascending long tensor of ray ids per rank."""
-    ids = torch.arange(n_rays)
-    gid = ids // group
-    c = world if not groups_per_row else int(groups_per_row)
-    owner = (gid % c + gid // c) % world
-    return [ids[owner == r] for r in range(world)]
+    single-process render with convergence_group = group.  Returns one ascending long tensor of ray ids per rank (cached)."""
+    return _interleaved_plan(n_rays, world, group, groups_per_row)["shards"]
 
 
 def shard_input_interleaved(inp, rank, world, group, groups_per_row=None):
@@ -50,17 +72,18 @@ def shard_input_interleaved(inp, rank, world, group, groups_per_row=None):
 
 def gather_rays_interleaved(local, n_rays, world, group, groups_per_row=None):
     """all_gather of per-ray outputs of an interleaved sharding into (n_rays, ...) in the frame's ray order (every rank gets
-    the whole image: one collective of (n_rays / world) rows per rank)."""
-    shards = shard_indices_interleaved(n_rays, world, group, groups_per_row)
-    width = max(len(s) for s in shards)
-    pad = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[:local.shape[0]] = local
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad)
-    out = torch.empty((n_rays,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    for b, s in zip(bufs, shards):
-        out[s.to(local.device)] = b[:len(s)]
-    return out
+    the whole image): ONE collective of (n_rays / world) rows per rank -- concatenate the outputs to keep along the last
+    dimension before calling -- and one cached index to put the rows back in ray order."""
+    plan = _interleaved_plan(n_rays, world, group, groups_per_row, local.device)
+    width = plan["width"]
+    if local.shape[0] == width:
+        pad = local.contiguous()
+    else:
+        pad = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[:local.shape[0]] = local
+    flat = torch.empty((world * width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather(list(flat.split(width)), pad)
+    return flat[plan["row_of_ray"]]
 
 
 def shard_input(inp, rank, world, group):

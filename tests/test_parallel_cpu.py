@@ -170,3 +170,38 @@ def test_lattice_deal_partitions_the_frame_and_balances_a_body_shaped_cost_map()
     # without the hint the deal is skewed by the world size: still a partition into whole groups
     shards = parallel.shard_indices_interleaved(5000, 3, 64)
     assert torch.equal(torch.cat(shards).sort().values, torch.arange(5000))
+
+
+def _interleaved_worker(rank, world, port, n, group, gpr, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    inp = {"uv": torch.arange(n * 2, dtype=torch.float32).reshape(1, n, 2), "pose": torch.eye(4)[None]}
+    sub, ids = parallel.shard_input_interleaved(inp, rank, world, group, gpr)
+    assert sub["uv"].shape[1] == len(ids) and torch.equal(sub["uv"][0], inp["uv"][0][ids])
+    ok = True
+    for _ in range(2):                                               # second call: the cached plan
+        local = torch.cat([sub["uv"][0].sum(-1, keepdim=True) * 2.0, sub["uv"][0] + 1.0], dim=1)     # three "outputs" in one tensor
+        full = parallel.gather_rays_interleaved(local, n, world, group, gpr)
+        want = torch.cat([inp["uv"][0].sum(-1, keepdim=True) * 2.0, inp["uv"][0] + 1.0], dim=1)
+        ok = ok and torch.equal(full, want)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok))
+
+
+@pytest.mark.parametrize("n,group,gpr,world", [(4096, 512, 4, 2), (1300, 64, None, 3), (2048, 512, 1, 2)])
+def test_interleaved_shards_gather_back_in_ray_order(n, group, gpr, world):
+    """shard_input_interleaved + gather_rays_interleaved over gloo: one collective reassembles several outputs in the frame's
+    ray order, also when the ranks hold different numbers of rays (ragged last group, 3 ranks)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_interleaved_worker, args=(r, world, port, n, group, gpr, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
