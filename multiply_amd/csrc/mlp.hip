@@ -682,6 +682,10 @@ extern "C" int mp_mlp_shade_rev(const MpNet* net, const void* wpack, const float
     if (max_count <= 0) return 0;
     if (seg_points < 256 || seg_points % 256) return -1;
     if (!net_ok(net) || !net_ok(gnet)) return -1;
+    // the reverse sweep fetches its stored sigmoids one chunk ahead into alternating buffers (mlp_core.hpp run_layer_pp):
+    // every sigmoid-multiplied layer must be 8 chunks (256 rows) so that the alternation carries across layers
+    for (int l = 0; l < gnet->n_layers; ++l)
+        if (gnet->layer[l].act == ACT_SIGMUL && gnet->layer[l].n_chunk != KS_REG) return -1;
     hipStream_t st = (hipStream_t)stream;
     using L = Lds<2, PNB, PWAVES>;
     constexpr int TILE = 16 * PNB * PWAVES;

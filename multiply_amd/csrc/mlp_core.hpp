@@ -643,11 +643,32 @@ __device__ __forceinline__ void run_layer_pp(const NetDesc& net, const LayerDesc
             const int ring_next = ring_pos + 1 == RING_SLOTS ? 0 : ring_pos + 1;
             const char* slot = wring + ring_pos * chunk_bytes(KS_IN) + lane * 16;
             const char* slot_next = wring + ring_next * chunk_bytes(KS_IN) + lane * 16;
+            // Reverse sweep: the stored sigmoids are fetched ONE CHUNK AHEAD within a layer (chunk c + 1's fragment is
+            // requested at the head of chunk c and renamed into place behind V(c); a layer's first fragment is requested
+            // at its own head): an HBM read under this load takes longer than an M phase, and a fragment fetched at the
+            // head of its own chunk stalled every V phase; the wait behind M(c) is COUNTED -- vmcnt(2), everything but the
+            // two loads just issued.  [tools/stream_model.hip: 0.45 -> 0.55 of the MFMA peak for this stream.  Carrying
+            // the fragment across the LAYER loop as well costs hipcc 7.2 the register file: 256 VGPRs + 112 spilled, from
+            // 208 -- and scratch traffic counts in vmcnt.]
+            constexpr bool REV = HID == HID_SIGMUL && HIDDEN;
+#ifdef MP_EXP_NOAHEAD   // ablation: every fragment at the head of its own chunk, full drain behind M(c)
+            constexpr bool AHEAD = false;
+#else
+            constexpr bool AHEAD = REV;
+#endif
             u32x4 (&sg)[2] = sgb[0];
-            if constexpr (HID == HID_SIGMUL && HIDDEN) {   // this chunk's stored sigmoids: needed in V(c), a whole M phase away
+            u32x4 sgn[2];
+            if constexpr (REV) {
+                if (!AHEAD || c == 0) {
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
-                    sg[nb] = *(const u32x4*)(sig.base + (size_t)sig_layer * sig.layer_bytes + (c * 2 + nb) * 1024 + lane * 16);
+                    for (int nb = 0; nb < 2; ++nb)
+                        sg[nb] = *(const u32x4*)(sig.base + (size_t)sig_layer * sig.layer_bytes + (c * 2 + nb) * 1024 + lane * 16);
+                }
+                if (AHEAD && c + 1 < KS_REG) {
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+                        sgn[nb] = *(const u32x4*)(sig.base + (size_t)sig_layer * sig.layer_bytes + ((c + 1) * 2 + nb) * 1024 + lane * 16);
+                }
             }
             // ---- M(c): 4 accumulators (block mbl, column block nb), biased
             f32x4 acc[CHUNK_MB][2];
@@ -715,11 +736,16 @@ __device__ __forceinline__ void run_layer_pp(const NetDesc& net, const LayerDesc
             // The reverse sweep's sigmoid loads (issued before M(c)) are waited for HERE by both kinds of wave: hipcc
             // does not know the asm-issued DMA, so a wait it inserted in V(c) -- reached by the late waves right behind
             // their DMA issue -- would wait for the fresh DMA pieces as well (measured: +9 % on k_mlp_grad).
-            if constexpr (HID == HID_SIGMUL && HIDDEN) dma_wait_all();
+            // In flight, oldest first: [this chunk's fragment, fetched a chunk ago] [late waves: the DMA pieces issued behind
+            // the previous barrier] [the two loads just issued for the next chunk] -- the counted wait covers the first two.
+            if constexpr (REV) {
+                if (AHEAD && c + 1 < KS_REG) __builtin_amdgcn_s_waitcnt(0x0F72);   // vmcnt(2)
+                else dma_wait_all();
+            }
             if (late) {
                 // every DMA piece this wave issued (one whole M phase ago) has landed; every wave is done with chunk ci:
                 // its ring slot is free for chunk ci + 3
-                dma_wait_all();
+                if constexpr (!REV) dma_wait_all();
                 __syncthreads();
 #ifndef MP_EXP_NOLOAD
                 if (ci + 3 <= pp_last) pp_issue<KS_IN>(wpack, wring, ci + 3, ring_pos, cm, dl);   // (ci + 3) % 3 == ring_pos
@@ -742,6 +768,12 @@ __device__ __forceinline__ void run_layer_pp(const NetDesc& net, const LayerDesc
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (REV) {
+                if (AHEAD && c + 1 < KS_REG) {
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) sg[nb] = sgn[nb];
+                }
+            }
             if (!late) {
                 MP_STAMP(2);
                 __syncthreads();   // the early waves issue no DMA: nothing to wait for (their stores need no wait)
