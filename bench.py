@@ -205,12 +205,19 @@ def train_cpu_baseline(model, gin, inp, tables, sc, n_samples, rays=512, iters=3
     tin["uv"] = gin["uv"][:, sel.to(dev)].contiguous()
     tin.update(current_epoch=301, index_outside=torch.zeros(rays, dtype=torch.bool, device=dev),
                smpl_pose_last=gin["smpl_pose"] + 0.01)
+    loss_fn = Loss(load_config().loss)
+    gt = {"rgb": torch.rand(1, rays, 3, generator=g)}
     model.train()
+    model.zero_grad(set_to_none=True)
     with contextlib.redirect_stdout(sys.stderr):
-        model(tin)
+        out = model(tin)
+        lo_gpu = loss_fn(out, {"rgb": gt["rgb"].to(dev)})
+    lo_gpu["loss"].backward()                       # the device's own iteration on these pixels: what the oracle is compared with
     torch.cuda.synchronize()
     graph = model._last_train
     model.eval()
+    grads_gpu = {k: p.grad.detach().cpu().double() for k, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad(set_to_none=True)
     cx = graph.cx
     hit = [cx["per"][p]["hit_index"][:graph.fg[p]["Rp"]].long().cpu() for p in cx["persons"]]
     z_given = [graph.fg[p]["zfinal"].cpu() for p in cx["persons"]]
@@ -224,22 +231,42 @@ def train_cpu_baseline(model, gin, inp, tables, sc, n_samples, rays=512, iters=3
         pp.sd = sd
     oin = dict(inp)
     oin["uv"] = inp["uv"][:, sel]
-    loss_fn = Loss(load_config().loss)
-    gt = {"rgb": torch.rand(1, rays, 3, generator=g)}
-    times = []
-    for _ in range(iters):
+    tl = torch.mean(torch.square((inp["smpl_pose"] + 0.01) - inp["smpl_pose"])).reshape(())      # multiply.py:242-243
+    names = [k for k, v in sd.items() if v.requires_grad]
+    times, parity = [], {}
+    for i in range(iters):
         t0 = time.time()
         want = oracle.forward_train(oin, hit, z_given, draws)
-        want.update(fg_rgb_values_each_person_list=[], index_in_surface=None, epoch=301, temporal_loss=torch.zeros(1),
+        want.update(fg_rgb_values_each_person_list=[], index_in_surface=None, epoch=301, temporal_loss=tl,
                     smpl_surface_loss=torch.zeros(1), zero_pose_loss=torch.zeros(1))
         with contextlib.redirect_stdout(sys.stderr):
             lo = loss_fn(want, gt)
-        torch.autograd.grad(lo["loss"], [v for v in sd.values() if v.requires_grad], allow_unused=True)
+        gw = torch.autograd.grad(lo["loss"], [sd[k] for k in names], allow_unused=True)
         times.append(time.time() - t0)
+        if i == 0:
+            # parity of the SAME iteration at the benchmarked workload: loss, and every parameter gradient (relative L2 per
+            # tensor; tensors whose gradient is below 1e-7 everywhere are compared absolutely and left out of the maximum)
+            worst, worst_name, n_cmp = 0.0, "", 0
+            for k, gwk in zip(names, gw):
+                if k not in grads_gpu or gwk is None:
+                    continue
+                a, b = grads_gpu[k].reshape(-1), gwk.double().reshape(-1)
+                if float((a - b).abs().max()) < 1e-7:
+                    continue
+                rel = float((a - b).norm() / (b.norm() + 1e-12))
+                n_cmp += 1
+                if rel > worst:
+                    worst, worst_name = rel, k
+            fwd = {k: float((out[k].detach().cpu() - want[k].detach()).abs().nan_to_num().max())
+                   for k in ("rgb_values", "acc_map", "acc_person_list", "normal_values")}
+            parity = {"parity_loss_abs": abs(float(lo_gpu["loss"]) - float(lo["loss"])), "loss_gpu": float(lo_gpu["loss"]),
+                      "loss_oracle": float(lo["loss"]), "parity_grad_rel_worst": worst, "parity_grad_worst_tensor": worst_name,
+                      "parity_grad_tensors": n_cmp, "parity_forward_max_abs": fwd}
+        del gw
     dt = float(np.mean(times))
     threads, phys, name = host_cpu()
     return {"value": 1e3 * dt, "unit": "ms/train-iter", "cores": threads, "physical_cores": phys, "cpu_model": name,
-            "kind": "port", "rays": rays, "iters": iters,
+            "kind": "port", "rays": rays, "iters": iters, **parity,
             "sample": f"mean of {iters} iterations on {rays} rays (hit rays {[int(len(h)) for h in hit]}): forward from the "
                       f"sampler's depths + loss + autograd on the fp32 torch oracle, {threads} threads; per iteration "
                       f"{[round(t, 1) for t in times]} s"}

@@ -40,4 +40,24 @@ __device__ __forceinline__ float wave_excl_scan(float v, float& total) {
     return incl - v;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: a `static int once = hipFuncSetAttribute(...)` covers
+// only the device that is current at the first call.  MP_LDS_ATTR(kernel, bytes) sets it once per (call site, device ordinal)
+// and makes the enclosing entry point return the HIP error code if the runtime refuses.
+inline int lds_attr(const void* kernel, int bytes, unsigned long long& done_mask) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 64 && ((done_mask >> dev) & 1ull)) return 0;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 64) done_mask |= 1ull << dev;
+    return 0;
+}
+#define MP_LDS_ATTR(kernel, bytes)                                                    \
+    do {                                                                              \
+        static unsigned long long mp_lds_done_ = 0;                                   \
+        const int mp_lds_rc_ = mp::lds_attr((const void*)(kernel), (bytes), mp_lds_done_); \
+        if (mp_lds_rc_) return mp_lds_rc_;                                            \
+    } while (0)
+
 }  // namespace mp

@@ -148,8 +148,7 @@ extern "C" int mp_composite(int n_rays, int n_person, int n_z, const int* const*
     const int S = n_z - 1;
     const int lds = WPB * n_person * (3 * S + 1) * (int)sizeof(float);
     if (lds > 160 * 1024) return -2;
-    static int once = (int)hipFuncSetAttribute((const void*)k_composite, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)once;
+    MP_LDS_ATTR((k_composite), 160 * 1024);
     hipLaunchKernelGGL(k_composite, dim3((n_rays + WPB - 1) / WPB), dim3(64 * WPB), lds, (hipStream_t)stream, n_rays, n_person, n_z,
                        inv_index, z, sdf, rgb, normal, beta, bg_rgb, rgb_values, fg_rgb_values, normal_values, acc_map,
                        acc_person, bg_T);

@@ -15,6 +15,7 @@
 //   nt: lane (li, lq) takes k = 8 lq + s for the 8 MFMA steps s of a stage  -> 8 consecutive floats of its row
 //   tn: lane li of row block i owns tile row 4 li + i (column 2 li + j)      -> 4 (2) consecutive floats of LDS row r
 #include <hip/hip_runtime.h>
+#include "common.hpp"
 #include "../../include/multiply_hip.h"
 
 namespace {
@@ -237,9 +238,8 @@ extern "C" int mp_gemm_nt(const float* A, int lda, const float* B, int ldb, floa
                           const float* bias, int bias_rows, int accumulate, int relu, void* stream) {
     if (M <= 0 || N <= 0) return 0;
     constexpr int LDS_NT = 2 * (BM + BN) * LDK * (int)sizeof(float);
-    static int once = (int)hipFuncSetAttribute((const void*)k_gemm_nt<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_NT) +
-                      (int)hipFuncSetAttribute((const void*)k_gemm_nt<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_NT);
-    (void)once;
+    MP_LDS_ATTR((k_gemm_nt<true>), LDS_NT);
+    MP_LDS_ATTR((k_gemm_nt<false>), LDS_NT);
     const bool fast = (lda & 3) == 0 && (ldb & 3) == 0 && ((size_t)A & 15) == 0 && ((size_t)B & 15) == 0 && K % BK == 0;
     if (fast)
         hipLaunchKernelGGL(k_gemm_nt<true>, dim3((M + BM - 1) / BM, (N + BN - 1) / BN), dim3(NT_THREADS), LDS_NT, (hipStream_t)stream,
@@ -261,9 +261,8 @@ extern "C" int mp_gemm_tn(const float* A, int lda, const float* B, int ldb, floa
     if (rows < 4 * BK) rows = 4 * BK;
     slices = (K + rows - 1) / rows;
     constexpr int LDS_TN = 4 * BK * LDM * (int)sizeof(float);
-    static int once = (int)hipFuncSetAttribute((const void*)k_gemm_tn<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TN) +
-                      (int)hipFuncSetAttribute((const void*)k_gemm_tn<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TN);
-    (void)once;
+    MP_LDS_ATTR((k_gemm_tn<true>), LDS_TN);
+    MP_LDS_ATTR((k_gemm_tn<false>), LDS_TN);
     const bool fast = (lda & 3) == 0 && (ldb & 3) == 0 && ((size_t)A & 15) == 0 && ((size_t)B & 15) == 0 && M % BM == 0 &&
                       N % BN == 0;
     if (fast)

@@ -921,9 +921,7 @@ extern "C" int mp_warp_inverse(const float* pts, const float* dirs, const float*
     // when pts != NULL, max_rays carries the number of explicit points and sdf_out may carry beta for mode 2 (unused)
     if (max_rays <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    static int once = (int)hipFuncSetAttribute((const void*)k_warp_inverse, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               WARP_LDS);
-    (void)once;
+    MP_LDS_ATTR((k_warp_inverse), WARP_LDS);
     const int n_slab = pts ? (max_rays + 63) / 64 : ((max_rays + 63) / 64) * n_s;
     const int threads = warp_threads(n_slab), nw = threads / 64;
     hipLaunchKernelGGL(k_warp_inverse, dim3(warp_grid(n_slab, nw)), dim3(threads), WARP_LDS, st, pts, dirs, pose,
@@ -941,9 +939,7 @@ extern "C" int mp_warp_inverse_shade(const float* dirs, const float* pose, const
                                      float* sdf_out, int* worklist, int* work_count, int* nn_index, void* stream) {
     if (max_rays <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    static int once = (int)hipFuncSetAttribute((const void*)k_warp_inverse, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               WARP_LDS);
-    (void)once;
+    MP_LDS_ATTR((k_warp_inverse), WARP_LDS);
     const int n_slab = ((max_rays + 63) / 64) * n_s;
     const int threads = warp_threads(n_slab), nw = threads / 64;
     hipLaunchKernelGGL(k_warp_inverse, dim3(warp_grid(n_slab, nw)), dim3(threads), WARP_LDS, st,
@@ -959,9 +955,7 @@ extern "C" int mp_warp_jacobian(const float* xc, const unsigned char* need, cons
                                 void* stream) {
     if ((n_s > 0 ? max_rays : n_pts) <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    static int once = (int)hipFuncSetAttribute((const void*)k_warp_jacobian, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               WARP_LDS);
-    (void)once;
+    MP_LDS_ATTR((k_warp_jacobian), WARP_LDS);
     const int n_slab = n_s > 0 ? ((max_rays + 63) / 64) * n_s : (n_pts + 63) / 64;
     const int threads = warp_threads(n_slab), nw = threads / 64;
     hipLaunchKernelGGL(k_warp_jacobian, dim3(warp_grid(n_slab, nw)), dim3(threads), WARP_LDS, st, xc, need, hit_count,

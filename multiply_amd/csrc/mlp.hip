@@ -7,6 +7,7 @@
 // Geometry: plain kernels run 8 waves x (2 column blocks of 16 points) = 2 waves per SIMD; the forward-mode kernel needs
 // value and its three tangents in one wave: 8 waves x 8 points in a half-block layout, also 2 waves per SIMD.
 #include <hip/hip_runtime.h>
+#include "common.hpp"
 #include "../../include/multiply_hip.h"
 #include "mlp_core.hpp"
 
@@ -593,11 +594,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_background(const NetDesc net_imp
     }
 }
 
-template <typename K>
-int set_lds(K kernel, int bytes) {
-    return (int)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-}
-
 // persistent grid: `per_cu` workgroups per CU, grid-stride over tiles
 int grid_for(int work_blocks, int per_cu) {
     const int cap = 256 * per_cu;
@@ -642,8 +638,7 @@ extern "C" int mp_mlp_sdf(const MpNet* net, const void* wpack, const float* bias
     if (!net_ok(net)) return -1;
     hipStream_t st = (hipStream_t)stream;
     using L = Lds<2, PNB, PWAVES>;
-    static int once = set_lds(k_mlp_sdf<PNB, PWAVES>, L::total);
-    (void)once;
+    MP_LDS_ATTR((k_mlp_sdf<PNB, PWAVES>), L::total);
     const NetDesc d = as_desc(net);
     hipLaunchKernelGGL((k_mlp_sdf<PNB, PWAVES>), dim3(grid_for((max_count + L::TILE - 1) / L::TILE, 1)),
                        dim3(PWAVES * 64), L::total, st, d, (const char*)wpack, bias, xc, worklist, count, max_count,
@@ -659,14 +654,12 @@ extern "C" int mp_mlp_full(const MpNet* net, const void* wpack, const float* bia
     const NetDesc d = as_desc(net);
     if (d_in == 3) {
         using L = Lds<2, PNB, PWAVES>;
-        static int once = set_lds(k_mlp_full<3, 6, 2, PNB, PWAVES>, L::total);
-        (void)once;
+        MP_LDS_ATTR((k_mlp_full<3, 6, 2, PNB, PWAVES>), L::total);
         hipLaunchKernelGGL((k_mlp_full<3, 6, 2, PNB, PWAVES>), dim3(grid_for((n + L::TILE - 1) / L::TILE, 1)),
                            dim3(PWAVES * 64), L::total, st, d, (const char*)wpack, bias, x, n, out);
     } else if (d_in == 4) {
         using L = Lds<3, PNB, PWAVES>;
-        static int once = set_lds(k_mlp_full<4, 10, 3, PNB, PWAVES>, L::total);
-        (void)once;
+        MP_LDS_ATTR((k_mlp_full<4, 10, 3, PNB, PWAVES>), L::total);
         hipLaunchKernelGGL((k_mlp_full<4, 10, 3, PNB, PWAVES>), dim3(grid_for((n + L::TILE - 1) / L::TILE, 1)),
                            dim3(PWAVES * 64), L::total, st, d, (const char*)wpack, bias, x, n, out);
     } else {
@@ -690,8 +683,8 @@ extern "C" int mp_mlp_shade_rev(const MpNet* net, const void* wpack, const float
     using L = Lds<2, PNB, PWAVES>;
     constexpr int TILE = 16 * PNB * PWAVES;
     constexpr int LDS_G = RING_SLOTS * chunk_bytes(0) + 512 + PWAVES * 2 * 16 * PNB * 48 * 2;
-    static int once = set_lds(k_mlp_fwdsave<PNB, PWAVES>, L::total) + set_lds(k_mlp_grad<PNB, PWAVES>, LDS_G);
-    (void)once;
+    MP_LDS_ATTR((k_mlp_fwdsave<PNB, PWAVES>), L::total);
+    MP_LDS_ATTR((k_mlp_grad<PNB, PWAVES>), LDS_G);
     const NetDesc d = as_desc(net), gd = as_desc(gnet);
     for (int off = 0; off < max_count; off += seg_points) {   // segments past the device-side count return at once
         const int n = max_count - off < seg_points ? max_count - off : seg_points;
@@ -713,8 +706,7 @@ extern "C" int mp_mlp_shade(const MpNet* net, const void* wpack, const float* bi
     hipStream_t st = (hipStream_t)stream;
     const NetDesc d = as_desc(net);
     using L = Lds<2, 2, 8>;
-    static int once = set_lds(k_mlp_shade, L::total);
-    (void)once;
+    MP_LDS_ATTR((k_mlp_shade), L::total);
     hipLaunchKernelGGL(k_mlp_shade, dim3(grid_for((max_count + 63) / 64, 1)), dim3(512), L::total, st, d,
                        (const char*)wpack, bias, xc, jinv, worklist, count, max_count, sdf_out, normal_out,
                        (char*)feat_frag);
@@ -728,8 +720,7 @@ extern "C" int mp_mlp_color(const MpNet* net, const void* wpack, const float* bi
     if (!net_ok(net)) return -1;
     hipStream_t st = (hipStream_t)stream;
     using L = Lds<2, PNB, PWAVES>;
-    static int once = set_lds(k_mlp_color<PNB, PWAVES>, L::total);
-    (void)once;
+    MP_LDS_ATTR((k_mlp_color<PNB, PWAVES>), L::total);
     const NetDesc d = as_desc(net);
     hipLaunchKernelGGL((k_mlp_color<PNB, PWAVES>), dim3(grid_for((max_count + L::TILE - 1) / L::TILE, 1)),
                        dim3(PWAVES * 64), L::total, st, d, (const char*)wpack, bias, xc, normal, (const char*)feat_frag,
@@ -744,8 +735,7 @@ extern "C" int mp_background(const MpNet* net_imp, const void* wpack_imp, const 
     if (!net_ok(net_imp) || !net_ok(net_ren)) return -1;
     hipStream_t st = (hipStream_t)stream;
     using L = Lds<3, PNB, PWAVES>;
-    static int once = set_lds(k_background<PNB, PWAVES>, L::total);
-    (void)once;
+    MP_LDS_ATTR((k_background<PNB, PWAVES>), L::total);
     const NetDesc d0 = as_desc(net_imp), d1 = as_desc(net_ren);
     hipLaunchKernelGGL((k_background<PNB, PWAVES>), dim3(grid_for((n_rays * 32 + L::TILE - 1) / L::TILE, 1)),
                        dim3(PWAVES * 64), L::total, st, d0, (const char*)wpack_imp, bias_imp, d1, (const char*)wpack_ren,

@@ -28,7 +28,9 @@ __device__ __forceinline__ float fexp(float x) { return __expf(x); }
 // LaplaceDensity (density.py:20-29): (1/beta) (0.5 + 0.5 sign(s) expm1(-|s|/beta)) = (1/beta) * {0.5 e, 1 - 0.5 e, 0.5}
 __device__ __forceinline__ float density(float sdf, float inv_beta) {
     const float e = fexp(-fabsf(sdf) * inv_beta);
-    return inv_beta * (sdf > 0.0f ? 0.5f * e : (sdf < 0.0f ? 1.0f - 0.5f * e : 0.5f));
+    // a NaN sdf (a broken network evaluation) stays NaN, as in the reference's sign() * expm1() form: it must surface in the
+    // error bound (nan_max), not turn into the density of the surface
+    return sdf != sdf ? sdf : inv_beta * (sdf > 0.0f ? 0.5f * e : (sdf < 0.0f ? 1.0f - 0.5f * e : 0.5f));
 }
 
 struct Arr {

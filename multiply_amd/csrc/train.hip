@@ -941,8 +941,7 @@ int mp_tr_composite_bwd(int n_rays, int n_person, int n_z, const int* const* inv
     if (per_wave > 160 * 1024) return -2;
     int wpb = 4;
     while (wpb > 1 && wpb * per_wave > 160 * 1024) wpb >>= 1;
-    static int once = (int)hipFuncSetAttribute((const void*)k_composite_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)once;
+    MP_LDS_ATTR((k_composite_bwd), 160 * 1024);
     hipLaunchKernelGGL(k_composite_bwd, dim3((n_rays + wpb - 1) / wpb), dim3(64 * wpb), wpb * per_wave, ST, n_rays, n_person, n_z,
                        inv_index, z, sdf, rgb, beta, bg_rgb, d_rgb_values, d_acc, d_acc_person, d_sdf, d_rgb, d_bg_rgb, d_beta);
     return (int)hipGetLastError();

@@ -113,13 +113,20 @@ class Loss(nn.Module):
         rgb_gt = ground_truth["rgb"][0].to(dev)
         rgb_loss = self.get_rgb_loss(torch.nan_to_num(mo["rgb_values"]), rgb_gt, keep=finite)
         eikonal_loss = self.get_eikonal_loss(mo["grad_theta"])
-        bce_loss = self.get_bce_los(mo["acc_map"])
-        bce_loss = torch.where(bce_loss.isnan(), torch.zeros_like(bce_loss), bce_loss).reshape(1)    # loss.py:124-128 (its
-        # "Nan: bce_loss" print would need the value on the host)
+        # loss.py:124-128 / 131-139: a NaN term is REPLACED by a fresh zero, so nothing flows back through it.  Without a host
+        # round trip that means: find the elements that would make the term NaN, evaluate it on sanitised values (no NaN
+        # node in the graph -- zeroing only the result would still send 0 * NaN = NaN backwards into every weight), and
+        # select the zero on the device.  (The reference's "Nan: bce_loss" print would need the value on the host.)
+        acc = mo["acc_map"]
+        bad_el = acc.isnan() | ((acc + self.eps) < 0) | ((1 - acc + self.eps) < 0)      # where the logarithms give NaN
+        bce_loss = self.get_bce_los(torch.where(bad_el, torch.full_like(acc, 0.5), acc))
+        bce_loss = torch.where(bad_el.any(), torch.zeros_like(bce_loss), bce_loss).reshape(1)
         opacity_sparse_loss = zero()
         if mo["index_in_surface"] is not None:
-            in_shape_loss = self.get_in_shape_loss(mo["acc_map"], mo["index_in_surface"])
-            in_shape_loss = torch.where(in_shape_loss.isnan(), torch.zeros_like(in_shape_loss), in_shape_loss).reshape(1)
+            mask = mo["index_in_surface"]
+            bad = (mask.sum() == 0) | (acc.isnan() & mask).any()                          # empty mean or a NaN inside it
+            in_shape_loss = torch.where(mask, (torch.nan_to_num(acc) - 1).abs(), torch.zeros_like(acc)).sum() / mask.sum().clamp(min=1)
+            in_shape_loss = torch.where(bad, torch.zeros_like(in_shape_loss), in_shape_loss).reshape(1)
         else:
             in_shape_loss = zero()
 

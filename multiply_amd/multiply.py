@@ -160,22 +160,43 @@ class Multiply(nn.Module):
         with torch.no_grad():
             return self._forward_eval(input, id, canonical_pose)
 
-    def _setup(self, input, id, canonical_pose, side_stream=False):
+    def _setup(self, input, id, canonical_pose, side_stream=False, _beta=None):
         """Rays, SMPL posing, nearest-vertex structures and the box cull for every person of the call
         (multiply.py:177-266).  Ends with the one host sync of the call (hit counts size the workspaces).
 
-        side_stream (training): the setup kernels read only the call's inputs -- never a network weight -- so they run on a
-        stream of their own and the host waits for THAT stream only: it does not wait for the previous iteration's backward
-        pass still running on the caller's stream, and keeps enqueueing (the GPU never idles between iterations).  The
-        inputs must be resident and complete (produced by work the host has already waited for, e.g. a data loader's
-        copies); everything allocated here is handed to the caller's stream (record_stream + an event wait)."""
+        side_stream: the setup kernels read only the call's inputs, so they run on a stream of their own and the host waits
+        for THAT stream only: it does not wait for the previous iteration's backward pass (or the previous frame) still
+        running on the caller's stream, and keeps enqueueing.  The inputs must be resident and complete (produced by work
+        the host has already waited for, e.g. a data loader's copies); everything allocated here is handed to the caller's
+        stream (record_stream + an event wait).  What is NOT an input of the call stays on the caller's stream:
+          * `density.beta` is a trained parameter -- the previous iteration's optimizer step may still be updating it on
+            the caller's stream.  Training: the setup kernels do not read it (the near cull is eval-only) and the call's
+            `beta` is computed on the caller's stream behind the join.  Eval: the near cull does read it, so the value is
+            computed on the caller's stream once per parameter version and the side stream waits for that event;
+          * body-model inputs that are being optimised (requires_grad / produced by BodyModelParams in this iteration on
+            the caller's stream): the side stream is refused, the setup runs in order."""
+        if side_stream and any(torch.is_tensor(input.get(k)) and (input[k].requires_grad or input[k].grad_fn is not None)
+                               for k in ("smpl_params", "smpl_pose", "smpl_shape", "smpl_trans")):
+            side_stream = False
         if side_stream:
             main = torch.cuda.current_stream()
             side = self.__dict__.get("_setup_stream")
             if side is None:
                 side = self.__dict__["_setup_stream"] = torch.cuda.Stream()
+            beta_in = None
+            if not self.training:
+                b = self.density.beta
+                cache = self.__dict__.get("_eval_beta")
+                if cache is None or cache[0] != b._version or cache[1].device != b.device:
+                    val = (b.detach().abs() + self.density.beta_min).reshape(1).float().contiguous()   # caller's stream
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)          # once per parameter version: later side-stream work is ordered behind it
+                    val.record_stream(side)
+                    cache = self.__dict__["_eval_beta"] = (b._version, val)
+                beta_in = cache[1]
             with torch.cuda.stream(side):
-                cx = self._setup(input, id, canonical_pose)
+                cx = self._setup(input, id, canonical_pose, _beta=beta_in if beta_in is not None else "defer")
 
             def hand_over(o):
                 if torch.is_tensor(o):
@@ -189,6 +210,8 @@ class Multiply(nn.Module):
                         hand_over(v)
             hand_over(cx)
             main.wait_stream(side)
+            if beta_in is None:       # training: the parameter as the caller's stream sees it (behind the last optimizer step)
+                cx["beta"] = (self.density.beta.detach().abs() + self.density.beta_min).reshape(1).float().contiguous()
             return cx
         L = hip.lib()
         dev = self.density.beta.device
@@ -207,7 +230,13 @@ class Multiply(nn.Module):
         persons = list(id) if isinstance(id, (list, tuple)) else (list(range(P)) if id == -1 else [id])
         rs = self.ray_sampler
         group = int(self.convergence_group or R)
-        beta = (self.density.beta.detach().abs() + self.density.beta_min).reshape(1).float().contiguous()
+        if torch.is_tensor(_beta):
+            beta = _beta
+        elif _beta == "defer":     # side-stream training setup: filled in on the caller's stream; no setup kernel reads it
+            assert self.training, "a deferred beta is only valid where the near cull (eval) does not run"
+            beta = None
+        else:
+            beta = (self.density.beta.detach().abs() + self.density.beta_min).reshape(1).float().contiguous()
 
         # rays (rend_util.get_camera_params)
         dirs = torch.empty(R, 3, **f32)

@@ -124,6 +124,26 @@ class _SMPLModule(nn.Module):
         self.register_buffer("posedirs", tables.posedirs)
         self.register_buffer("parents", torch.from_numpy(tables.parents_np.copy()).to(dev))          # long, parents[0] = -1
         self.register_buffer("lbs_weights", tables.lbs_weights)
+        self._register_load_state_dict_pre_hook(self._check_tables)
+
+    _TABLE_KEYS = ("v_template", "shapedirs", "J_regressor", "posedirs", "lbs_weights", "parents", "faces_tensor")
+
+    def _check_tables(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """Everything derived from the tables at construction (canonical vertices and inverse bone transforms, the joint
+        shape basis, the nearest-vertex cluster order, the canonical meshes) is NOT rebuilt by load_state_dict: a
+        checkpoint whose body-model tables differ from the ones this model was built with (another gender, synthetic
+        tables) is refused here instead of leaving the model silently inconsistent."""
+        for k in self._TABLE_KEYS:
+            v = state_dict.get(prefix + k)
+            if v is None:
+                continue
+            cur = getattr(self, k)
+            same = tuple(v.shape) == tuple(cur.shape) and bool(
+                torch.equal(v.to(cur.device).to(cur.dtype), cur) if not cur.is_floating_point()
+                else torch.allclose(v.to(cur.device).to(cur.dtype), cur, rtol=0, atol=1e-7))
+            if not same:
+                error_msgs.append(f"{prefix}{k}: the checkpoint's SMPL table differs from the one this model was constructed with "
+                                  f"(gender / betas_path / smpl_tables); construct the model with the checkpoint's body model")
 
 
 class _PoseTfs(torch.autograd.Function):

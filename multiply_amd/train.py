@@ -481,7 +481,13 @@ class TrainGraph:
             imp, ren, dfm = m.foreground_implicit_network_list[p], m.foreground_rendering_network_list[p], m.deformer_list[p]
             server = m.smpl_server_list[p]
             skin_w = server.tables.lbs_weights
-            zfinal, iters, wcount = m._sample_person(cx, n, p, dr)
+            if dr.get("z_given") is not None:
+                # depths handed in by the caller instead of sampled here (the sampler runs without gradients in the reference,
+                # ray_sampler.py:86-87): lets a test drive everything downstream from an INDEPENDENT sampler's depths
+                zfinal, iters, wcount = dr["z_given"].to(dev).float().contiguous(), None, None
+                assert zfinal.shape == (Rp, NZ), f"z_given of person {p}: {tuple(zfinal.shape)} != {(Rp, NZ)}"
+            else:
+                zfinal, iters, wcount = m._sample_person(cx, n, p, dr)
             npts = Rp * S
             E = N_EIKONAL
             Pt = npts + E

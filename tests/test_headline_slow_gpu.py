@@ -1,0 +1,64 @@
+"""The headline configuration against the oracle at scale: BASELINE.json configs[1] -- the full 512x512 two-person frame with
+N_samples = 128, rendered ONCE by the device exactly as bench.py renders it (own cull, convergence groups of 512 rays in
+8x8-pixel tile order) -- compared with the CPU oracle on MP_SLOW_GROUPS (default 32) whole convergence groups spread over
+the frame = 16 384 rays.  The oracle needs ~1 min per thousand rays on the GPU box's host cores, so the test only runs
+with MP_RUN_SLOW=1 (`MP_RUN_SLOW=1 python -m pytest tests/test_headline_slow_gpu.py -m gpu -s`); its printed summary of the
+last run is committed under profiles/.  The always-on versions: test_render_gpu.py (1 024 rays), bench.py's 2 048-ray sample."""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import multiply_oracle as O
+from tests import tolerances as TOL
+from tests.test_render_gpu import report
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.skipif(os.environ.get("MP_RUN_SLOW") != "1", reason="~15 min of CPU oracle; set MP_RUN_SLOW=1")
+def test_headline_frame_vs_oracle_on_16k_rays():
+    import bench
+    n_groups = int(os.environ.get("MP_SLOW_GROUPS", "32"))
+    model, inp, tables, sc = bench.build_model(128)
+    model.convergence_group = 512
+    got = model(bench.to_dev(inp))
+    torch.cuda.synchronize()
+    R = inp["uv"].shape[1]
+    n_hit = model.last_stats["n_hit"]
+    hit = [model._last["per"][p]["hit_index"][:n].long().cpu() for p, n in zip(model._last["persons"], n_hit)]
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    oracle = O.MultiplyOracle(sd, tables, sc["smpl_params"][0, :, 76:], O.SamplerCfg(N_samples=128, N_samples_eval=128))
+    groups = np.unique(np.linspace(0, R // 512 - 1, n_groups).round().astype(int))
+    keys = ("rgb_values", "acc_map", "acc_person_list", "normal_values", "fg_rgb_values")
+    parts, rays = {k: [] for k in keys}, []
+    t0 = time.time()
+    for g in groups:
+        c0 = int(g) * 512
+        sub = dict(inp)
+        sub["uv"] = inp["uv"][:, c0:c0 + 512]
+        hg = [h[(h >= c0) & (h < c0 + 512)] - c0 for h in hit]
+        hg = [h if len(h) else torch.zeros(1, dtype=torch.long) for h in hg]        # multiply.py:262-263 per chunk
+        w = oracle.forward_eval(sub, hg)
+        for k in keys:
+            parts[k].append(w[k])
+        rays.append(torch.arange(c0, c0 + 512))
+    dt = time.time() - t0
+    rays = torch.cat(rays)
+    n_body = int(sum(((h[:, None] // 512) == torch.as_tensor(groups)[None, :]).any(1).sum() for h in hit))
+    lines = [f"headline frame vs oracle: {len(rays)} rays = {len(groups)} convergence groups of 512 spread over the 512x512 frame, "
+             f"{n_body} ray-person pairs inside the boxes; oracle {dt:.0f} s on {torch.get_num_threads()} threads"]
+    ok = True
+    for k in keys:
+        st = report("headline 16k " + k, got[k].cpu()[rays], torch.cat(parts[k], 0))
+        e = st.err
+        lines.append(f"{k:16s} max {st[0]:.3e} mean {st[1]:.3e} p99 {float(torch.quantile(e, 0.99)):.2e} p99.9 "
+                     f"{float(torch.quantile(e, 0.999)):.2e} rays > 1e-2: {int((e > 1e-2).sum())} of {e.numel()}")
+        ok = ok and TOL.within(st, TOL.EVAL[k])
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_16k.txt", "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+    assert ok

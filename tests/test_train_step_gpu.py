@@ -103,6 +103,11 @@ def test_training_forward_loss_and_all_parameter_gradients():
 
     # backward: every parameter.  Relative error in the L2 sense per tensor; the colour nets' ReLU masks and the
     # |sdf| of the background density can flip for single samples between summation orders, hence 2e-2 there.
+    worst = _compare_parameter_gradients(model, oracle, names, gw)
+    print(f"[parity] worst relative parameter-gradient error {worst:.3e} over {len(names)} tensors")
+
+
+def _compare_parameter_gradients(model, oracle, names, gw):
     got = dict(model.named_parameters())
     worst = 0.0
     for k, g in zip(names, gw):
@@ -119,7 +124,75 @@ def test_training_forward_loss_and_all_parameter_gradients():
         worst = max(worst, rel)
         tol = TOL.TRAIN_GRAD_REL_RENDERING if "rendering" in k else TOL.TRAIN_GRAD_REL
         assert rel < tol or float((a - b).abs().max()) < 1e-7, f"{k}: rel {rel:.3e} |g| {float(b.norm()):.3e}"
-    print(f"[parity] worst relative parameter-gradient error {worst:.3e} over {len(names)} tensors")
+    return worst
+
+
+def test_training_forward_and_gradients_from_the_oracles_own_sampler_depths():
+    """The other tests hand the DEVICE's depths to the oracle.  Here the depths come from the ORACLE's sampler (fp32 SDF
+    queries, the same recorded draws) and are handed to the device (`z_given`): everything downstream of the sampler --
+    warp, both networks, normals, eikonal term, compositing, background, loss, every parameter gradient -- is compared from
+    depths the device never produced."""
+    model, oracle, inp, gin, gt, loss_fn, train = _train_setup()
+    R = inp["uv"].shape[1]
+    hit = [torch.arange(R), torch.arange(R)]
+    cx = model._setup({**gin, "hit_index": hit}, -1, False)
+    draws = train.make_draws(model, cx, None)
+    dirs, cam1 = O.get_camera_rays(inp["uv"][0], inp["pose"][0], inp["intrinsics"][0])
+    cam = cam1[None].expand(R, -1)
+    z_oracle = []
+    for p in cx["persons"]:
+        so = oracle.servers[p].forward(inp["smpl_params"][0, p, 0], inp["smpl_trans"][0, p], inp["smpl_pose"][0, p],
+                                       inp["smpl_shape"][0, p])
+        cond = inp["smpl_pose"][0, p, 3:] / np.pi
+        fn = lambda pts: oracle.persons[p].sdf_func(pts, cond, so["smpl_tfs"], so["smpl_verts"], eval_mode=False)[0]
+        d = _cpu(draws["person"][p])
+        with torch.no_grad():
+            z, _ = O.error_bound_sample(oracle.cfg, dirs, cam, fn, oracle.beta().detach(),
+                                        dict(t_rand=d["t_rand"], u_final=d["u_final"], extra_idx=d["extra_idx"].long()))
+        z_oracle.append(z.float())
+        draws["person"][p]["z_given"] = z.float().cuda()
+    out = train.forward_train(model, {**gin, "hit_index": hit}, draws=draws)
+    lo = loss_fn(out, gt)
+    model.zero_grad()
+    lo["loss"].backward()
+    torch.cuda.synchronize()
+    for p in cx["persons"]:
+        assert torch.equal(model._last_train.fg[p]["zfinal"].cpu(), z_oracle[p])          # the device did not sample
+    for v in oracle.sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    want = oracle.forward_train(inp, hit, z_oracle, _cpu(draws))
+    tl = torch.mean(torch.square((inp["smpl_pose"] + 0.01) - inp["smpl_pose"]))
+    want.update(fg_rgb_values_each_person_list=[], index_in_surface=None, epoch=301, temporal_loss=tl.reshape(()),
+                smpl_surface_loss=torch.zeros(1), zero_pose_loss=torch.zeros(1), sam_mask=gin["sam_mask"].squeeze().cpu())
+    lw = loss_fn(want, gt)
+    names = [k for k, v in oracle.sd.items() if v.requires_grad]
+    gw = torch.autograd.grad(lw["loss"], [oracle.sd[k] for k in names], allow_unused=True)
+    for k, tol in TOL.TRAIN_FWD.items():
+        mx, mean = report("train (oracle depths) " + k, out[k], want[k].detach())
+        assert mx < tol, k
+    assert abs(float(lo["loss"]) - float(lw["loss"])) < 1e-4 * max(1.0, abs(float(lw["loss"])))
+    worst = _compare_parameter_gradients(model, oracle, names, gw)
+    print(f"[parity] from the oracle's depths: loss gpu {float(lo['loss']):.6f} oracle {float(lw['loss']):.6f}, worst relative "
+          f"parameter-gradient error {worst:.3e}")
+
+
+def test_training_parity_at_the_benchmarked_workload():
+    """BASELINE.json configs[1] as bench.py's `train_iter` runs it: 512 random pixels of the 512x512 two-person frame,
+    N_samples = 128 (161 composited samples per ray and person), epoch 301.  One iteration of the device (forward + loss +
+    hand-written backward) against one iteration of the oracle under torch autograd on the same pixels, depths and draws --
+    the comparison bench.py records in its JSON line (`train_iter.cpu_baseline.parity_*`)."""
+    import bench
+    model, inp, tables, sc = bench.build_model(128)
+    model.convergence_group = 512
+    gin = bench.to_dev(inp)
+    res = bench.train_cpu_baseline(model, gin, inp, tables, sc, 128, rays=512, iters=1)
+    print("[parity] bench workload:", {k: v for k, v in res.items() if k.startswith(("parity", "loss_"))})
+    assert res["parity_grad_tensors"] >= 60
+    assert res["parity_loss_abs"] < 1e-4 * max(1.0, abs(res["loss_oracle"]))
+    assert res["parity_grad_rel_worst"] < TOL.TRAIN_GRAD_REL_RENDERING, res["parity_grad_worst_tensor"]
+    for k, v in res["parity_forward_max_abs"].items():
+        assert v < TOL.TRAIN_FWD.get(k, 8e-6) * 2, (k, v)
 
 
 def test_training_step_reduces_loss():

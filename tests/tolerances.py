@@ -30,5 +30,19 @@ TRAIN_GRAD_REL = 5e-3                       # per-tensor relative L2 error of a 
 TRAIN_GRAD_REL_RENDERING = 2e-2             # colour nets: single ReLU masks flip between summation orders
 
 
+class Stats(tuple):
+    """(max, mean) of an error vector, with the vector itself attached (`.err`, one entry per ray / element)."""
+
+    def __new__(cls, err):
+        st = tuple.__new__(cls, (float(err.max()) if err.numel() else 0.0, float(err.mean()) if err.numel() else 0.0))
+        st.err = err
+        return st
+
+
 def within(stats, tol):
+    """tol = (max, mean), or a Dist: mean, the BULK bound with the fraction of rays allowed above it, and a hard maximum."""
+    if isinstance(tol, dict):
+        err = stats.err
+        above = float((err > tol["bulk"]).sum()) / max(err.numel(), 1)
+        return stats[1] < tol["mean"] and above <= tol["frac"] and stats[0] < tol["hard"]
     return stats[0] < tol[0] and stats[1] < tol[1]
