@@ -246,12 +246,14 @@ def train_cpu_baseline(model, gin, inp, tables, sc, n_samples, rays=512, iters=3
         if i == 0:
             # parity of the SAME iteration at the benchmarked workload: loss, and every parameter gradient (relative L2 per
             # tensor; tensors whose gradient is below 1e-7 everywhere are compared absolutely and left out of the maximum)
-            worst, worst_name, n_cmp = 0.0, "", 0
+            worst, worst_name, n_cmp, n_tiny, n_nograd = 0.0, "", 0, 0, 0
             for k, gwk in zip(names, gw):
                 if k not in grads_gpu or gwk is None:
+                    n_nograd += k not in grads_gpu
                     continue
                 a, b = grads_gpu[k].reshape(-1), gwk.double().reshape(-1)
-                if float((a - b).abs().max()) < 1e-7:
+                if float(b.abs().max()) < 1e-7 and float((a - b).abs().max()) < 1e-7:
+                    n_tiny += 1
                     continue
                 rel = float((a - b).norm() / (b.norm() + 1e-12))
                 n_cmp += 1
@@ -261,7 +263,8 @@ def train_cpu_baseline(model, gin, inp, tables, sc, n_samples, rays=512, iters=3
                    for k in ("rgb_values", "acc_map", "acc_person_list", "normal_values")}
             parity = {"parity_loss_abs": abs(float(lo_gpu["loss"]) - float(lo["loss"])), "loss_gpu": float(lo_gpu["loss"]),
                       "loss_oracle": float(lo["loss"]), "parity_grad_rel_worst": worst, "parity_grad_worst_tensor": worst_name,
-                      "parity_grad_tensors": n_cmp, "parity_forward_max_abs": fwd}
+                      "parity_grad_tensors": n_cmp, "parity_grad_tensors_below_1e-7": n_tiny,
+                      "parity_state_entries_without_gradient": n_nograd, "parity_forward_max_abs": fwd}
         del gw
     dt = float(np.mean(times))
     threads, phys, name = host_cpu()

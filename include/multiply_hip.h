@@ -125,6 +125,16 @@ int mp_knn_build(const float* verts, const int* perm, float* vsorted, float* cbo
  * minimum-volume box).  obb [15] = centre3, axes (3 rows), half extents3. */
 int mp_obb(const float* verts, float inflate, float* obb, void* stream);
 
+/* The MINIMUM-VOLUME oriented box the reference asks trimesh for (multiply.py:208-214: smpl_mesh.bounding_box_oriented,
+ * primitives.Box(extents * 1.2, transform)) from the convex hull of the posed vertices.  The hull is computed by the caller
+ * (multiply_amd/obb.py hull_search_inputs: Qhull); the search over (hull-facet normal, silhouette edge) candidates and the box
+ * itself are computed here in fp64.  All inputs fp64, device resident:
+ *   hull_verts [H][3]; normals [N][3] the distinct facet normals in the caller's order of preference; per hull edge
+ *   edge_vec [E][3] and the normals of its two facets edge_na / edge_nb [E][3]; work [2 N] scratch.
+ *   obb [16] as mp_obb: centre3, axes (3 rows: facet normal, rectangle sides), half extents3 x inflate, pad. */
+int mp_obb_hull(const double* hull_verts, int n_hull_verts, const double* normals, int n_normals, const double* edge_vec,
+                const double* edge_na, const double* edge_nb, int n_edges, float inflate, double* work, float* obb, void* stream);
+
 /* ---- rays -------------------------------------------------------------------------------------
  * rend_util.get_camera_params (lib/utils/rend_util.py:45-87) + far sphere root (:131-147).
  *   uv [R][2], intrinsics [16], pose [16] -> dirs [R][3], far [R]; cam is pose[:3,3]. */
@@ -234,8 +244,17 @@ int mp_composite(int n_rays, int n_person, int n_z, const int* const* inv_index,
 /* C[M,N] (+)= A[M,K] . B[N,K]^T (+ bias[N] on rows < bias_rows) (optional ReLU); exact-fp32 MFMA */
 int mp_gemm_nt(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
                const float* bias, int bias_rows, int accumulate, int relu, void* stream);
+/* The same product with every fp32 operand split into two bfloat16 halves (x = hi + lo) on its way into LDS and three
+ * v_mfma_f32_16x16x32_bf16 per block product (hi.hi + hi.lo + lo.hi), fp32 accumulate: relative error ~2^-16 per product,
+ * fp32 range; same arguments and epilogue. */
+int mp_gemm_nt_bf16x3(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+               const float* bias, int bias_rows, int accumulate, int relu, void* stream);
 /* C[M,N] += A[K,M]^T . B[K,N]  (C must be initialised; fp32 atomics) */
 int mp_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, float* colsum,
+               int colsum_rows, void* stream);
+/* The same contraction on the split-bf16 path (see mp_gemm_nt_bf16x3); the 4 x 4 register transposition that turns the row-major
+ * operands into k-contiguous MFMA fragments happens on the way into LDS.  colsum stays an exact fp32 sum. */
+int mp_gemm_tn_bf16x3(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, float* colsum,
                int colsum_rows, void* stream);
 /* Fourier features (embedders.py) of x [P][d_in] (d_in 3|4, L octaves) times `scale` into out[.][ld] at col0; fwd != 0 also
  * writes the three (d_in = 3) tangent row blocks */

@@ -137,6 +137,126 @@ __global__ __launch_bounds__(NT_THREADS) void k_gemm_nt(const float* __restrict_
         }
 }
 
+// ---- mp_gemm_nt_bf16x3: the same product on the 16-bit matrix cores at (almost) fp32 accuracy ---------------------------------
+// Every fp32 operand is split on its way into LDS into two bfloat16 halves, x = hi + lo + r with |r| <= 2^-17 |x| (hi = bf16(x),
+// lo = bf16(x - hi)), and a product is three MFMAs, hi.hi + hi.lo + lo.hi (the dropped lo.lo term is 2^-16 relative): relative
+// error ~2^-16 per product instead of the 2^-9 of a plain bf16 product, the RANGE of fp32 (no loss scaling: the gradient
+// operands of the backward pass reach 1e-9, below half precision's subnormals), fp32 accumulation.  One v_mfma_f32_16x16x32_bf16
+// (16 cycles) covers the whole 32-deep LDS stage of a 16x16 block, so a stage costs 8 blocks x 3 = 24 MFMAs = 384 matrix-pipe
+// cycles per wave against 64 x 32 = 2048 with v_mfma_f32_16x16x4_f32: the training GEMMs (M ~ 5e4 rows, N = K = 256) leave the
+// compute-bound regime and run at the rate HBM delivers their fp32 operands.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int LDK16 = BK + 8;   // bf16 elements per LDS row: 80 B, 16 B aligned, the 16 rows of a b128 read on 16 distinct bank quads
+
+template <bool FAST>
+__global__ __launch_bounds__(NT_THREADS) void k_gemm_nt_b3(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                    float* __restrict__ C, int ldc, int M, int N, int K,
+                                                    const float* __restrict__ bias, int bias_rows, int accumulate, int relu) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // [stage][hi | lo][row][k] for A, then the same for B
+    __bf16* As = (__bf16*)smem;
+    __bf16* Bs = As + 2 * 2 * BM * LDK16;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int wm = (wave >> 2) * 64, wn = (wave & 3) * 32;   // 2 x 4 waves, each 64 x 32
+    const int li = lane & 15, lq = lane >> 4;
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+    const int sr = t >> 3, sk = (t & 7) * 4;       // staging: row sr + 64 q, k offset sk
+    const bool a_al = (lda & 3) == 0 && ((size_t)A & 15) == 0, b_al = (ldb & 3) == 0 && ((size_t)B & 15) == 0;
+    f32x4 ra[2], rb[2];
+    const float* pa[2];
+    const float* pb[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        pa[q] = A + (size_t)min(m0 + sr + 64 * q, M - 1) * lda + sk;
+        pb[q] = B + (size_t)min(n0 + sr + 64 * q, N - 1) * ldb + sk;
+    }
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if constexpr (FAST) {
+                ra[q] = *(const f32x4*)(pa[q] + k0);
+                rb[q] = *(const f32x4*)(pb[q] + k0);
+            } else {
+                const int am = m0 + sr + 64 * q, bn = n0 + sr + 64 * q, k = k0 + sk;
+                ra[q] = am < M ? ld4(A + (size_t)am * lda + k, a_al && k + 3 < K, K - k) : (f32x4){0, 0, 0, 0};
+                rb[q] = bn < N ? ld4(B + (size_t)bn * ldb + k, b_al && k + 3 < K, K - k) : (f32x4){0, 0, 0, 0};
+            }
+        }
+    };
+    auto split_store = [&](__bf16* tile, f32x4 v, int row) {   // tile = [hi | lo][row][k] of one stage
+        const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+        const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
+        *(bf16x4*)(tile + row * LDK16 + sk) = hi;
+        *(bf16x4*)(tile + BM * LDK16 + row * LDK16 + sk) = lo;
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            split_store(As + buf * 2 * BM * LDK16, ra[q], sr + 64 * q);
+            split_store(Bs + buf * 2 * BN * LDK16, rb[q], sr + 64 * q);
+        }
+    };
+    const int nk = (K + BK - 1) / BK;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+        const __bf16* at = As + buf * 2 * BM * LDK16;
+        const __bf16* bt = Bs + buf * 2 * BN * LDK16;
+        bf16x8 ah[4], al[4], bh[2], bl[2];
+        // lane (li, lq) supplies k = 8 lq .. 8 lq + 7 of its row (the k index of an MFMA is free to permute): one b128 per operand
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ah[i] = *(const bf16x8*)(at + (wm + i * 16 + li) * LDK16 + 8 * lq);
+            al[i] = *(const bf16x8*)(at + BM * LDK16 + (wm + i * 16 + li) * LDK16 + 8 * lq);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bh[j] = *(const bf16x8*)(bt + (wn + j * 16 + li) * LDK16 + 8 * lq);
+            bl[j] = *(const bf16x8*)(bt + BN * LDK16 + (wn + j * 16 + li) * LDK16 + 8 * lq);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);   // the small terms first
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+        if (kt + 1 < nk) sstore(buf ^ 1);
+        __syncthreads();
+    }
+    // D: col = lane&15 (n), row = 4*(lane>>4)+reg (m)
+    const int cn = lane & 15, cr = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn + j * 16 + cn;
+            if (n >= N) continue;
+            const float bn = bias ? bias[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm + i * 16 + cr + r;
+                if (m >= M) continue;
+                float v = acc[i][j][r];
+                if (m < bias_rows) v += bn;
+                float* c = C + (size_t)m * ldc + n;
+                if (accumulate) v += *c;
+                if (relu) v = fmaxf(v, 0.0f);
+                *c = v;
+            }
+        }
+}
+
 // C[M,N] += sum_r A[r,m] B[r,n]; block = 128x128 tile of C x one slice of the rows
 // FAST: aligned operands, M and N multiples of the tile: only the row-slice bound remains in the loop
 template <bool FAST>
@@ -232,6 +352,126 @@ __global__ __launch_bounds__(NT_THREADS) void k_gemm_tn(const float* __restrict_
     }
 }
 
+// ---- mp_gemm_tn_bf16x3: the weight-gradient contraction with the same split -------------------------------------------------
+// C[m][n] += sum_r A[r][m] B[r][n]: the MFMA's k index is the ROW index of both operands, which are row-major in HBM -- each lane
+// needs consecutive rows of one column.  The transposition happens in registers on the way into LDS: a staging thread loads a
+// 4 (rows) x 4 (columns) block with four coalesced float4 loads and writes, per column, the four rows as ONE 8-byte group of
+// bf16 (hi tile and lo tile).  LDS image per operand and half: [row block of 4][column][4 x bf16]: a thread's four columns are 32
+// contiguous bytes (two b128 writes, conflict-free across the wave), and a lane's operand for a 32-row stage is the two row
+// blocks (2 kg, 2 kg + 1) of its column: two b64 reads, consecutive lanes on consecutive 8-byte slots (conflict-free).
+template <bool FAST>
+__global__ __launch_bounds__(NT_THREADS) void k_gemm_tn_b3(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                    float* __restrict__ C, int ldc, int M, int N, int K, int rows_per_block,
+                                                    float* __restrict__ colsum, int colsum_rows) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int HALF = (BK / 4) * BM * 4;            // bf16 elements of one [row block][column][4] tile (BM == BN)
+    __bf16* Ts = (__bf16*)smem;                          // [stage][A | B][hi | lo][HALF]
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int r_begin = blockIdx.z * rows_per_block, r_end = min(K, r_begin + rows_per_block);
+    const int wm = (wave >> 2) * 64, wn = (wave & 3) * 32;   // 2 x 4 waves, each 64 (m) x 32 (n)
+    const int li = lane & 15, kg = lane >> 4;
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+    // staging: threads 0..255 take A, 256..511 take B; each a 4-row x 4-column block of the 32 x 128 stage tile
+    const bool is_b = t >= 256;
+    const int tt = t & 255, mg = tt & 31, rb = tt >> 5;    // columns 4 mg .. 4 mg + 3, rows 4 rb .. 4 rb + 3 of the stage
+    const float* src = is_b ? B : A;
+    const int ld = is_b ? ldb : lda, c0 = (is_b ? n0 : m0) + 4 * mg, cmax = is_b ? N : M;
+    const bool al = (ld & 3) == 0 && ((size_t)src & 15) == 0;
+    const bool do_sum = colsum != nullptr && blockIdx.y == 0 && !is_b;
+    f32x4 rr[4], csum = {0.f, 0.f, 0.f, 0.f};
+    auto gload = [&](int r0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = r0 + 4 * rb + e;
+            if constexpr (FAST) rr[e] = r < r_end ? *(const f32x4*)(src + (size_t)r * ld + c0) : (f32x4){0, 0, 0, 0};
+            else rr[e] = r < r_end ? ld4(src + (size_t)r * ld + c0, al && c0 + 3 < cmax, cmax - c0) : (f32x4){0, 0, 0, 0};
+            if (do_sum && r < colsum_rows) csum += rr[e];
+        }
+    };
+    auto sstore = [&](int buf) {
+        __bf16* tile = Ts + ((buf * 2 + (is_b ? 1 : 0)) * 2) * HALF + (rb * BM + 4 * mg) * 4;
+        bf16x8 h[2], l[2];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                   // column c of the block: its four rows
+            const f32x4 v = {rr[0][c], rr[1][c], rr[2][c], rr[3][c]};
+            const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+            const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { h[c >> 1][(c & 1) * 4 + e] = hi[e]; l[c >> 1][(c & 1) * 4 + e] = lo[e]; }
+        }
+        *(bf16x8*)(tile) = h[0];
+        *(bf16x8*)(tile + 8) = h[1];
+        *(bf16x8*)(tile + HALF) = l[0];
+        *(bf16x8*)(tile + HALF + 8) = l[1];
+    };
+    const int nk = (r_end - r_begin + BK - 1) / BK;
+    if (nk > 0) {
+        gload(r_begin);
+        sstore(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(r_begin + (kt + 1) * BK);
+        const __bf16* ta = Ts + (buf * 2 + 0) * 2 * HALF;
+        const __bf16* tb = Ts + (buf * 2 + 1) * 2 * HALF;
+        // lane (li, kg): k slots = the 8 rows of row blocks 2 kg and 2 kg + 1, for its column
+        auto frag = [&](const __bf16* tile, int col) {
+            const bf16x4 p = *(const bf16x4*)(tile + ((2 * kg) * BM + col) * 4);
+            const bf16x4 q = *(const bf16x4*)(tile + ((2 * kg + 1) * BM + col) * 4);
+            bf16x8 f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { f[e] = p[e]; f[4 + e] = q[e]; }
+            return f;
+        };
+        bf16x8 ah[4], al_[4], bh[2], bl[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ah[i] = frag(ta, wm + 16 * i + li); al_[i] = frag(ta + HALF, wm + 16 * i + li); }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { bh[j] = frag(tb, wn + 16 * j + li); bl[j] = frag(tb + HALF, wn + 16 * j + li); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al_[i], bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+        if (kt + 1 < nk) sstore(buf ^ 1);
+        __syncthreads();
+    }
+    // D: col = lane&15 (n), row = 4*(lane>>4)+reg (m)
+    const int cn = lane & 15, cr = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn + 16 * j + cn;
+            if (n >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm + 16 * i + cr + r;
+                if (m < M) atomicAdd(C + (size_t)m * ldc + n, acc[i][j][r]);
+            }
+        }
+    if (colsum != nullptr && blockIdx.y == 0) {   // A-staging threads with the same mg hold partial sums of the same 4 columns
+        __syncthreads();
+        float* red = smem;
+        for (int i = t; i < BM; i += NT_THREADS) red[i] = 0.f;
+        __syncthreads();
+        if (!is_b)
+            for (int e = 0; e < 4; ++e) atomicAdd(&red[4 * mg + e], csum[e]);
+        __syncthreads();
+        for (int i = t; i < BM; i += NT_THREADS)
+            if (m0 + i < M && red[i] != 0.f) atomicAdd(colsum + m0 + i, red[i]);
+    }
+}
+
 }  // namespace
 
 extern "C" int mp_gemm_nt(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
@@ -246,6 +486,22 @@ extern "C" int mp_gemm_nt(const float* A, int lda, const float* B, int ldb, floa
                            A, lda, B, ldb, C, ldc, M, N, K, bias, bias_rows, accumulate, relu);
     else
         hipLaunchKernelGGL(k_gemm_nt<false>, dim3((M + BM - 1) / BM, (N + BN - 1) / BN), dim3(NT_THREADS), LDS_NT, (hipStream_t)stream,
+                           A, lda, B, ldb, C, ldc, M, N, K, bias, bias_rows, accumulate, relu);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_gemm_nt_bf16x3(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+                                 const float* bias, int bias_rows, int accumulate, int relu, void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    constexpr int LDS_B3 = 2 * 2 * (BM + BN) * LDK16 * 2;   // 2 stages x (hi, lo) x (A, B) tiles of bf16
+    MP_LDS_ATTR((k_gemm_nt_b3<true>), LDS_B3);
+    MP_LDS_ATTR((k_gemm_nt_b3<false>), LDS_B3);
+    const bool fast = (lda & 3) == 0 && (ldb & 3) == 0 && ((size_t)A & 15) == 0 && ((size_t)B & 15) == 0 && K % BK == 0;
+    if (fast)
+        hipLaunchKernelGGL(k_gemm_nt_b3<true>, dim3((M + BM - 1) / BM, (N + BN - 1) / BN), dim3(NT_THREADS), LDS_B3, (hipStream_t)stream,
+                           A, lda, B, ldb, C, ldc, M, N, K, bias, bias_rows, accumulate, relu);
+    else
+        hipLaunchKernelGGL(k_gemm_nt_b3<false>, dim3((M + BM - 1) / BM, (N + BN - 1) / BN), dim3(NT_THREADS), LDS_B3, (hipStream_t)stream,
                            A, lda, B, ldb, C, ldc, M, N, K, bias, bias_rows, accumulate, relu);
     return (int)hipGetLastError();
 }
@@ -270,6 +526,29 @@ extern "C" int mp_gemm_tn(const float* A, int lda, const float* B, int ldb, floa
                            ldc, M, N, K, rows, colsum, colsum_rows);
     else
         hipLaunchKernelGGL(k_gemm_tn<false>, dim3((M + BM - 1) / BM, (N + BN - 1) / BN, slices), dim3(NT_THREADS), LDS_TN,
+                           (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, rows, colsum, colsum_rows);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_gemm_tn_bf16x3(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+                                 float* colsum, int colsum_rows, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    int slices = (512 + tiles - 1) / tiles;
+    int rows = (K + slices - 1) / slices;
+    rows = (rows + BK - 1) / BK * BK;
+    if (rows < 4 * BK) rows = 4 * BK;
+    slices = (K + rows - 1) / rows;
+    constexpr int LDS_B3 = 2 * 2 * 2 * (BK / 4) * BM * 4 * 2;   // 2 stages x (A, B) x (hi, lo) x [BK/4][128][4] bf16
+    MP_LDS_ATTR((k_gemm_tn_b3<true>), LDS_B3);
+    MP_LDS_ATTR((k_gemm_tn_b3<false>), LDS_B3);
+    const bool fast = (lda & 3) == 0 && (ldb & 3) == 0 && ((size_t)A & 15) == 0 && ((size_t)B & 15) == 0 && M % BM == 0 &&
+                      N % BN == 0;
+    if (fast)
+        hipLaunchKernelGGL(k_gemm_tn_b3<true>, dim3(M / BM, N / BN, slices), dim3(NT_THREADS), LDS_B3, (hipStream_t)stream, A, lda, B, ldb,
+                           C, ldc, M, N, K, rows, colsum, colsum_rows);
+    else
+        hipLaunchKernelGGL(k_gemm_tn_b3<false>, dim3((M + BM - 1) / BM, (N + BN - 1) / BN, slices), dim3(NT_THREADS), LDS_B3,
                            (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, rows, colsum, colsum_rows);
     return (int)hipGetLastError();
 }

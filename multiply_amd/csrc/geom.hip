@@ -814,6 +814,126 @@ __global__ void k_hits_from_index(const int* __restrict__ hit_index, int n_hit, 
     }
 }
 
+// ---- minimum-volume oriented box from the convex hull (multiply.py:208-214: trimesh's bounding_box_oriented) -------------
+// The box is flush with a hull facet; on that facet's plane the minimum-area rectangle has a side along (the projection of) a
+// SILHOUETTE edge of the hull (multiply_amd/obb.py, the published algorithm).  The hull comes from the host (Qhull, ~3 ms);
+// the search -- facets x silhouette edges x hull vertices, ~10^7..10^8 fp64 operations that took the host 50 ms in numpy --
+// runs here, one workgroup per facet normal, in the same order of preference as the host statement (first minimal edge per
+// normal, first minimal normal), in double precision like it.
+constexpr int OBB_T = 256;
+__device__ __forceinline__ void obb_frame(const double* n, const double* e, double* d, double* w, bool& ok) {
+    const double en = e[0] * n[0] + e[1] * n[1] + e[2] * n[2];
+    d[0] = e[0] - en * n[0]; d[1] = e[1] - en * n[1]; d[2] = e[2] - en * n[2];
+    const double ln = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    ok = ln > 1e-12;
+    const double inv = ok ? 1.0 / ln : 0.0;
+    d[0] *= inv; d[1] *= inv; d[2] *= inv;
+    w[0] = n[1] * d[2] - n[2] * d[1]; w[1] = n[2] * d[0] - n[0] * d[2]; w[2] = n[0] * d[1] - n[1] * d[0];
+}
+__global__ __launch_bounds__(OBB_T) void k_obb_hull_search(const double* __restrict__ hv, int H, const double* __restrict__ normals,
+                                                           const double* __restrict__ evec, const double* __restrict__ ena,
+                                                           const double* __restrict__ enb, int E, double* __restrict__ work) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* sh = (double*)smem;                      // [H][3] hull vertices
+    __shared__ double r_val[OBB_T];
+    __shared__ int r_idx[OBB_T];
+    __shared__ double r_lo[OBB_T], r_hi[OBB_T];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const double n[3] = {normals[3 * b], normals[3 * b + 1], normals[3 * b + 2]};
+    for (int i = t; i < 3 * H; i += OBB_T) sh[i] = hv[i];
+    __syncthreads();
+    double lo = 1e300, hi = -1e300;
+    for (int i = t; i < H; i += OBB_T) {
+        const double h = sh[3 * i] * n[0] + sh[3 * i + 1] * n[1] + sh[3 * i + 2] * n[2];
+        lo = fmin(lo, h); hi = fmax(hi, h);
+    }
+    double best = 1e300;
+    int best_e = 0x7fffffff;
+    for (int e = t; e < E; e += OBB_T) {
+        const double sa = ena[3 * e] * n[0] + ena[3 * e + 1] * n[1] + ena[3 * e + 2] * n[2];
+        const double sb = enb[3 * e] * n[0] + enb[3 * e + 1] * n[1] + enb[3 * e + 2] * n[2];
+        if (!(sa * sb <= 1e-12)) continue;           // both facets face the same way: not on the silhouette
+        double d[3], w[3];
+        bool ok;
+        obb_frame(n, evec + 3 * e, d, w, ok);
+        if (!ok) continue;
+        double ulo = 1e300, uhi = -1e300, wlo = 1e300, whi = -1e300;
+        for (int i = 0; i < H; ++i) {
+            const double x = sh[3 * i], y = sh[3 * i + 1], z = sh[3 * i + 2];
+            const double pu = x * d[0] + y * d[1] + z * d[2], pw = x * w[0] + y * w[1] + z * w[2];
+            ulo = fmin(ulo, pu); uhi = fmax(uhi, pu); wlo = fmin(wlo, pw); whi = fmax(whi, pw);
+        }
+        const double area = (uhi - ulo) * (whi - wlo);
+        if (area < best) { best = area; best_e = e; }          // ascending e per thread: the first minimal edge wins a tie
+    }
+    r_val[t] = best; r_idx[t] = best_e; r_lo[t] = lo; r_hi[t] = hi;
+    __syncthreads();
+    for (int s = OBB_T / 2; s > 0; s >>= 1) {
+        if (t < s) {
+            if (r_val[t + s] < r_val[t] || (r_val[t + s] == r_val[t] && r_idx[t + s] < r_idx[t])) { r_val[t] = r_val[t + s]; r_idx[t] = r_idx[t + s]; }
+            r_lo[t] = fmin(r_lo[t], r_lo[t + s]); r_hi[t] = fmax(r_hi[t], r_hi[t + s]);
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        work[2 * b] = r_idx[0] == 0x7fffffff ? 1e300 : r_val[0] * (r_hi[0] - r_lo[0]);   // volume of this facet's best box
+        work[2 * b + 1] = (double)r_idx[0];
+    }
+}
+__global__ __launch_bounds__(OBB_T) void k_obb_hull_pick(const double* __restrict__ hv, int H, const double* __restrict__ normals, int N,
+                                                         const double* __restrict__ evec, const double* __restrict__ work,
+                                                         float inflate, float* __restrict__ obb) {
+    __shared__ double r_val[OBB_T];
+    __shared__ int r_idx[OBB_T];
+    __shared__ double r_lo[3][OBB_T], r_hi[3][OBB_T];
+    const int t = threadIdx.x;
+    double best = 1e300;
+    int bi = 0x7fffffff;
+    for (int b = t; b < N; b += OBB_T)
+        if (work[2 * b] < best) { best = work[2 * b]; bi = b; }
+    r_val[t] = best; r_idx[t] = bi;
+    __syncthreads();
+    for (int s = OBB_T / 2; s > 0; s >>= 1) {
+        if (t < s && (r_val[t + s] < r_val[t] || (r_val[t + s] == r_val[t] && r_idx[t + s] < r_idx[t]))) { r_val[t] = r_val[t + s]; r_idx[t] = r_idx[t + s]; }
+        __syncthreads();
+    }
+    const int b = r_idx[0];
+    if (b == 0x7fffffff) {                            // degenerate hull: no candidate (never for a body)
+        if (t < 16) obb[t] = 0.0f;
+        return;
+    }
+    const int e = (int)work[2 * b + 1];
+    double ax[3][3];
+    ax[0][0] = normals[3 * b]; ax[0][1] = normals[3 * b + 1]; ax[0][2] = normals[3 * b + 2];
+    bool ok;
+    obb_frame(ax[0], evec + 3 * e, ax[1], ax[2], ok);
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int i = t; i < H; i += OBB_T)
+        for (int k = 0; k < 3; ++k) {
+            const double p = hv[3 * i] * ax[k][0] + hv[3 * i + 1] * ax[k][1] + hv[3 * i + 2] * ax[k][2];
+            lo[k] = fmin(lo[k], p); hi[k] = fmax(hi[k], p);
+        }
+    for (int k = 0; k < 3; ++k) { r_lo[k][t] = lo[k]; r_hi[k][t] = hi[k]; }
+    __syncthreads();
+    for (int s = OBB_T / 2; s > 0; s >>= 1) {
+        if (t < s)
+            for (int k = 0; k < 3; ++k) { r_lo[k][t] = fmin(r_lo[k][t], r_lo[k][t + s]); r_hi[k][t] = fmax(r_hi[k][t], r_hi[k][t + s]); }
+        __syncthreads();
+    }
+    if (t == 0) {
+        double c[3] = {0, 0, 0};
+        for (int k = 0; k < 3; ++k) {
+            const double m = 0.5 * (r_lo[k][0] + r_hi[k][0]);
+            for (int a = 0; a < 3; ++a) c[a] += m * ax[k][a];
+        }
+        for (int a = 0; a < 3; ++a) obb[a] = (float)c[a];
+        for (int k = 0; k < 3; ++k)
+            for (int a = 0; a < 3; ++a) obb[3 + 3 * k + a] = (float)ax[k][a];
+        for (int k = 0; k < 3; ++k) obb[12 + k] = (float)(0.5 * (r_hi[k][0] - r_lo[k][0]) * (double)inflate);
+        obb[15] = 0.0f;
+    }
+}
+
 int warp_grid(int n_slab, int nw) {
     int g = (n_slab + nw - 1) / nw;
     return g < 1 ? 1 : (g > 256 ? 256 : g);
@@ -849,6 +969,21 @@ extern "C" int mp_knn_build(const float* verts, const int* perm, float* vsorted,
 
 extern "C" int mp_obb(const float* verts, float inflate, float* obb, void* stream) {
     hipLaunchKernelGGL(k_obb, dim3(1), dim3(256), 0, (hipStream_t)stream, verts, inflate, obb);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_obb_hull(const double* hull_verts, int n_hull_verts, const double* normals, int n_normals, const double* edge_vec,
+                           const double* edge_na, const double* edge_nb, int n_edges, float inflate, double* work, float* obb,
+                           void* stream) {
+    if (n_hull_verts < 4 || n_normals < 1 || n_edges < 1) return -1;
+    const int lds = n_hull_verts * 3 * (int)sizeof(double);
+    if (lds > 96 * 1024) return -2;                   // 4096 hull vertices; a posed SMPL body has a few hundred
+    hipStream_t st = (hipStream_t)stream;
+    MP_LDS_ATTR((k_obb_hull_search), 96 * 1024);
+    hipLaunchKernelGGL(k_obb_hull_search, dim3(n_normals), dim3(OBB_T), lds, st, hull_verts, n_hull_verts, normals, edge_vec, edge_na,
+                       edge_nb, n_edges, work);
+    hipLaunchKernelGGL(k_obb_hull_pick, dim3(1), dim3(OBB_T), 0, st, hull_verts, n_hull_verts, normals, n_normals, edge_vec, work,
+                       inflate, obb);
     return (int)hipGetLastError();
 }
 

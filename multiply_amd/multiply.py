@@ -111,12 +111,18 @@ class Multiply(nn.Module):
         self.mesh_face_vertices_list = [v[0][f] [None] for v, f in zip(self.mesh_v_cano_list, self.mesh_f_cano_list)]
         self.convergence_group = None
         self.obb_inflate = 1.2
-        # cull box (multiply.py:208-214): "pca" = principal-axes box on the device (k_obb; conservative, identical eval pixels),
-        # "hull" = the minimum-volume box trimesh's bounding_box_oriented computes, by the published algorithm on the host
-        # (multiply_amd/obb.py; one device sync + ~10-100 ms of CPU work per person and call, like the reference)
-        self.obb_mode = os.environ.get("MP_OBB_MODE", "pca")
+        # cull box (multiply.py:208-214): "hull" = the minimum-volume box trimesh's bounding_box_oriented computes, by the published
+        # algorithm (multiply_amd/obb.py: Qhull on the host, one extra device sync + ~3 ms per person and call; the candidate search
+        # on the device, mp_obb_hull); "pca" = principal-axes box, device only (k_obb; conservative: identical eval pixels).
+        # "auto" (default): the reference's box wherever the hit set changes the result -- TRAINING mode, where no outlier override
+        # exists (multiply.py:142-143 is eval-only) and the rays a person is sampled on enter the loss -- and the device-only box
+        # in eval mode, where both give the same pixels (test_forward_eval_box_cull_is_conservative).
+        self.obb_mode = os.environ.get("MP_OBB_MODE", "auto")
         # eval-mode refinement of the box cull that provably leaves every pixel unchanged (mp_ray_cull_near); 0 = box only
         self.near_cull = os.environ.get("MP_NEAR_CULL", "1") != "0"
+        # ray-sharded data-parallel training: a torch.distributed process group (or True = the default group) over which the
+        # sampler's per-iteration convergence vote is all-reduced (MAX) -- see _sample_person; None: the vote is per process
+        self.sampler_vote_group = None
         self.last_stats = {}
         self.profile = False
         self.phase_events = {}
@@ -147,6 +153,11 @@ class Multiply(nn.Module):
         """{phase: (n_brackets, total ms)} of the events recorded since the last reset (synchronises)."""
         torch.cuda.synchronize()
         return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.phase_events.items()}
+
+    def _obb_mode_now(self):
+        if self.obb_mode not in ("auto", "hull", "pca"):
+            raise ValueError(f"obb_mode {self.obb_mode!r}: expected 'auto', 'hull' or 'pca'")
+        return ("hull" if self.training else "pca") if self.obb_mode == "auto" else self.obb_mode
 
     def _sampler_cfg(self):
         rs = self.ray_sampler
@@ -280,9 +291,17 @@ class Multiply(nn.Module):
                 hip.check(L.mp_ray_hits_from_index(hip.ptr(hit_index), hi.numel(), R, hip.ptr(counts[n:n + 1]),
                                                    hip.ptr(inv_index), st), "mp_ray_hits_from_index")
             else:
-                if self.obb_mode == "hull":
-                    from .obb import obb_record
-                    obb = torch.from_numpy(obb_record(verts.cpu().numpy(), self.obb_inflate)).to(dev)
+                if self._obb_mode_now() == "hull":
+                    # hull on the host (Qhull, ~3 ms; the one extra device sync of this mode), search + box on the device
+                    from .obb import hull_search_inputs
+                    buf, nh, nn_, ne = hull_search_inputs(verts.cpu().numpy())
+                    hb = torch.from_numpy(buf).to(dev)
+                    o_n, o_e = 3 * nh, 3 * (nh + nn_)
+                    work = torch.empty(2 * nn_, dtype=torch.float64, device=dev)
+                    obb = torch.empty(16, **f32)
+                    hip.check(L.mp_obb_hull(hip.ptr(hb), nh, hip.ptr(hb[o_n:]), nn_, hip.ptr(hb[o_e:]), hip.ptr(hb[o_e + 3 * ne:]),
+                                            hip.ptr(hb[o_e + 6 * ne:]), ne, C.c_float(self.obb_inflate), hip.ptr(work),
+                                            hip.ptr(obb), st), "mp_obb_hull")
                 else:
                     obb = torch.empty(16, **f32)
                     hip.check(L.mp_obb(hip.ptr(verts), C.c_float(self.obb_inflate), hip.ptr(obb), st), "mp_obb")
@@ -361,6 +380,14 @@ class Multiply(nn.Module):
             with self._ph("sampler_bound"):
                 hip.check(L.mp_sampler_bound(C.byref(cfg), C.byref(state), hip.ptr(beta), hip.ptr(pp["hit_index"]),
                                              hip.ptr(pp["count"]), Rp, group, R, it, st), "mp_sampler_bound")
+            if self.sampler_vote_group is not None:
+                # ray-sharded data parallelism: the reference's convergence vote (`not_converge = beta.max() > beta0`,
+                # ray_sampler.py:137) spans ALL rays of the call -- here the rays of every rank.  One MAX all-reduce of this
+                # iteration's group flags (n_groups ints, 1 in training) between the bound and the resampling kernels makes the
+                # N-rank step sample exactly like the single-process step (option (a)).
+                import torch.distributed as dist
+                grp = None if self.sampler_vote_group is True else self.sampler_vote_group
+                dist.all_reduce(gflag[it * n_groups:(it + 1) * n_groups], op=dist.ReduceOp.MAX, group=grp)
             with self._ph("sampler_resample"):
                 hip.check(L.mp_sampler_resample(C.byref(cfg), C.byref(state), hip.ptr(beta), hip.ptr(far),
                                                 hip.ptr(pp["hit_index"]), hip.ptr(pp["count"]), Rp, group, R, it,
@@ -368,9 +395,9 @@ class Multiply(nn.Module):
         pp["_sampler_keep"] = (zs, sdfs, nz, znew, sdfnew, betar, active, gflag, any_active, xc_new, work, draws)
         return zfinal, iters, wcount
 
-    def sample_rays(self, ray_dirs, cam_loc, cond, smpl_tfs, smpl_verts, person_id):
+    def sample_rays(self, ray_dirs, cam_loc, cond, smpl_tfs, smpl_verts, person_id, draws=None):
         """The sampler on explicit rays, outside forward(): what ErrorBoundSampler.get_z_vals(ray_dirs, cam_loc, model, cond,
-        smpl_tfs, eval_mode, smpl_verts, person_id) does in the reference (ray_sampler.py:66-220) for ONE person, eval mode:
+        smpl_tfs, eval_mode, smpl_verts, person_id) does in the reference (ray_sampler.py:66-220) for ONE person (draws = None: eval mode):
         every ray is sampled (no box cull), the convergence vote spans the call.  ray_dirs (R,3) unit vectors, cam_loc (3,)
         or (R,3) with equal rows, cond the pose conditioning (69,) / {'smpl': (1,69)}, smpl_tfs (1,24,4,4), smpl_verts
         (1,6890,3) posed vertices.  -> z_vals (R, N_samples + N_samples_extra + 2) sorted depths."""
@@ -404,8 +431,8 @@ class Multiply(nn.Module):
                                hit_index=torch.arange(R, **i32), count=torch.full((1,), R, **i32), cond=cvec)}
         cx = dict(dev=dev, R=R, pose=pose.reshape(16).contiguous(), dirs=dirs, far=far, per=per, persons=[person_id], n_hit=[R],
                   group=R, beta=beta)
-        with torch.no_grad():
-            zfinal, _, _ = self._sample_person(cx, 0, person_id)
+        with torch.no_grad():      # draws (training mode): {t_rand [R,NE], u_final [R,N], extra_idx [max_iters,N_extra] int32}
+            zfinal, _, _ = self._sample_person(cx, 0, person_id, draws)
         return zfinal
 
     def _forward_eval(self, input, id, canonical_pose, composite=True):

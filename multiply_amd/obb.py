@@ -12,9 +12,11 @@ never built: an edge of the projection's hull is the projection of a SILHOUETTE 
 face opposite ways with respect to n), so those edges are the candidate directions -- a superset of the 2-D hull's edges cannot
 beat the optimum, which the theorem places ON a hull edge.
 
-This is the parity route of the cull (`Multiply.obb_mode = "hull"`): it needs the posed vertices on the host (one device
-sync per person and call) and ~10-20 ms of CPU work, like the reference's own trimesh call.  The default cull
-(`"pca"`, csrc/geom.hip k_obb) stays on the device; it is proven conservative for eval renders (identical pixels)."""
+`Multiply.obb_mode = "hull"` (the default in training mode, where the hit set decides which samples exist): the HULL is built
+on the host (Qhull, ~3 ms for a posed body; needs the posed vertices there: one device sync per person and call, like the
+reference's own trimesh call), the candidate search and the box run on the device in fp64 (csrc/geom.hip mp_obb_hull; the
+numpy statement below, `min_volume_obb`, takes 50 ms and stays as the host-side cross-check of that kernel).  `"pca"`
+(csrc/geom.hip k_obb) never leaves the device; it is proven conservative for eval renders (identical pixels)."""
 import numpy as np
 
 
@@ -23,13 +25,12 @@ def _hull(points):
     return ConvexHull(points)
 
 
-def min_volume_obb(points):
-    """points (V, 3) -> (centre (3,), axes (3, 3) rows = unit box axes, half_extents (3,)), float64.
-    The first axis is the winning hull-facet normal, the other two span its plane (the rectangle's sides)."""
+def _hull_parts(points):
+    """hull vertices (H, 3), distinct facet normals in order of first appearance (N, 3; one of +n / -n), and per hull edge its
+    vector and the normals of its two facets (E, 3 each) -- float64"""
     p = np.asarray(points, dtype=np.float64)
     hull = _hull(p)
-    hv_idx = hull.vertices
-    hv = p[hv_idx]                                                   # (H, 3) hull vertices
+    hv = p[hull.vertices]
     # unique facet normals (Qhull triangulates coplanar facets: merge them; keep one of +n / -n)
     n_all = hull.equations[:, :3]
     flip = (n_all[:, 0] < 0) | ((n_all[:, 0] == 0) & (n_all[:, 1] < 0)) | ((n_all[:, 0] == 0) & (n_all[:, 1] == 0) & (n_all[:, 2] < 0))
@@ -45,10 +46,25 @@ def min_volume_obb(points):
     assert e.shape[0] % 2 == 0 and np.array_equal(e[0::2], e[1::2]), "hull is not a closed 2-manifold"
     edges, fa, fb = e[0::2], fid[0::2], fid[1::2]
     evec = p[edges[:, 1]] - p[edges[:, 0]]                           # (E, 3)
-    best = (np.inf, None)
     fn = hull.equations[:, :3]
+    return hv, normals, evec, fn[fa], fn[fb]
+
+
+def hull_search_inputs(points):
+    """the five fp64 arrays mp_obb_hull reads (include/multiply_hip.h), as ONE contiguous float64 buffer + their row counts:
+    [hull_verts | normals | edge_vec | edge_na | edge_nb] -- one host-to-device copy per person"""
+    hv, normals, evec, ena, enb = _hull_parts(points)
+    buf = np.ascontiguousarray(np.concatenate([hv, normals, evec, ena, enb]).reshape(-1), dtype=np.float64)
+    return buf, hv.shape[0], normals.shape[0], evec.shape[0]
+
+
+def min_volume_obb(points):
+    """points (V, 3) -> (centre (3,), axes (3, 3) rows = unit box axes, half_extents (3,)), float64.
+    The first axis is the winning hull-facet normal, the other two span its plane (the rectangle's sides)."""
+    hv, normals, evec, ena, enb = _hull_parts(points)
+    best = (np.inf, None)
     for n in normals:
-        sa, sb = fn[fa] @ n, fn[fb] @ n
+        sa, sb = ena @ n, enb @ n
         sil = (sa * sb <= 1e-12)                                     # facets facing opposite ways (or edge-on): silhouette
         d = evec[sil]
         d = d - np.outer(d @ n, n)                                   # candidate side directions in the plane

@@ -283,3 +283,145 @@ class PersonShardedGradSync:
         for p in self.params:
             p.grad = self.flat[o:o + p.numel()].reshape(p.shape).clone()
             o += p.numel()
+
+
+# ======================================================================================================================
+# Frame-sharded data parallelism and the epoch-level stages under it (last paragraph).
+#
+# One optimiser step of the reference handles ONE frame (multiply_model.py:131-222: batch size 1, 512 pixels).  With N ranks a
+# step handles N frames, one per rank: every rank runs forward + loss + backward on its own frame -- the per-frame rows of the
+# BodyModelParams tables included -- and ONE flat all-reduce averages the gradients of the shared networks AND of the body-model
+# tables (a rank's table gradient is non-zero in its own frame's rows only; the tables are small -- frames x 85 floats per
+# person -- so they ride dense in the same flat buffer instead of a sparse exchange).  Every rank then takes the same optimiser
+# step on the same averaged gradients: the replicas stay bit-identical without a parameter broadcast.
+#
+# The stages between epochs -- canonical-mesh extraction every 20 epochs, instance masks / SAM prompts every 50
+# (multiply_model.py:489-518) -- are single-GPU work whose PRODUCTS every rank needs: rank `src` runs them, the products (a few
+# tensors of data-dependent shape) are broadcast.
+# ======================================================================================================================
+_DTYPES = [torch.float32, torch.float64, torch.float16, torch.bfloat16, torch.int64, torch.int32, torch.int16, torch.int8,
+           torch.uint8, torch.bool]
+
+
+def broadcast_tensors(tensors, src=0, group=None, device=None):
+    """A list of tensors whose NUMBER, SHAPES and DTYPES only rank `src` knows (the other ranks pass None) -> the same list on
+    every rank.  Two collectives: one int64 header (count; per tensor dtype code, ndim, up to 8 extents), one byte payload."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return list(tensors)
+    rank = dist.get_rank(group)
+    MAXT, MAXD = 64, 8
+    if rank == src:
+        tensors = [t.detach().contiguous() for t in tensors]
+        assert len(tensors) <= MAXT and all(t.dim() <= MAXD for t in tensors)
+        device = tensors[0].device if tensors and device is None else device
+        hdr = torch.zeros(1 + MAXT * (2 + MAXD), dtype=torch.int64)
+        hdr[0] = len(tensors)
+        for i, t in enumerate(tensors):
+            o = 1 + i * (2 + MAXD)
+            hdr[o], hdr[o + 1] = _DTYPES.index(t.dtype), t.dim()
+            for d, e in enumerate(t.shape):
+                hdr[o + 2 + d] = e
+    else:
+        hdr = torch.zeros(1 + MAXT * (2 + MAXD), dtype=torch.int64)
+    if device is None:
+        device = torch.device("cpu")
+    hdr = hdr.to(device)
+    dist.broadcast(hdr, src=src, group=group)
+    h = hdr.cpu().tolist()
+    metas = []
+    for i in range(h[0]):
+        o = 1 + i * (2 + MAXD)
+        metas.append((_DTYPES[h[o]], tuple(h[o + 2:o + 2 + h[o + 1]])))
+    nbytes = [torch.empty(0, dtype=dt).element_size() * int(torch.Size(sh).numel()) for dt, sh in metas]
+    # every piece starts on a 16-byte boundary of the payload so that its typed view is aligned
+    offs, total = [], 0
+    for n in nbytes:
+        offs.append(total)
+        total += (n + 15) // 16 * 16
+    payload = torch.zeros(max(total, 16), dtype=torch.uint8, device=device)
+    if rank == src:
+        for t, o, n in zip(tensors, offs, nbytes):
+            if n:
+                payload[o:o + n] = t.to(device).reshape(-1).view(torch.uint8) if t.dtype != torch.bool else t.to(device).reshape(-1).to(torch.uint8)
+    dist.broadcast(payload, src=src, group=group)
+    out = []
+    for (dt, sh), o, n in zip(metas, offs, nbytes):
+        raw = payload[o:o + n]
+        out.append((raw.to(torch.bool) if dt == torch.bool else raw.view(dt)).reshape(sh).clone())
+    return out
+
+
+def refresh_canonical_meshes_broadcast(model, conds=None, res_up=2, src=0, group=None, extract=None):
+    """The every-20-epochs stage under data parallelism (multiply_model.py:497-506): rank `src` re-extracts every person's
+    canonical mesh (multiply_amd.mesh.refresh_canonical_meshes: MISE + marching cubes on the device), the vertex and face arrays
+    are broadcast, EVERY rank re-assigns mesh_v_cano_list / mesh_f_cano_list / mesh_face_vertices_list (read by the in / off-
+    surface flags of the next 20 epochs' training forwards, multiply.py:153-167).  `extract(model)` -> (vertex list, face list)
+    replaces the extractor (tests)."""
+    rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+    dev = model.density.beta.device
+    items = None
+    if rank == src:
+        if extract is None:
+            from .mesh import refresh_canonical_meshes
+            vs, fs = refresh_canonical_meshes(model, conds, res_up)
+        else:
+            vs, fs = extract(model)
+        items = [t for v, f in zip(vs, fs) for t in (v, f)]
+    items = broadcast_tensors(items, src=src, group=group, device=dev)
+    vs, fs = [t.to(dev) for t in items[0::2]], [t.to(dev) for t in items[1::2]]
+    model.mesh_v_cano_list, model.mesh_f_cano_list = vs, fs
+    model.mesh_face_vertices_list = [v[0][f][None] for v, f in zip(vs, fs)]
+    return vs, fs
+
+
+def frame_instance_masks_broadcast(model, inputs, use_smpl_mesh, res_up=2, src=0, group=None, produce=None):
+    """The every-50-epochs stage (multiply_model.py:741-939, one frame of get_instance_mask): rank `src` rasterises the persons'
+    meshes (multiply_amd.mesh_losses.frame_instance_masks), every rank receives the instance masks (P,H,W) bool, the depth maps
+    and the 27 projected key points per person -- what the SAM prompts and the data set's mask refresh are built from."""
+    rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+    dev = model.density.beta.device
+    items = None
+    if rank == src:
+        if produce is None:
+            from .mesh_losses import frame_instance_masks
+            masks, depth, kps = frame_instance_masks(model, inputs, use_smpl_mesh, res_up)
+        else:
+            masks, depth, kps = produce(model, inputs)
+        items = [masks, torch.stack(list(depth), 0), kps]
+    masks, depth, kps = broadcast_tensors(items, src=src, group=group, device=dev)
+    return masks, list(depth), kps
+
+
+class FrameShardedTrainer:
+    """One data-parallel optimiser step over N frames, one per rank (see the section comment).  `params` = the shared networks'
+    parameters AND the BodyModelParams tables that are being optimised; `optimizers` are stepped by every rank on the averaged
+    gradients.  step(inputs, targets, frame_idx) -> the loss dict of this rank's frame."""
+
+    def __init__(self, model, body_model_list, loss_fn, optimizers, vote_group=None):
+        self.model, self.body, self.loss_fn, self.opts = model, list(body_model_list), loss_fn, list(optimizers)
+        params = [p for p in model.parameters() if p.requires_grad]
+        params += [p for bm in self.body for p in bm.parameters() if p.requires_grad]
+        self.sync = GradientAllReduce(params)
+        self.vote_group = vote_group
+
+    def step(self, inputs, targets, frame_idx, sync=True):
+        """sync=False: no collective and no optimiser step -- the plain single-process gradient of this frame (tests)"""
+        from .mesh_losses import body_model_inputs
+        inp = dict(inputs)
+        if self.body:
+            idx = torch.as_tensor(frame_idx, device=self.model.density.beta.device).reshape(1).long()
+            inp["smpl_trans"], inp["smpl_shape"], inp["smpl_pose"] = body_model_inputs(self.body, idx)
+            last = torch.clamp(idx - 1, min=0)                                  # multiply_model.py:170-178
+            with torch.no_grad():
+                _, _, inp["smpl_pose_last"] = body_model_inputs(self.body, last)
+        self.model.train()
+        out = self.model(inp)
+        lo = self.loss_fn(out, targets)
+        for p in self.sync.params:
+            p.grad = None
+        lo["loss"].backward()
+        if sync:
+            self.sync()                                                          # ONE flat all-reduce: networks + body tables
+            for o in self.opts:
+                o.step()
+        return lo

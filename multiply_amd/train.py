@@ -38,14 +38,28 @@ def _chk(code, what):
         print("[mp sync ok]", what, flush=True)
 
 
+# Arithmetic of the training GEMMs (csrc/gemm.hip):
+#   "bf16x3" (default): every fp32 operand split into two bfloat16 halves on its way into LDS, three 16-bit MFMAs per product
+#            (hi.hi + hi.lo + lo.hi), fp32 accumulation: ~2^-16 relative per product, the range of fp32 (no loss scaling),
+#            5x less matrix-pipe time than the exact-fp32 instruction -- the GEMMs run at the rate HBM delivers their operands;
+#   "f32":   v_mfma_f32_16x16x4_f32, bitwise an fmaf chain -- the cross-check (tests/test_train_step_gpu.py runs both).
+TRAIN_PRECISION = __import__("os").environ.get("MP_TRAIN_PRECISION", "bf16x3")
+
+
 def gemm_nt(A, lda, B, ldb, Cm, ldc, M, N, K, bias=None, bias_rows=0, accumulate=False, relu=False):
-    _chk(hip.lib().mp_gemm_nt(A, lda, B, ldb, Cm, ldc, M, N, K, bias, bias_rows, int(accumulate), int(relu),
-                              hip.stream()), "mp_gemm_nt")
+    if TRAIN_PRECISION == "f32":
+        fn, name = hip.lib().mp_gemm_nt, "mp_gemm_nt"
+    elif TRAIN_PRECISION == "bf16x3":
+        fn, name = hip.lib().mp_gemm_nt_bf16x3, "mp_gemm_nt_bf16x3"
+    else:
+        raise ValueError(f"MP_TRAIN_PRECISION {TRAIN_PRECISION!r}: expected 'bf16x3' or 'f32'")
+    _chk(fn(A, lda, B, ldb, Cm, ldc, M, N, K, bias, bias_rows, int(accumulate), int(relu), hip.stream()), name)
 
 
 def gemm_tn(A, lda, B, ldb, Cm, ldc, M, N, K, colsum=None, colsum_rows=0):
     """Cm[M,N] += A[K,M]^T B[K,N];  colsum[M] += column sums of A's first colsum_rows rows (the bias gradient)"""
-    _chk(hip.lib().mp_gemm_tn(A, lda, B, ldb, Cm, ldc, M, N, K, colsum, colsum_rows, hip.stream()), "mp_gemm_tn")
+    fn = hip.lib().mp_gemm_tn if TRAIN_PRECISION == "f32" else hip.lib().mp_gemm_tn_bf16x3
+    _chk(fn(A, lda, B, ldb, Cm, ldc, M, N, K, colsum, colsum_rows, hip.stream()), "mp_gemm_tn")
 
 
 def off(t, n_floats):

@@ -205,3 +205,67 @@ def test_interleaved_shards_gather_back_in_ray_order(n, group, gpr, world):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res)
+
+
+def _stage_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = True
+    # ---- tensors whose number / shapes / dtypes only the source knows
+    g = torch.Generator().manual_seed(3)
+    src_list = [torch.randn(1, 1234, 3, generator=g), torch.randint(0, 1234, (2466, 3), generator=g), torch.rand(2, 17, 19, generator=g) > 0.5,
+                torch.zeros(0, 3), torch.randn(5, generator=g).double(), torch.randint(0, 100, (2, 27, 2), generator=g).to(torch.int32)]
+    got = parallel.broadcast_tensors(src_list if rank == 1 else None, src=1)
+    ok = ok and len(got) == len(src_list) and all(a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b) for a, b in zip(got, src_list))
+
+    # ---- the every-20-epochs stage: rank 0 "extracts" (stand-in extractor), every rank ends up with the same three lists
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.density = torch.nn.Module()
+            self.density.beta = torch.nn.Parameter(torch.tensor(0.1))
+            self.mesh_v_cano_list, self.mesh_f_cano_list, self.mesh_face_vertices_list = [], [], []
+    m = M()
+    calls = []
+
+    def extract(model):
+        calls.append(rank)
+        gg = torch.Generator().manual_seed(11)
+        vs = [torch.randn(1, n, 3, generator=gg) for n in (700, 913)]
+        fs = [torch.randint(0, n, (f, 3), generator=gg) for n, f in ((700, 1396), (913, 1822))]
+        return vs, fs
+    vs, fs = parallel.refresh_canonical_meshes_broadcast(m, extract=extract)
+    ok = ok and calls == ([0] if rank == 0 else [])                                  # only the source ran the extractor
+    want_v, want_f = extract(None)
+    ok = ok and all(torch.equal(a, b) for a, b in zip(m.mesh_v_cano_list, want_v)) and all(torch.equal(a, b) for a, b in zip(m.mesh_f_cano_list, want_f))
+    ok = ok and [tuple(t.shape) for t in m.mesh_face_vertices_list] == [(1, 1396, 3, 3), (1, 1822, 3, 3)]
+    ok = ok and torch.equal(m.mesh_face_vertices_list[1][0], want_v[1][0][want_f[1]])
+
+    # ---- the every-50-epochs stage: masks, depth maps, key points
+    def produce(model, inputs):
+        gg = torch.Generator().manual_seed(5)
+        depth = [torch.rand(24, 32, generator=gg) for _ in range(2)]
+        return torch.stack([d > 0.5 for d in depth]), depth, torch.randint(0, 32, (2, 27, 2), generator=gg).to(torch.int32)
+    masks, depth, kps = parallel.frame_instance_masks_broadcast(m, {}, True, produce=produce)
+    wm, wd, wk = produce(None, None)
+    ok = ok and masks.dtype == torch.bool and torch.equal(masks, wm) and all(torch.equal(a, b) for a, b in zip(depth, wd)) and torch.equal(kps, wk)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok))
+
+
+def test_epoch_stage_products_are_broadcast_from_the_producing_rank():
+    """frame-sharded data parallelism: canonical-mesh refresh and instance masks run on ONE rank, their
+    products -- tensors of data-dependent number, shape and dtype -- reach every rank bit for bit (gloo, 2 ranks)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_stage_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)

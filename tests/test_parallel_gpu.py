@@ -39,3 +39,15 @@ def test_person_sharded_training_matches_single_process():
     """loss, outputs and every local gradient of a person-sharded training step (one all_gather of the per-sample rows in the
     forward, one flat all-reduce of the background gradients after the backward) equal the single-process step"""
     _run_two_ranks("dist_person_sharded_train.py", 29950)
+
+
+def test_data_parallel_sampler_vote_reproduces_the_single_process_depths():
+    """ray-sharded DP training: one MAX all-reduce of the sampler's per-iteration convergence flag (ray_sampler.py:137) makes the
+    2-rank step sample bit for bit like the single-process step on all rays"""
+    _run_two_ranks("dist_sampler_vote.py", 30700)
+
+
+def test_frame_sharded_training_step_and_epoch_stage_broadcast():
+    """a step over two frames (one per rank, body-model table rows included, one flat all-reduce) equals the
+    mean of the single-frame gradients; the replicas stay identical after Adam; rank 0's canonical meshes reach rank 1"""
+    _run_two_ranks("dist_frame_sharded.py", 31100)

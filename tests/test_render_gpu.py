@@ -39,15 +39,13 @@ def report(name, got, want):
     # NaNs must appear at the same places (the reference filters them in the loss, loss.py:120)
     assert (got.isnan() == want.isnan()).all(), f"{name}: NaN pattern differs"
     e = (got - want).abs()
-    if e.dim() > 1:                       # per ray (pixel): the worst component
-        e = e.reshape(e.shape[0], -1).nan_to_num(nan=-1.0).max(dim=1).values
-        e = e[e >= 0]
-    else:
-        e = e[~e.isnan()]
-    st = TOL.Stats(e)
-    q = lambda f: float(torch.quantile(e, f)) if e.numel() else 0.0
-    print(f"[parity] {name}: max {st[0]:.3e} mean {st[1]:.3e} | p99 {q(0.99):.2e} p99.9 {q(0.999):.2e} | rays > 1e-2: "
-          f"{int((e > 1e-2).sum())} > 3e-3: {int((e > 3e-3).sum())} of {e.numel()}")
+    ray = e.reshape(e.shape[0], -1).nan_to_num(nan=-1.0).max(dim=1).values if e.dim() > 1 else e.nan_to_num(nan=-1.0)
+    ray = ray[ray >= 0]                   # the worst element of every ray (row)
+    e = e[~e.isnan()]
+    st = TOL.Stats(e, ray)
+    q = lambda f: float(torch.quantile(ray, f)) if ray.numel() else 0.0
+    print(f"[parity] {name}: max {st[0]:.3e} mean {st[1]:.3e} | rays: p99 {q(0.99):.2e} p99.9 {q(0.999):.2e}, > 1e-2: "
+          f"{int((ray > 1e-2).sum())}, > 3e-3: {int((ray > 3e-3).sum())} of {ray.numel()}")
     return st
 
 
@@ -404,9 +402,31 @@ def test_error_bound_sampler_public_entry_point():
         ref = torch.cat([want["z_vals"][p], want["z_max"][p][:, None]], 1)
         assert TOL.within(report(f"get_z_vals person {p} vs oracle", z, ref), TOL.Z_VALS)
         assert bool((z_eik >= z.min(1, keepdim=True).values).all()) and float(z_bg[0, -1]) == pytest.approx(1 / 3.0)
+    # training mode: the reference's random branches, draws taken inside get_z_vals; with the SAME draws handed to the oracle's
+    # sampler the depths agree like the in-forward training sampler's (tests/test_train_step_gpu.py)
     model.train()
-    with pytest.raises(NotImplementedError):
-        model.ray_sampler.get_z_vals(last["dirs"], cam[None], model, None, None, False, None, 0)
+    pp = last["per"][0]
+    cam = gin["pose"][0, :3, 3]
+    torch.manual_seed(77)
+    (z, z_bg), z_eik = model.ray_sampler.get_z_vals(last["dirs"], cam[None].expand(R, 3), model, {"smpl": pp["cond"][None]},
+                                                     pp["tfs"][None], False, pp["verts"][None], 0)
+    torch.cuda.synchronize()
+    rs = model.ray_sampler
+    torch.manual_seed(77)                                  # replay the draws get_z_vals consumed, in its order
+    t_rand, u_final = torch.rand(R, rs.N_samples_eval, device="cuda"), torch.rand(R, rs.N_samples, device="cuda")
+    extra = torch.stack([torch.randperm(rs.N_samples_eval * k, device="cuda")[:rs.N_samples_extra]
+                         for k in range(1, rs.max_total_iters + 1)])
+    so = oracle.servers[0].forward(inp["smpl_params"][0, 0, 0], inp["smpl_trans"][0, 0], inp["smpl_pose"][0, 0], inp["smpl_shape"][0, 0])
+    cond = inp["smpl_pose"][0, 0, 3:] / np.pi
+    dirs_o, cam_o = O.get_camera_rays(inp["uv"][0], inp["pose"][0], inp["intrinsics"][0])
+    fn = lambda pts: oracle.persons[0].sdf_func(pts, cond, so["smpl_tfs"], so["smpl_verts"], eval_mode=False)[0]
+    with torch.no_grad():
+        zo, _ = O.error_bound_sample(oracle.cfg, dirs_o, cam_o[None].expand(R, -1), fn, oracle.beta().detach(),
+                                     dict(t_rand=t_rand.cpu(), u_final=u_final.cpu(), extra_idx=extra.cpu().long()))
+    assert z.shape == zo.shape and bool((z[:, 1:] >= z[:, :-1]).all())
+    assert TOL.within(report("get_z_vals (training draws) person 0 vs oracle", z, zo), TOL.TRAIN_Z_VALS)
+    assert z_bg.shape == (R, 32) and bool((z_bg[:, 1:] > z_bg[:, :-1]).all()) and float(z_bg.max()) <= 1 / 3.0 + 1e-6
+    assert float((z_bg[0] - z_bg[1]).abs().max()) > 0     # jittered per ray
 
 
 def test_full_size_frame_properties():

@@ -12,6 +12,15 @@ from tests.util import seeded_networks
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _exact_fp32_gemms(monkeypatch):
+    """These are tests of the ALGEBRA of the hand-written forward / adjoint kernels against torch autograd at fp32-roundoff
+    tolerances, so the GEMMs between them run on the exact-fp32 matrix instruction (MP_TRAIN_PRECISION=f32); test_gemms checks
+    both GEMM arithmetics themselves, tests/test_train_step_gpu.py the whole training step in the default split-bf16 mode."""
+    from multiply_amd import train as T
+    monkeypatch.setattr(T, "TRAIN_PRECISION", "f32")
+
+
 def rel(name, got, want):
     got, want = got.double().cpu(), want.double().cpu()
     e = (got - want).abs().max().item() / (want.abs().max().item() + 1e-30)
@@ -19,25 +28,35 @@ def rel(name, got, want):
     return e
 
 
-def test_gemms():
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_gemms(precision, monkeypatch):
+    """exact-fp32 MFMA (bitwise an fmaf chain: 2e-6 / 2e-5 relative to the largest entry) and the split-bf16 path (three 16-bit
+    MFMAs per product, ~2^-16 per product: measured 4e-6 / 6e-6, asserted 3e-5) against a float64 product"""
     from multiply_amd import train as T
+    monkeypatch.setattr(T, "TRAIN_PRECISION", precision)
+    tol_nt, tol_tn = (2e-6, 2e-5) if precision == "f32" else (3e-5, 3e-5)
     torch.manual_seed(0)
     for (M, N, K) in [(1000, 257, 39), (4097, 256, 256), (300, 3, 256), (129, 130, 17)]:
         A = torch.randn(M, K, device="cuda"); B = torch.randn(N, K, device="cuda"); b = torch.randn(N, device="cuda")
         Cm = torch.empty(M, N, device="cuda")
         T.gemm_nt(T._p(A), K, T._p(B), K, T._p(Cm), N, M, N, K, T._p(b), M // 2)
-        want = A @ B.T
-        want[:M // 2] += b
-        assert rel(f"gemm_nt {M}x{N}x{K}", Cm, want) < 2e-6
+        want = (A.double() @ B.double().T)
+        want[:M // 2] += b.double()
+        assert rel(f"gemm_nt[{precision}] {M}x{N}x{K}", Cm, want) < tol_nt
         T.gemm_nt(T._p(A), K, T._p(B), K, T._p(Cm), N, M, N, K, None, 0, accumulate=True, relu=True)
-        assert rel("gemm_nt accumulate+relu", Cm, torch.relu(want + A @ B.T)) < 2e-6
+        assert rel("gemm_nt accumulate+relu", Cm, torch.relu(want + A.double() @ B.double().T)) < tol_nt
     for (M, N, K) in [(256, 256, 50000), (257, 39, 3000), (3, 128, 777), (256, 257, 100001)]:
         A = torch.randn(K, M, device="cuda"); B = torch.randn(K, N, device="cuda")
         Cm = torch.ones(M, N, device="cuda")
         cs = torch.zeros(M, device="cuda")
         T.gemm_tn(T._p(A), M, T._p(B), N, T._p(Cm), N, M, N, K, T._p(cs), K // 2)
-        assert rel(f"gemm_tn {M}x{N}x{K}", Cm, 1.0 + A.T @ B) < 2e-5
-        assert rel("gemm_tn fused column sum", cs, A[:K // 2].sum(0)) < 2e-5
+        assert rel(f"gemm_tn[{precision}] {M}x{N}x{K}", Cm, 1.0 + A.double().T @ B.double()) < tol_tn
+        assert rel("gemm_tn fused column sum", cs, A[:K // 2].double().sum(0)) < 2e-5
+    if precision == "bf16x3":      # the split keeps the RANGE of fp32: operands far below half precision's subnormals
+        A = torch.randn(2000, 256, device="cuda") * 1e-9; B = torch.randn(256, 256, device="cuda")
+        Cm = torch.empty(2000, 256, device="cuda")
+        T.gemm_nt(T._p(A), 256, T._p(B), 256, T._p(Cm), 256, 2000, 256, 256)
+        assert rel("gemm_nt[bf16x3] operands of magnitude 1e-9", Cm, A.double() @ B.double().T) < tol_nt
 
 
 def _implicit_torch(sd, prefix, x, cond, multires):

@@ -2,17 +2,28 @@
 
 The MLPs run with f16 MFMA operands and fp32 accumulation, everything else is fp32; the oracle is fp32 throughout.  Each
 bound is <= 5x the largest value MEASURED on MI355X over the test scenes (the measured figures are quoted beside it and in
-DESIGN.md §4), so that an order-of-magnitude regression of a kernel turns the suite red.  Isolated grazing rays dominate the
-max of the transmittance-like quantities (a sample's alpha flips between ~0 and ~1 with the f16 rounding of its sdf)."""
+DESIGN.md §4), so that an order-of-magnitude regression of a kernel turns the suite red."""
 
+def Dist(mean, bulk, frac, hard):
+    """distribution bound of a transmittance-like quantity: element mean < `mean`; at most the fraction `frac` of the rays
+    may have an element off by more than `bulk`; no element off by more than `hard`"""
+    return dict(mean=mean, bulk=bulk, frac=frac, hard=hard)
+
+
+# Transmittance-like quantities (opacities, normals, the foreground colour over a white background): a ray that GRAZES a
+# surface has one sample whose alpha flips between ~0 and ~1 with the f16 rounding of its sdf, so single rays can be off by
+# several 1e-2 while everything else agrees to 1e-3.  A worst-case bound alone would have to be ~0.1 and assert nothing:
+# these are bounded by their DISTRIBUTION instead.  Measured on MI355X (headline 1 024-ray scene / the 16 384-ray slow test,
+# profiles/r03_parity_16k.txt): 0.3-0.4 % of the rays above 1e-2 (99th percentile 2.5e-3), worst single ray 4.7e-2.
+_GRAZE = dict(bulk=1e-2, frac=0.02, hard=0.15)
 EVAL = {                                   # eval-mode Multiply.forward outputs, per pixel
     # largest measured over the test scenes   (max, mean)
-    "rgb_values": (8e-3, 3e-5),             # 1.7e-3, 6.2e-6   (headline N = 128 scene)
-    "fg_rgb_values": (0.15, 1e-3),          # 4.0e-2, 2.4e-4   fg + T_bg * 1: the transmittance error, undamped by a dark background
-    "acc_map": (0.15, 1e-3),                # 5.3e-2, 4e-4
-    "acc_person_list": (0.15, 1e-3),        # 4.7e-2, 1.4e-4
-    "bg_transmittance": (0.15, 1e-3),       # 4.9e-3, 1.2e-4
-    "normal_values": (0.15, 8e-4),          # 3.9e-2, 1.9e-4
+    "rgb_values": (8e-3, 3e-5),             # 1.7e-3, 1.3e-5   (headline N = 128 scene)
+    "fg_rgb_values": Dist(1e-3, **_GRAZE),  # mean 2.4e-4; 3 of 1024 rays above 1e-2; fg + T_bg * 1: the transmittance error, undamped
+    "acc_map": Dist(1e-3, **_GRAZE),        # mean 4.8e-4; 4 of 1024 rays above 1e-2, worst 5.3e-2
+    "acc_person_list": Dist(1e-3, **_GRAZE),   # mean 2.7e-4; 4 of 1024
+    "bg_transmittance": Dist(1e-3, **_GRAZE),  # mean 1.2e-4
+    "normal_values": Dist(8e-4, **_GRAZE),  # mean 3.2e-4; 3 of 1024 rays above 1e-2, worst 3.9e-2
     "bg_rgb": (1.5e-4, 2.5e-5),             # 2.7e-5, 5.4e-6
 }
 Z_VALS = (5e-2, 3e-4)                       # sampler depths (inverse CDF of f16 sdf queries); measured 1.4e-2, 6.7e-5
@@ -24,25 +35,42 @@ MLP = {                                     # the fused MLP kernels on random po
     "normal_rev_vs_fwd": 8e-3,              # 1.7e-3
     "bg_rgb": 1.6e-4,                       # 3.3e-5
 }
-# training-mode outputs, fp32 on both sides (exact-f32 MFMA GEMMs vs torch), max |err|; measured 7e-7 ... 1.8e-6
-TRAIN_FWD = {"rgb_values": 8e-6, "acc_map": 8e-6, "acc_person_list": 8e-6, "grad_theta": 5e-6, "normal_values": 8e-6}
+# training-mode outputs vs the fp32 oracle, max |err|.  The differentiable path runs its GEMMs either on the exact-fp32 matrix
+# instruction (MP_TRAIN_PRECISION=f32: fp32 on both sides, summation order only; measured 7e-7 ... 1.8e-6) or -- the default --
+# on split-bfloat16 products (three 16-bit MFMAs per product, ~2^-16 relative each; measured rgb 7.7e-7, acc 4.4e-6,
+# grad_theta 1.2e-5)
+TRAIN_FWD_BY_PRECISION = {
+    "f32": {"rgb_values": 8e-6, "acc_map": 8e-6, "acc_person_list": 8e-6, "grad_theta": 5e-6, "normal_values": 8e-6},
+    "bf16x3": {"rgb_values": 8e-6, "acc_map": 2e-5, "acc_person_list": 2e-5, "grad_theta": 5e-5, "normal_values": 5e-5},
+}
+
+
+def train_fwd():
+    from multiply_amd import train
+    return TRAIN_FWD_BY_PRECISION[train.TRAIN_PRECISION]
+
+
+TRAIN_FWD = TRAIN_FWD_BY_PRECISION["bf16x3"]
 TRAIN_GRAD_REL = 5e-3                       # per-tensor relative L2 error of a parameter gradient; measured 4.8e-4
 TRAIN_GRAD_REL_RENDERING = 2e-2             # colour nets: single ReLU masks flip between summation orders
 
 
 class Stats(tuple):
-    """(max, mean) of an error vector, with the vector itself attached (`.err`, one entry per ray / element)."""
+    """(max, mean) over the ELEMENTS of |got - want|, with the error of every element (`.err`) and the worst element of every
+    ray / row (`.ray`) attached"""
 
-    def __new__(cls, err):
+    def __new__(cls, err, ray=None):
         st = tuple.__new__(cls, (float(err.max()) if err.numel() else 0.0, float(err.mean()) if err.numel() else 0.0))
         st.err = err
+        st.ray = err if ray is None else ray
         return st
 
 
 def within(stats, tol):
-    """tol = (max, mean), or a Dist: mean, the BULK bound with the fraction of rays allowed above it, and a hard maximum."""
+    """tol = (max, mean) over elements, or a Dist {mean, bulk, frac, hard}: element mean below `mean`, at most the fraction
+    `frac` of the RAYS with an element above `bulk`, and nothing above `hard`."""
     if isinstance(tol, dict):
-        err = stats.err
-        above = float((err > tol["bulk"]).sum()) / max(err.numel(), 1)
+        ray = stats.ray
+        above = float((ray > tol["bulk"]).sum()) / max(ray.numel(), 1)
         return stats[1] < tol["mean"] and above <= tol["frac"] and stats[0] < tol["hard"]
     return stats[0] < tol[0] and stats[1] < tol[1]
