@@ -149,10 +149,17 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int LDK16 = BK + 8;   // bf16 elements per LDS row: 80 B, 16 B aligned, the 16 rows of a b128 read on 16 distinct bank quads
 
-template <bool FAST>
-__global__ __launch_bounds__(NT_THREADS) void k_gemm_nt_b3(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                                    float* __restrict__ C, int ldc, int M, int N, int K,
-                                                    const float* __restrict__ bias, int bias_rows, int accumulate, int relu) {
+// PA: how many stages ahead the A operand (the activation rows: HBM) is fetched through a register ring (the k loop is
+// unrolled by PA, so the ring slots are compile-time).  Measured on a 50k x 256 x 256 product: PA = 1 (the shape of the fp32
+// kernel) 44.8 us, PA = 4 49.4 us; a 128 x 256 tile per workgroup (activation rows read once instead of once per column tile,
+// 120 KB of LDS = one workgroup per CU) 58.6 us -- neither memory latency nor the repeated read is what bounds it (the repeat is
+// served by the Infinity Cache); at 100-150 MB per product it runs at 2.2-3.3 TB/s.  PA = 1 is what is instantiated.
+// Fragments of A are read per row block inside the MFMA loop: 91 VGPRs, two workgroups (four waves per SIMD) per CU.
+template <bool FAST, int PA>
+__global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt_b3(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                       float* __restrict__ C, int ldc, int M, int N, int K,
+                                                       const float* __restrict__ bias, int bias_rows, int accumulate, int relu) {
+    static_assert(PA == 1 || FAST, "the deep prefetch is for the bounds-free path");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // [stage][hi | lo][row][k] for A, then the same for B
     __bf16* As = (__bf16*)smem;
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(NT_THREADS) void k_gemm_nt_b3(const float* __restri
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
     const int sr = t >> 3, sk = (t & 7) * 4;       // staging: row sr + 64 q, k offset sk
     const bool a_al = (lda & 3) == 0 && ((size_t)A & 15) == 0, b_al = (ldb & 3) == 0 && ((size_t)B & 15) == 0;
-    f32x4 ra[2], rb[2];
+    f32x4 ra[PA][2], rb[2];
     const float* pa[2];
     const float* pb[2];
 #pragma unroll
@@ -176,15 +183,24 @@ __global__ __launch_bounds__(NT_THREADS) void k_gemm_nt_b3(const float* __restri
         pa[q] = A + (size_t)min(m0 + sr + 64 * q, M - 1) * lda + sk;
         pb[q] = B + (size_t)min(n0 + sr + 64 * q, N - 1) * ldb + sk;
     }
-    auto gload = [&](int k0) {
+    auto gload_a = [&](f32x4 (&r)[2], int k0) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             if constexpr (FAST) {
-                ra[q] = *(const f32x4*)(pa[q] + k0);
+                r[q] = *(const f32x4*)(pa[q] + k0);
+            } else {
+                const int am = m0 + sr + 64 * q, k = k0 + sk;
+                r[q] = am < M ? ld4(A + (size_t)am * lda + k, a_al && k + 3 < K, K - k) : (f32x4){0, 0, 0, 0};
+            }
+        }
+    };
+    auto gload_b = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if constexpr (FAST) {
                 rb[q] = *(const f32x4*)(pb[q] + k0);
             } else {
-                const int am = m0 + sr + 64 * q, bn = n0 + sr + 64 * q, k = k0 + sk;
-                ra[q] = am < M ? ld4(A + (size_t)am * lda + k, a_al && k + 3 < K, K - k) : (f32x4){0, 0, 0, 0};
+                const int bn = n0 + sr + 64 * q, k = k0 + sk;
                 rb[q] = bn < N ? ld4(B + (size_t)bn * ldb + k, b_al && k + 3 < K, K - k) : (f32x4){0, 0, 0, 0};
             }
         }
@@ -195,44 +211,54 @@ __global__ __launch_bounds__(NT_THREADS) void k_gemm_nt_b3(const float* __restri
         *(bf16x4*)(tile + row * LDK16 + sk) = hi;
         *(bf16x4*)(tile + BM * LDK16 + row * LDK16 + sk) = lo;
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf, const f32x4 (&r)[2]) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            split_store(As + buf * 2 * BM * LDK16, ra[q], sr + 64 * q);
+            split_store(As + buf * 2 * BM * LDK16, r[q], sr + 64 * q);
             split_store(Bs + buf * 2 * BN * LDK16, rb[q], sr + 64 * q);
         }
     };
-    const int nk = (K + BK - 1) / BK;
-    gload(0);
-    sstore(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * BK);
+    auto mfma_stage = [&](int buf) {
         const __bf16* at = As + buf * 2 * BM * LDK16;
         const __bf16* bt = Bs + buf * 2 * BN * LDK16;
-        bf16x8 ah[4], al[4], bh[2], bl[2];
+        bf16x8 bh[2], bl[2];
         // lane (li, lq) supplies k = 8 lq .. 8 lq + 7 of its row (the k index of an MFMA is free to permute): one b128 per operand
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ah[i] = *(const bf16x8*)(at + (wm + i * 16 + li) * LDK16 + 8 * lq);
-            al[i] = *(const bf16x8*)(at + BM * LDK16 + (wm + i * 16 + li) * LDK16 + 8 * lq);
-        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             bh[j] = *(const bf16x8*)(bt + (wn + j * 16 + li) * LDK16 + 8 * lq);
             bl[j] = *(const bf16x8*)(bt + BN * LDK16 + (wn + j * 16 + li) * LDK16 + 8 * lq);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            const bf16x8 ah = *(const bf16x8*)(at + (wm + i * 16 + li) * LDK16 + 8 * lq);
+            const bf16x8 al = *(const bf16x8*)(at + BM * LDK16 + (wm + i * 16 + li) * LDK16 + 8 * lq);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);   // the small terms first
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);   // the small terms first
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
             }
-        if (kt + 1 < nk) sstore(buf ^ 1);
-        __syncthreads();
+        }
+    };
+    const int nk = (K + BK - 1) / BK;
+#pragma unroll
+    for (int s_ = 0; s_ < PA; ++s_)
+        if (s_ < nk) gload_a(ra[s_], s_ * BK);
+    gload_b(0);
+    sstore(0, ra[0]);
+    __syncthreads();
+    for (int kt0 = 0; kt0 < nk; kt0 += PA) {
+#pragma unroll
+        for (int u = 0; u < PA; ++u) {
+            const int kt = kt0 + u, buf = kt & 1;
+            if (kt < nk) {
+                if (kt + 1 < nk) gload_b((kt + 1) * BK);
+                if (kt + PA < nk) gload_a(ra[u], (kt + PA) * BK);     // slot u held stage kt: stored to LDS one iteration ago
+                mfma_stage(buf);
+                if (kt + 1 < nk) sstore(buf ^ 1, ra[(u + 1) % PA]);
+                __syncthreads();
+            }
+        }
     }
     // D: col = lane&15 (n), row = 4*(lane>>4)+reg (m)
     const int cn = lane & 15, cr = (lane >> 4) * 4;
@@ -359,8 +385,9 @@ __global__ __launch_bounds__(NT_THREADS) void k_gemm_tn(const float* __restrict_
 // bf16 (hi tile and lo tile).  LDS image per operand and half: [row block of 4][column][4 x bf16]: a thread's four columns are 32
 // contiguous bytes (two b128 writes, conflict-free across the wave), and a lane's operand for a 32-row stage is the two row
 // blocks (2 kg, 2 kg + 1) of its column: two b64 reads, consecutive lanes on consecutive 8-byte slots (conflict-free).
+// (operand rows fetched PT = 2 stages ahead through a register ring, k loop unrolled by 2 -- what fits under 128 VGPRs; see k_gemm_nt_b3)
 template <bool FAST>
-__global__ __launch_bounds__(NT_THREADS) void k_gemm_tn_b3(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+__global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_tn_b3(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                     float* __restrict__ C, int ldc, int M, int N, int K, int rows_per_block,
                                                     float* __restrict__ colsum, int colsum_rows) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -383,8 +410,9 @@ __global__ __launch_bounds__(NT_THREADS) void k_gemm_tn_b3(const float* __restri
     const int ld = is_b ? ldb : lda, c0 = (is_b ? n0 : m0) + 4 * mg, cmax = is_b ? N : M;
     const bool al = (ld & 3) == 0 && ((size_t)src & 15) == 0;
     const bool do_sum = colsum != nullptr && blockIdx.y == 0 && !is_b;
-    f32x4 rr[4], csum = {0.f, 0.f, 0.f, 0.f};
-    auto gload = [&](int r0) {
+    constexpr int PT = 2;
+    f32x4 rr_[PT][4], csum = {0.f, 0.f, 0.f, 0.f};
+    auto gload = [&](f32x4 (&rr)[4], int r0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int r = r0 + 4 * rb + e;
@@ -393,7 +421,7 @@ __global__ __launch_bounds__(NT_THREADS) void k_gemm_tn_b3(const float* __restri
             if (do_sum && r < colsum_rows) csum += rr[e];
         }
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf, const f32x4 (&rr)[4]) {
         __bf16* tile = Ts + ((buf * 2 + (is_b ? 1 : 0)) * 2) * HALF + (rb * BM + 4 * mg) * 4;
         bf16x8 h[2], l[2];
 #pragma unroll
@@ -410,40 +438,45 @@ __global__ __launch_bounds__(NT_THREADS) void k_gemm_tn_b3(const float* __restri
         *(bf16x8*)(tile + HALF + 8) = l[1];
     };
     const int nk = (r_end - r_begin + BK - 1) / BK;
-    if (nk > 0) {
-        gload(r_begin);
-        sstore(0);
-    }
+#pragma unroll
+    for (int s_ = 0; s_ < PT; ++s_)
+        if (s_ < nk) gload(rr_[s_], r_begin + s_ * BK);
+    if (nk > 0) sstore(0, rr_[0]);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) gload(r_begin + (kt + 1) * BK);
-        const __bf16* ta = Ts + (buf * 2 + 0) * 2 * HALF;
-        const __bf16* tb = Ts + (buf * 2 + 1) * 2 * HALF;
-        // lane (li, kg): k slots = the 8 rows of row blocks 2 kg and 2 kg + 1, for its column
-        auto frag = [&](const __bf16* tile, int col) {
-            const bf16x4 p = *(const bf16x4*)(tile + ((2 * kg) * BM + col) * 4);
-            const bf16x4 q = *(const bf16x4*)(tile + ((2 * kg + 1) * BM + col) * 4);
-            bf16x8 f;
+    // lane (li, kg): k slots = the 8 rows of row blocks 2 kg and 2 kg + 1, for its column
+    auto frag = [&](const __bf16* tile, int col) {
+        const bf16x4 p = *(const bf16x4*)(tile + ((2 * kg) * BM + col) * 4);
+        const bf16x4 q = *(const bf16x4*)(tile + ((2 * kg + 1) * BM + col) * 4);
+        bf16x8 f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { f[e] = p[e]; f[4 + e] = q[e]; }
-            return f;
-        };
-        bf16x8 ah[4], al_[4], bh[2], bl[2];
+        for (int e = 0; e < 4; ++e) { f[e] = p[e]; f[4 + e] = q[e]; }
+        return f;
+    };
+    for (int kt0 = 0; kt0 < nk; kt0 += PT) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { ah[i] = frag(ta, wm + 16 * i + li); al_[i] = frag(ta + HALF, wm + 16 * i + li); }
+        for (int u = 0; u < PT; ++u) {
+            const int kt = kt0 + u, buf = kt & 1;
+            if (kt < nk) {
+                if (kt + PT < nk) gload(rr_[u], r_begin + (kt + PT) * BK);   // slot u held stage kt: in LDS since the last iteration
+                const __bf16* ta = Ts + (buf * 2 + 0) * 2 * HALF;
+                const __bf16* tb = Ts + (buf * 2 + 1) * 2 * HALF;
+                bf16x8 bh[2], bl[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { bh[j] = frag(tb, wn + 16 * j + li); bl[j] = frag(tb + HALF, wn + 16 * j + li); }
+                for (int j = 0; j < 2; ++j) { bh[j] = frag(tb, wn + 16 * j + li); bl[j] = frag(tb + HALF, wn + 16 * j + li); }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) {
+                    const bf16x8 ah = frag(ta, wm + 16 * i + li), al_ = frag(ta + HALF, wm + 16 * i + li);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al_[i], bh[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al_, bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+                if (kt + 1 < nk) sstore(buf ^ 1, rr_[(u + 1) % PT]);
+                __syncthreads();
             }
-        if (kt + 1 < nk) sstore(buf ^ 1);
-        __syncthreads();
+        }
     }
     // D: col = lane&15 (n), row = 4*(lane>>4)+reg (m)
     const int cn = lane & 15, cr = (lane >> 4) * 4;
@@ -494,15 +527,15 @@ extern "C" int mp_gemm_nt_bf16x3(const float* A, int lda, const float* B, int ld
                                  const float* bias, int bias_rows, int accumulate, int relu, void* stream) {
     if (M <= 0 || N <= 0) return 0;
     constexpr int LDS_B3 = 2 * 2 * (BM + BN) * LDK16 * 2;   // 2 stages x (hi, lo) x (A, B) tiles of bf16
-    MP_LDS_ATTR((k_gemm_nt_b3<true>), LDS_B3);
-    MP_LDS_ATTR((k_gemm_nt_b3<false>), LDS_B3);
+    MP_LDS_ATTR((k_gemm_nt_b3<true, 1>), LDS_B3);
+    MP_LDS_ATTR((k_gemm_nt_b3<false, 1>), LDS_B3);
     const bool fast = (lda & 3) == 0 && (ldb & 3) == 0 && ((size_t)A & 15) == 0 && ((size_t)B & 15) == 0 && K % BK == 0;
-    if (fast)
-        hipLaunchKernelGGL(k_gemm_nt_b3<true>, dim3((M + BM - 1) / BM, (N + BN - 1) / BN), dim3(NT_THREADS), LDS_B3, (hipStream_t)stream,
-                           A, lda, B, ldb, C, ldc, M, N, K, bias, bias_rows, accumulate, relu);
-    else
-        hipLaunchKernelGGL(k_gemm_nt_b3<false>, dim3((M + BM - 1) / BM, (N + BN - 1) / BN), dim3(NT_THREADS), LDS_B3, (hipStream_t)stream,
-                           A, lda, B, ldb, C, ldc, M, N, K, bias, bias_rows, accumulate, relu);
+    const dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
+#define MP_NT_B3(F, P) hipLaunchKernelGGL((k_gemm_nt_b3<F, P>), grid, dim3(NT_THREADS), LDS_B3, (hipStream_t)stream, A, lda, B, ldb, C, \
+                                           ldc, M, N, K, bias, bias_rows, accumulate, relu)
+    if (fast) MP_NT_B3(true, 1);
+    else MP_NT_B3(false, 1);
+#undef MP_NT_B3
     return (int)hipGetLastError();
 }
 
