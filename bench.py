@@ -135,8 +135,16 @@ def train_iterations(model, gin, steps, warmup, dist, barrier, seed=0, rays=512)
     R = gin["uv"].shape[1]
     loss_fn = Loss(load_config().loss)
     opt = torch.optim.Adam(model.parameters(), lr=5.0e-4)            # multiply_model.py configure_optimizers
-    ar = GradientAllReduce(model.parameters())
+    # N > 1: the gradient buckets are all-reduced WHILE the backward sweep goes on (parallel.BucketedGradientSync); the
+    # "allreduce" phase below is then what is left after loss.backward() returned
+    from multiply_amd.parallel import BucketedGradientSync
+    overlapped = bool(dist) and os.environ.get("MP_FLAT_ALLREDUCE", "0") != "1"
+    model.grad_bucket_sync = BucketedGradientSync() if overlapped else None
+    ar = (lambda: None) if overlapped else GradientAllReduce(model.parameters())
     model.train()
+    # ray-sharded DP: the sampler's convergence vote spans the rays of ALL ranks (one MAX all-reduce per sampler iteration), so
+    # that the N-rank step samples like the single-process 512-ray step (ray_sampler.py:137; tests/dist_sampler_vote.py)
+    model.sampler_vote_group = True if dist else None
     model.async_setup = True       # the inputs below are resident before the loop: the setup's host sync need not wait for
     evs = []                       # the previous iteration's backward (Multiply._setup)
     acc = [0.0] * 4
@@ -186,6 +194,8 @@ def train_iterations(model, gin, steps, warmup, dist, barrier, seed=0, rays=512)
             acc[i] += ev[i].elapsed_time(ev[i + 1])
     model.eval()
     model.async_setup = False
+    model.sampler_vote_group = None
+    model.grad_bucket_sync = None
     return dt, [a / max(steps, 1) for a in acc], float(lo["loss"]), model.last_stats
 
 
@@ -406,6 +416,17 @@ def main():
 
     train = None
     if args.train_steps > 0:
+        from multiply_amd import train as _T
+        if _T.TRAIN_PRECISION == "f32":
+            train_dtype, train_peak = "f32", 157.3
+            train_note = "exact-fp32 matrix instruction (v_mfma_f32_16x16x4_f32), MP_TRAIN_PRECISION=f32"
+            train_peak_note = "the fp32-matrix peak, 157.3 TFLOP/s"
+        else:
+            train_dtype, train_peak = "bf16x3", PEAK_BF16_TFLOPS / 3.0
+            train_note = ("fp32 tensors and fp32 accumulation; every GEMM operand is split into two bfloat16 halves and a product is "
+                          "three 16-bit MFMAs (~2^-16 relative per product, fp32 range) -- not a reduced-precision training step: "
+                          "parity_* below compare it with the fp32 oracle")
+            train_peak_note = "the dense 16-bit MFMA peak / 3 (three MFMAs per product) = 833 TFLOP/s"
         rays_rank = 512 // world             # strong scaling: the reference's 512 pixels per iteration split over the ranks
         full = to_dev(inp)
         tdt, tph, tloss, tstats = train_iterations(model, full, args.train_steps, args.train_warmup, dist, barrier, seed=rank,
@@ -420,14 +441,14 @@ def main():
         train = {"metric": "ms/train-iter (forward + loss + backward + gradient all-reduce + Adam step)",
                  "ms_per_iter": 1e3 * tdt / args.train_steps, "steps": args.train_steps, "warmup": args.train_warmup,
                  "rays_per_iter_per_gpu": rays_rank, "rays_per_iter": rays_rank * world, "scaling": "strong",
-                 "dtype": "f32",
+                 "dtype": train_dtype, "dtype_note": train_note, "obb_mode": model.obb_mode,
                  "gpu_ms": {"forward+loss": tph[0], "backward": tph[1], "allreduce": tph[2], "adam": tph[3]},
                  "hit_rays": tstats["n_hit"], "last_loss": tloss,
-                 "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": 157.3, "flop_per_iter_this_rank": tflop,
+                 "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": train_peak, "flop_per_iter_this_rank": tflop,
                               "achieved": tflop / (tdt / args.train_steps) / 1e12,
-                              "frac": tflop / (tdt / args.train_steps) / 1e12 / 157.3,
-                              "note": "exact-fp32 MFMA GEMM work of the differentiable path (the f16 sampler queries are not "
-                                      "counted) over the whole iteration's wall time"}}
+                              "frac": tflop / (tdt / args.train_steps) / 1e12 / train_peak,
+                              "note": "algorithmic GEMM FLOP of the differentiable path (the f16 sampler queries are not counted) "
+                                      "over the whole iteration's wall time; peak = " + train_peak_note}}
 
     n_shaded = float(sum(int(w.sum()) for s_ in shaded for w in s_)) / args.steps          # per frame (this rank's share)
     n_sdf = float(sum(int(w[:-1].sum()) for s_ in sdf_evals for w in s_)) / args.steps
@@ -452,7 +473,7 @@ def main():
     traffic = None
     kernels = {"mlp_shade": ["k_mlp_fwdsave", "k_mlp_grad"] if model.shade_mode == "reverse" else ["k_mlp_shade"],
                "mlp_color": ["k_mlp_color"], "background": ["k_background"], "sampler_mlp_sdf": ["k_mlp_sdf"]}[dom]
-    pmc_file = next((os.path.join(REPO, "profiles", f) for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+    pmc_file = next((os.path.join(REPO, "profiles", f) for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
                      if os.path.exists(os.path.join(REPO, "profiles", f))), None)
     if pmc_file and args.res == 512 and args.samples == 128 and world == 1:
         with open(pmc_file) as f:
@@ -474,7 +495,11 @@ def main():
             "metric": "rays/sec rendering full 512x512 frames (eval forward, all persons, with background)",
             "value": R * args.steps / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f16",
+            "dtype_note": "MLP operands IEEE half (f16: the bf16 operand width and MFMA rate BASELINE.json's configs[1] names, 3 more "
+                          "mantissa bits), fp32 accumulation; everything else fp32.  The reference is fp32; stated tolerances vs the "
+                          "fp32 oracle: tests/tolerances.py, cpu_baseline.parity_* below",
+            "collective_backend": (backend if dist else None), "data": "synthetic",
             "config": {"workload": f"2-person synthetic SMPL scene, {args.res}x{args.res} rays/frame, N_samples="
                                    f"{args.samples} (+32 extra +2 bounds = {args.samples + 33} composited samples/ray/"
                                    f"person), N_samples_eval={max(128, args.samples)}, 32 background samples, "

@@ -140,6 +140,42 @@ class GradientAllReduce:
         return self.flat
 
 
+class BucketedGradientSync:
+    """The same averaging, OVERLAPPED with the backward pass: the hand-written adjoint sweep
+    (multiply_amd/train.py TrainGraph.backward) finishes one person's networks after the other, then the background nets.  Set
+    as `model.grad_bucket_sync`, every retired group of gradients is copied into its own flat bucket and its all-reduce is
+    launched at once with async_op=True -- on RCCL's own stream, beside the next person's backward kernels -- and the sweep's
+    last act is to wait for the buckets and hand the AVERAGED gradients to autograd (p.grad is final when loss.backward()
+    returns; no GradientAllReduce call afterwards).  Buckets: one per person (SDF + colour net, ~3.3 MB), one for the
+    background nets, the frame code and density.beta (~2.3 MB)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.pending = []
+
+    def retire(self, params, grads):
+        """params / grads: the tensors of one retired group (same order on every rank)"""
+        if not params:
+            return
+        flat = torch.cat([g.reshape(-1).float() for g in grads])
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.pending.append((work, flat, list(params), [g.shape for g in grads]))
+
+    def finish(self, grads_by_id):
+        """waits for every bucket; -> grads_by_id with the retired entries replaced by their averages"""
+        world = dist.get_world_size(self.group)
+        for work, flat, params, shapes in self.pending:
+            work.wait()
+            flat.mul_(1.0 / world)
+            o = 0
+            for p, sh in zip(params, shapes):
+                n = int(torch.Size(sh).numel())
+                grads_by_id[id(p)] = flat[o:o + n].reshape(sh).to(grads_by_id[id(p)].dtype)
+                o += n
+        self.pending = []
+        return grads_by_id
+
+
 # ======================================================================================================================
 # Person-sharded rendering (SURVEY.md §8e, BASELINE.json configs[3]): rank g owns the networks' work of persons
 # {p : p % world == g} for ALL rays of the call, then ONE exchange step turns "all rays of my persons" into "all persons

@@ -676,10 +676,17 @@ class TrainGraph:
              "mp_tr_composite_bwd")
         grads = {}
         self.pose_grads = {}
+        # data-parallel training: buckets of retired gradients are all-reduced while the sweep goes on (parallel.BucketedGradientSync)
+        sync = getattr(m, "grad_bucket_sync", None)
 
         def collect(obj):
             for prm, g in zip(obj.params(), obj.param_grads()):
                 grads[id(prm)] = g if id(prm) not in grads else grads[id(prm)] + g
+
+        def retire(*objs):
+            if sync is not None:
+                prms = [prm for o in objs for prm in o.params()]
+                sync.retire(prms, [grads[id(prm)] for prm in prms])
 
         for p in persons:
             n = all_persons.index(p)                                  # position among the composited persons
@@ -698,6 +705,7 @@ class TrainGraph:
                 _chk(L.mp_tr_eik_bwd(Pt, npts, N_EIKONAL, _p(dg), _p(dZ8), _p(dgrad), st), "mp_tr_eik_bwd")
             dcond = it.backward(dZ8, dgrad, want_dx=self.pose_grad) if rev else it.backward(dZ8, want_dx=self.pose_grad)
             collect(it); collect(rt)
+            retire(it, rt)
             if self.pose_grad:
                 # x_c enters the SDF net (value + tangent rows) and the colour net (XA[:, :3]); the transforms also shape
                 # the normals through Jinv.  -> d tfs -> d (scale, transl, thetas, betas)   (multiply.py:196-206, 270)
@@ -736,6 +744,10 @@ class TrainGraph:
             grads[id(w)] = gw
         bp = m.density.beta
         grads[id(bp)] = (d_beta.reshape(bp.shape) * torch.sign(bp.detach())).to(bp.dtype)     # density.py:31-33
+        if sync is not None:
+            tail = [bp] + ([m.frame_latent_encoder.weight] + b["it"].params() + b["rt"].params() if self.bg is not None else [])
+            sync.retire(tail, [grads[id(prm)] for prm in tail])
+            grads = sync.finish(grads)
         return grads
 
 

@@ -121,6 +121,24 @@ def main():
     print(f"[rank {rank}] loss gpu {float(lo['loss']):.6f} oracle {float(lw['loss']):.6f}; worst relative error of the "
           f"all-reduced gradients vs the averaged oracle gradients {worst_rel:.3e}", flush=True)
     check(abs(float(lo["loss"]) - float(lw["loss"])) < 1e-4 * max(1.0, abs(float(lw["loss"]))), "loss")
+    # ---- the bucketed, overlapped variant (buckets all-reduced while the backward sweep goes on): the same averaged gradients
+    flat_ref = {k: p_.grad.detach().clone() for k, p_ in model.named_parameters() if p_.grad is not None}
+    model.grad_bucket_sync = parallel.BucketedGradientSync()
+    from multiply_amd import train as T
+    out2 = T.forward_train(model, tg, draws=graph.draws)            # the same draws: the same forward
+    lo2 = loss_fn(out2, {"rgb": gt["rgb"].cuda()})
+    model.zero_grad()
+    lo2["loss"].backward()                                          # p.grad is already the average when this returns
+    torch.cuda.synchronize()
+    model.grad_bucket_sync = None
+    worst_b = 0.0
+    for k, p_ in model.named_parameters():
+        if k in flat_ref:
+            g2 = p_.grad if p_.grad is not None else torch.zeros_like(flat_ref[k])      # parameters no loss term reaches
+            d = float((g2 - flat_ref[k]).abs().max()) / (float(flat_ref[k].abs().max()) + 1e-30)
+            worst_b = max(worst_b, d)
+    print(f"[rank {rank}] bucketed overlapped all-reduce vs the flat one: worst relative difference {worst_b:.2e}", flush=True)
+    check(worst_b < 2e-2, "bucketed gradient sync differs from the flat all-reduce")     # two runs: fp32 atomics, ReLU flips
     flag = torch.tensor([1.0 if ok else 0.0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     dist.barrier()

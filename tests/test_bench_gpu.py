@@ -36,6 +36,8 @@ def test_single_gpu_line_has_roofline_and_cpu_baseline():
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c and c["parity_rgb_max_abs"] < 8e-3
     t = d["train_iter"]
     assert t["ms_per_iter"] > 0 and t["rays_per_iter"] == 512 and t["cpu_baseline"]["value"] > 0 and 0 < t["roofline"]["frac"] < 1
+    assert t["dtype"] == "bf16x3" and "dtype_note" in d and t["cpu_baseline"]["parity_grad_rel_worst"] < 2e-2
+    assert t["cpu_baseline"]["parity_loss_abs"] < 1e-4
 
 
 def test_gpus_flag_starts_the_ranks_and_reports_strong_scaling():
@@ -44,9 +46,25 @@ def test_gpus_flag_starts_the_ranks_and_reports_strong_scaling():
     d = _run(["--gpus", "2", "--res", "64", "--steps", "2", "--warmup", "1", "--train-steps", "2", "--train-warmup", "1"],
              env={"MP_BENCH_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and "cpu_baseline" not in d
+    assert d["collective_backend"] == "gloo"
     assert d["config"]["rays_per_step"] == 64 * 64 and "ray-sharded dp2" in d["config"]["parallelism"]
     assert d["weak"]["scaling"] == "weak" and d["weak"]["value"] > 0
     assert d["train_iter"]["rays_per_iter_per_gpu"] == 256 and d["train_iter"]["rays_per_iter"] == 512
+
+
+def test_two_ranks_over_rccl_when_the_box_has_two_gpus():
+    """the SAME command on the backend the driver's multi-GPU runs use ("nccl" = RCCL over xGMI): one rank per GPU, the image
+    all_gather and the flat gradient all-reduce as real device collectives.  A one-GPU box cannot run it -- said loudly, not
+    silently replaced by the gloo variant above."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        msg = (f"RCCL PATH NOT EXECUTED: this box exposes {torch.cuda.device_count()} GPU(s); bench.py --gpus 2 on backend 'nccl' "
+               f"needs one GPU per rank (the gloo variant of the same code path ran in the test above)")
+        print("\n[WARNING] " + msg, file=sys.stderr)
+        pytest.skip(msg)
+    d = _run(["--gpus", "2", "--res", "64", "--steps", "2", "--warmup", "1", "--train-steps", "2", "--train-warmup", "1"])
+    assert d["n_gpus"] == 2 and d["collective_backend"] == "nccl" and d["value"] > 0
+    assert d["train_iter"]["rays_per_iter_per_gpu"] == 256 and d["train_iter"]["gpu_ms"]["allreduce"] > 0
 
 
 def test_world_size_mismatch_is_refused():

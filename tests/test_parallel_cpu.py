@@ -269,3 +269,37 @@ def test_epoch_stage_products_are_broadcast_from_the_producing_rank():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res)
+
+
+def _exchange_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_slice, width = 5, 7
+    # rank g's dense block: rows = all rays of the call (slice-major), value encodes (producer rank, ray, column)
+    dense = (1000.0 * rank + torch.arange(world * n_slice, dtype=torch.float32)[:, None] * 10 + torch.arange(width)[None, :]).contiguous()
+    a2a = parallel._exchange_by_rays(dense, world, True)        # the RCCL branch: all_to_all_single (gloo implements it for CPU tensors)
+    gat = parallel._exchange_by_rays(dense, world, False)       # the fallback: all_gather + select
+    want = torch.stack([1000.0 * g + (torch.arange(rank * n_slice, (rank + 1) * n_slice, dtype=torch.float32)[:, None] * 10
+                                      + torch.arange(width)[None, :]) for g in range(world)], 0)
+    ok = a2a.shape == (world, n_slice, width) and torch.equal(a2a, want) and torch.equal(gat, want)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_person_sharded_exchange_all_to_all_branch(world):
+    """parallel._exchange_by_rays: the all_to_all_single branch (what runs over RCCL) and the all_gather fallback deliver the same
+    [producer rank][my ray slice] blocks -- 'all rays of my persons' becomes 'all persons of my rays'"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
