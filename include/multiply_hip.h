@@ -84,10 +84,12 @@ int mp_mlp_shade(const MpNet* net, const void* wpack, const float* bias, const f
                  void* feat_frag, void* stream);
 
 /* mp_mlp_shade_rev: same outputs as mp_mlp_shade, computed in reverse mode, segment by segment of the worklist:
- * a plain forward sweep that writes sigmoid(100 z) of every hidden unit (4096 B per work index) into `sig`
- * (seg_points * 4096 B, seg_points a multiple of 256, ZERO-INITIALISED once by the caller), then a reverse sweep through
+ * a plain forward sweep that writes sigmoid(100 z) of every hidden unit as UNORM8 (mp_sig_bytes_per_point() = 2048 B per work
+ * index) into `sig` (seg_points * mp_sig_bytes_per_point() B, seg_points a multiple of 256, ZERO-INITIALISED once by the
+ * caller), then a reverse sweep through
  * the TRANSPOSED layers (gnet / gpack: the 'grad' plan of multiply_amd/hip.py; w8_slots: the sdf row of the last layer,
  * 256 halves in K-slot order).  Two network columns per point instead of the four of the forward-mode kernel. */
+int mp_sig_bytes_per_point(void);
 int mp_mlp_shade_rev(const MpNet* net, const void* wpack, const float* bias, const MpNet* gnet, const void* gpack,
                      const void* w8_slots, const float* xc, const float* jinv, const int* worklist, const int* count,
                      int max_count, float* sdf_out, float* normal_out, void* feat_frag, void* sig, int seg_points,

@@ -284,7 +284,8 @@ struct GradCapture {
 
 
 // ---- sweep 1: work indices [offset, offset + seg) of the worklist.  sig block of (tile t, wave w) of the segment:
-//      sig + ((t * 8 + w) * 8 layers) * 16 KiB;  inside: [layer][K step][block][lane][16 B]
+//      sig + ((t * 8 + w) * 8 layers) * SIG_LAYER;  inside: [layer][K step = chunk][lane][16 B] as UNORM8 (both column blocks of
+//      a chunk in one 16-byte vector; half-precision build: [layer][K step][block][lane][16 B])
 template <int NB, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_mlp_fwdsave(const NetDesc net, const char* __restrict__ wpack,
                                                             const float* __restrict__ bias, const float* __restrict__ xc,
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_fwdsave(const NetDesc net, c
     float* bias_lds = (float*)(smem + L::bias0);
     op_t* stage = (op_t*)(smem + L::stage) + wave * L::PTS * in_stride(KS_IN);
     load_bias(net, bias, bias_lds);
-    constexpr int SIG_LAYER = KS_REG * NB * 1024;
+    constexpr int SIG_LAYER = KS_REG * SIG_CHUNK_BYTES;   // one wave's sigmoids of one layer: 8 (UNORM8) or 16 KiB
     for (int t = blockIdx.x; offset + t * L::TILE < count; t += gridDim.x) {
         const int w = offset + t * L::TILE + wave * L::PTS + lane;
         const int id = (lane < L::PTS && w < count) ? (worklist ? worklist[w] : w) : -1;
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_grad(const NetDesc net, cons
     op_t* w8 = (op_t*)(smem + RING);                                  // [256] sdf-row weights in K-slot order
     op_t* tabs = w8 + 256 + wave * (2 * PTS * 48);
     for (int i = threadIdx.x; i < 256; i += blockDim.x) w8[i] = w8_slots[i];
-    constexpr int SIG_LAYER = KS_REG * NB * 1024;
+    constexpr int SIG_LAYER = KS_REG * SIG_CHUNK_BYTES;   // one wave's sigmoids of one layer: 8 (UNORM8) or 16 KiB
     for (int t = blockIdx.x; offset + t * TILE < count; t += gridDim.x) {
         const int w = offset + t * TILE + wave * PTS + (lane & (PTS - 1));
         const int id = w < count ? (worklist ? worklist[w] : w) : -1;     // lanes l and l+32 both know point l's id
@@ -392,9 +393,25 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_grad(const NetDesc net, cons
 #pragma unroll
         for (int ks = 0; ks < KS_REG; ++ks) {
             const opx8 wv = *(const opx8*)(w8 + ks * 32 + 8 * gq);
+            if constexpr (SIG8) {
+                // chunk ks: dword 2 nb + mbl = the bytes of row pairs (mbl, j = 0, 1) of column block nb -> halves 0 .. 7 in operand order
+                const u32x4 pk = *(const u32x4*)(sio.base + (size_t)7 * SIG_LAYER + ks * 1024 + lane * 16);
+                const opx8 wq = wv * (op_t)(1.0f / 255.0f);
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-                Bcur[ks][nb] = *(const opx8*)(sio.base + (size_t)7 * SIG_LAYER + (ks * NB + nb) * 1024 + lane * 16) * wv;
+                for (int nb = 0; nb < NB; ++nb) {
+                    const unsigned d0 = nb == 0 ? pk.x : pk.z, d1 = nb == 0 ? pk.y : pk.w;
+                    u32x4 h;   // halves 1024 + b
+                    h.x = __builtin_amdgcn_perm(0x64646464u, d0, 0x04010400u);
+                    h.y = __builtin_amdgcn_perm(0x64646464u, d0, 0x04030402u);
+                    h.z = __builtin_amdgcn_perm(0x64646464u, d1, 0x04010400u);
+                    h.w = __builtin_amdgcn_perm(0x64646464u, d1, 0x04030402u);
+                    Bcur[ks][nb] = (__builtin_bit_cast(opx8, h) - (op_t)1024.0f) * wq;
+                }
+            } else {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    Bcur[ks][nb] = *(const opx8*)(sio.base + (size_t)7 * SIG_LAYER + (ks * NB + nb) * 1024 + lane * 16) * wv;
+            }
         }
         float g[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
         f32x4 out[NB];
@@ -667,6 +684,8 @@ extern "C" int mp_mlp_full(const MpNet* net, const void* wpack, const float* bia
     }
     return (int)hipGetLastError();
 }
+
+extern "C" int mp_sig_bytes_per_point(void) { return 8 * KS_REG * SIG_CHUNK_BYTES / 32; }
 
 extern "C" int mp_mlp_shade_rev(const MpNet* net, const void* wpack, const float* bias, const MpNet* gnet, const void* gpack,
                                 const void* w8_slots, const float* xc, const float* jinv, const int* worklist,

@@ -438,16 +438,36 @@ constexpr bool LOG_POLY = false;
 constexpr bool LOG_POLY = true;
 #endif
 constexpr float LOG2P_C1 = 1.42459527f, LOG2P_C2 = -0.58921265f, LOG2P_C3 = 0.16538905f;
+// The stored sigmoids travel through HBM as UNORM8 (default; -DMP_EXP_SIG16: as halves, 4 KiB per point).  At half precision the
+// forward sweep writes 512 B per point and hidden layer: at a fraction f of the MFMA peak that is f x 9.8 TB/s of stores (the
+// reverse sweep: the same in loads) -- HBM caps the forward sweep at ~0.45 of the peak and the reverse sweep at ~0.54 whatever
+// the instruction stream does (tools/stream_model.hip reproduces it).  A byte per sigmoid halves both.
+//   quantise (forward):  t = 255 s + 1024 in half precision (one v_pk_fma_f16, round to nearest): the low byte of a half in
+//                        [1024, 2048) IS its integer part - 1024 = round(255 s); the four low bytes of two row pairs are gathered
+//                        into one dword by one v_perm_b32.   +1.5 VALU per row pair, 8 B instead of 16 per lane, chunk and block
+//   restore (reverse):   v_perm_b32 spreads two bytes under 0x64 (= the halves 1024 + b), - 1024, x 1/255.   +3 VALU per row pair
+// sigmoid(100 z) of the beta = 100 softplus is 0 or 1 to within a step for all but the units in transition: the error is
+// <= 1/510 absolute on those and ZERO on the saturated ones (0 -> 0, 1 -> 255 -> 1).
+#ifdef MP_EXP_SIG16
+constexpr bool SIG8 = false;
+#else
+constexpr bool SIG8 = true;
+#endif
+constexpr int SIG_CHUNK_BYTES = SIG8 ? 1024 : 2048;   // per wave and chunk: 64 lanes x (2 column blocks x 4 row pairs x 2 sigmoids)
 struct ActConst {
     unsigned c1, c2, c3;   // the coefficients as packed half pairs, in vector registers (gfx9 VOP3P: no literals, one SGPR)
+    unsigned c1024, c64;   // 8-bit sigmoids: 1024.0 pairs; 0x64646464 (the high bytes of halves 1024 + b)
 };
 __device__ __forceinline__ ActConst act_const() {
     const h2 a = {(op_t)LOG2P_C1, (op_t)LOG2P_C1}, b = {(op_t)LOG2P_C2, (op_t)LOG2P_C2}, c = {(op_t)LOG2P_C3, (op_t)LOG2P_C3};
-    return ActConst{bits(a), bits(b), bits(c)};
+    const h2 k = {(op_t)1024.0f, (op_t)1024.0f};
+    return ActConst{bits(a), bits(b), bits(c), bits(k), 0x64646464u};
 }
+__device__ __forceinline__ unsigned sconst(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }   // into an SGPR
 // stages of the V program per layer kind (HIDDEN = false: the linear output layers, conversion only)
 __host__ __device__ constexpr int pp_stages(int hid, bool hidden) {
-    return !hidden ? 1 : hid == HID_SOFTPLUS_SAVE ? (LOG_POLY ? 10 : 11) : hid == HID_SOFTPLUS ? (LOG_POLY ? 7 : 8) : 2;
+    return !hidden ? 1 : hid == HID_SOFTPLUS_SAVE ? (LOG_POLY ? 10 : 11) + (SIG8 ? 2 : 0) : hid == HID_SOFTPLUS ? (LOG_POLY ? 7 : 8)
+                     : hid == HID_SIGMUL && SIG8 ? 5 : 2;
 }
 
 // stage ST for row pair q = 4 mbl + 2 nb + j  (mbl: 16-row block of the chunk, nb: column block, j: row pair)
@@ -466,6 +486,26 @@ __device__ __forceinline__ void pp_instr(ActRegs8& a, const ActConst& k, const f
         a.z[q] = bits(to_h2(acc[mbl][nb][2 * j], acc[mbl][nb][2 * j + 1]));
         if constexpr (!HIDDEN) {
             if (c < KS_REG) Bn.put(c, nb, mbl, j, __builtin_bit_cast(h2, a.z[q]));
+        }
+    } else if constexpr (HID == HID_SIGMUL && SIG8) {   // restore the byte-sized sigmoids, then multiply
+        static_assert(ST >= 1 && ST <= 4 && HIDDEN, "pp_instr: stage");
+        // sg[0] = this chunk's 16 bytes: dword 2 nb + mbl holds row pairs j = 0, 1 of block (mbl, nb) as bytes (2 j, 2 j + 1)
+        constexpr int e = 2 * nb + mbl;
+        if constexpr (ST == 1) {
+            unsigned src;
+            if constexpr (e == 0) src = sg[0].x;
+            else if constexpr (e == 1) src = sg[0].y;
+            else if constexpr (e == 2) src = sg[0].z;
+            else src = sg[0].w;
+            // D = bytes of {S0 = 0x64.., S1 = src}: (src byte 2 j, 0x64, src byte 2 j + 1, 0x64) = the halves 1024 + b
+            asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(a.u[q]) : "v"(k.c64), "v"(src), "s"(sconst(j == 0 ? 0x04010400u : 0x04030402u)));
+        } else if constexpr (ST == 2) {
+            asm volatile("v_pk_add_f16 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(a.u[q]) : "v"(k.c1024));
+        } else if constexpr (ST == 3) {
+            asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(a.u[q]) : "s"(sconst(0x1C041C04u)));     // x 1/255 (0x1C04 = 0.0039215)
+        } else {
+            const h2 z = __builtin_bit_cast(h2, a.z[q]) * __builtin_bit_cast(h2, a.u[q]);
+            if (c < KS_REG) Bn.put(c, nb, mbl, j, z);
         }
     } else if constexpr (!SP) {       // ReLU / multiplication by the stored sigmoid: one packed instruction
         static_assert(ST == 1 && HIDDEN, "pp_instr: stage");
@@ -508,14 +548,30 @@ __device__ __forceinline__ void pp_instr(ActRegs8& a, const ActConst& k, const f
         asm volatile("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(a.d[q]) : "v"(a.z[q]), "v"(a.h[q]));
     } else if constexpr (ST == S0) {  // sigmoid(z') = 2^(z' - h')
         asm volatile("v_exp_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=&v"(a.s[q]) : "v"(a.d[q]));
-    } else {
-        static_assert(ST == S1, "pp_instr: stage");
+    } else if constexpr (ST == S1) {
         asm volatile("v_exp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(a.s[q]) : "v"(a.d[q]));
-        constexpr int e = 2 * mbl + j;   // by name, see the note at the HID_SIGMUL read
-        if constexpr (e == 0) sg[nb].x = a.s[q];
-        else if constexpr (e == 1) sg[nb].y = a.s[q];
-        else if constexpr (e == 2) sg[nb].z = a.s[q];
-        else sg[nb].w = a.s[q];
+        if constexpr (!SIG8) {
+            constexpr int e = 2 * mbl + j;   // by name, see the note at the HID_SIGMUL read
+            if constexpr (e == 0) sg[nb].x = a.s[q];
+            else if constexpr (e == 1) sg[nb].y = a.s[q];
+            else if constexpr (e == 2) sg[nb].z = a.s[q];
+            else sg[nb].w = a.s[q];
+        }
+    } else if constexpr (ST == S1 + 1) {   // 8-bit: 1024 + 255 s (0x5BF8 = 255.0): the mantissa's low byte is round(255 s)
+        static_assert(SIG8, "pp_instr: stage");
+        asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(a.s[q]) : "s"(sconst(0x5BF85BF8u)), "v"(k.c1024));
+    } else {                               // 8-bit: the low bytes of the four halves of row pairs j = 0, 1 into one dword
+        static_assert(SIG8 && ST == S1 + 2, "pp_instr: stage");
+        if constexpr (j == 0) {
+            unsigned d;
+            // D = bytes of {S0 = pair j = 1, S1 = pair j = 0}: S1.b0, S1.b2, S0.b0, S0.b2
+            asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a.s[q + 1]), "v"(a.s[q]), "s"(sconst(0x06040200u)));
+            constexpr int e = 2 * nb + mbl;
+            if constexpr (e == 0) sg[0].x = d;
+            else if constexpr (e == 1) sg[0].y = d;
+            else if constexpr (e == 2) sg[0].z = d;
+            else sg[0].w = d;
+        }
     }
 }
 template <int HID, bool HIDDEN, int I, typename NB_T>
@@ -647,7 +703,7 @@ __device__ __forceinline__ void run_layer_pp(const NetDesc& net, const LayerDesc
             // requested at the head of chunk c and renamed into place behind V(c); a layer's first fragment is requested
             // at its own head): an HBM read under this load takes longer than an M phase, and a fragment fetched at the
             // head of its own chunk stalled every V phase; the wait behind M(c) is COUNTED -- vmcnt(2), everything but the
-            // two loads just issued.  [tools/stream_model.hip: 0.45 -> 0.55 of the MFMA peak for this stream.  Carrying
+            // loads just issued.  [tools/stream_model.hip: 0.45 -> 0.55 of the MFMA peak for this stream.  Carrying
             // the fragment across the LAYER loop as well costs hipcc 7.2 the register file: 256 VGPRs + 112 spilled, from
             // 208 -- and scratch traffic counts in vmcnt.]
             constexpr bool REV = HID == HID_SIGMUL && HIDDEN;
@@ -658,16 +714,17 @@ __device__ __forceinline__ void run_layer_pp(const NetDesc& net, const LayerDesc
 #endif
             u32x4 (&sg)[2] = sgb[0];
             u32x4 sgn[2];
+            constexpr int SGV = SIG8 ? 1 : 2;   // 16-byte vectors per lane and chunk
             if constexpr (REV) {
                 if (!AHEAD || c == 0) {
 #pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
-                        sg[nb] = *(const u32x4*)(sig.base + (size_t)sig_layer * sig.layer_bytes + (c * 2 + nb) * 1024 + lane * 16);
+                    for (int v = 0; v < SGV; ++v)
+                        sg[v] = *(const u32x4*)(sig.base + (size_t)sig_layer * sig.layer_bytes + (c * SGV + v) * 1024 + lane * 16);
                 }
                 if (AHEAD && c + 1 < KS_REG) {
 #pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
-                        sgn[nb] = *(const u32x4*)(sig.base + (size_t)sig_layer * sig.layer_bytes + ((c + 1) * 2 + nb) * 1024 + lane * 16);
+                    for (int v = 0; v < SGV; ++v)
+                        sgn[v] = *(const u32x4*)(sig.base + (size_t)sig_layer * sig.layer_bytes + ((c + 1) * SGV + v) * 1024 + lane * 16);
                 }
             }
             // ---- M(c): 4 accumulators (block mbl, column block nb), biased
@@ -739,7 +796,7 @@ __device__ __forceinline__ void run_layer_pp(const NetDesc& net, const LayerDesc
             // In flight, oldest first: [this chunk's fragment, fetched a chunk ago] [late waves: the DMA pieces issued behind
             // the previous barrier] [the two loads just issued for the next chunk] -- the counted wait covers the first two.
             if constexpr (REV) {
-                if (AHEAD && c + 1 < KS_REG) __builtin_amdgcn_s_waitcnt(0x0F72);   // vmcnt(2)
+                if (AHEAD && c + 1 < KS_REG) __builtin_amdgcn_s_waitcnt(0x0F70 | SGV);   // vmcnt(SGV): all but the loads just issued
                 else dma_wait_all();
             }
             if (late) {
@@ -763,15 +820,15 @@ __device__ __forceinline__ void run_layer_pp(const NetDesc& net, const LayerDesc
 #endif
                 if constexpr (HID == HID_SOFTPLUS_SAVE && HIDDEN) {
 #pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
-                        *(u32x4*)(sig.base + (size_t)sig_layer * sig.layer_bytes + (c * 2 + nb) * 1024 + lane * 16) = sg[nb];
+                    for (int v = 0; v < SGV; ++v)
+                        *(u32x4*)(sig.base + (size_t)sig_layer * sig.layer_bytes + (c * SGV + v) * 1024 + lane * 16) = sg[v];
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (REV) {
                 if (AHEAD && c + 1 < KS_REG) {
 #pragma unroll
-                    for (int nb = 0; nb < 2; ++nb) sg[nb] = sgn[nb];
+                    for (int v = 0; v < SGV; ++v) sg[v] = sgn[v];
                 }
             }
             if (!late) {
@@ -1003,6 +1060,8 @@ __device__ __forceinline__ void run_net(const NetDesc& net, const char* __restri
     constexpr bool PP = !FWD && NB == 2;
 #endif
 #endif
+    static_assert(PP || !SIG8 || (HID != HID_SOFTPLUS_SAVE && HID != HID_SIGMUL),
+                  "the interleaved (round-1) stream stores half-precision sigmoids: build the ablation with -DMP_EXP_SIG16");
     if constexpr (PP) {
         // The phase-separated stream keeps THREE chunks in flight (prologue<.., true>: chunks 0, 1 and 2) and fetches
         // chunk ci + 3 behind the barrier that frees chunk ci's slot.

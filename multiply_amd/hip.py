@@ -420,19 +420,20 @@ def grad_net(imp):
     return g.refresh()
 
 
-SEG_POINTS = int(os.environ.get("MP_SEG_POINTS", 1 << 21))   # work items per segment of the reverse-mode shading (x 4 KiB of stored sigmoids)
+SEG_POINTS = int(os.environ.get("MP_SEG_POINTS", 1 << 21))   # work items per segment of the reverse-mode shading (x 2 KiB of stored sigmoids)
 
 
 def sig_scratch(device, n_points):
-    """(buffer, segment size) for the stored sigmoids of the reverse-mode shading kernels: 4 KiB per work item of ONE
-    segment, sized to the call (min(n rounded up to a tile, SEG_POINTS)) and grown on demand -- never the fixed 8 GiB.
-    New parts are zero-initialised: the K steps a narrower layer never writes (layer 3 has 217 outputs) must read as finite
-    numbers in the reverse sweep."""
+    """(buffer, segment size) for the stored sigmoids of the reverse-mode shading kernels: mp_sig_bytes_per_point() bytes (2 KiB:
+    one byte per hidden unit; 4 KiB in a -DMP_EXP_SIG16 build) per work item of ONE segment, sized to the call (min(n rounded up to
+    a tile, SEG_POINTS)) and grown on demand -- never a fixed multi-GiB block.  New parts are zero-initialised: the K steps a
+    narrower layer never writes (layer 3 has 217 outputs) must read as finite numbers in the reverse sweep."""
+    per = int(lib().mp_sig_bytes_per_point())
     seg = min(SEG_POINTS, max(256, (int(n_points) + 255) // 256 * 256))
     key = str(device)
     buf = _SCRATCH.get(key)
-    if buf is None or buf.numel() < seg * 4096:
-        grown = torch.empty(seg * 4096, dtype=torch.uint8, device=device)
+    if buf is None or buf.numel() < seg * per:
+        grown = torch.empty(seg * per, dtype=torch.uint8, device=device)
         old = 0 if buf is None else buf.numel()
         if old:
             grown[:old] = buf
