@@ -199,7 +199,7 @@ def test_training_parity_at_the_benchmarked_workload():
     for k, v in res["parity_forward_max_abs"].items():
         # measured at this workload: rgb 1.3e-6, acc 2.9e-6, normals 1.2e-4 (82 k shaded samples per person: the worst one
         # sits where |grad sdf| is small and the normalisation amplifies the fp32 summation-order difference)
-        assert v < (6e-4 if k == "normal_values" else 2 * TOL.train_fwd().get(k, 8e-6)), (k, v)
+        assert v < (6e-4 if k == "normal_values" else 3 * TOL.train_fwd().get(k, 8e-6)), (k, v)
 
 
 def test_training_step_reduces_loss():

