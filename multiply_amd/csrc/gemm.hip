@@ -155,34 +155,37 @@ constexpr int LDK16 = BK + 8;   // bf16 elements per LDS row: 80 B, 16 B aligned
 // 120 KB of LDS = one workgroup per CU) 58.6 us -- neither memory latency nor the repeated read is what bounds it (the repeat is
 // served by the Infinity Cache); at 100-150 MB per product it runs at 2.2-3.3 TB/s.  PA = 1 is what is instantiated.
 // Fragments of A are read per row block inside the MFMA loop: 91 VGPRs, two workgroups (four waves per SIMD) per CU.
-template <bool FAST, int PA>
+// NJ: 16-column blocks per wave (2: a 128 x 128 tile of C per workgroup; 4: 128 x 256 = the whole width of the 256-wide layers,
+// the activation rows are fetched ONCE instead of once per column tile);  NST: LDS stages (2: loads of stage t + 1 stored while
+// stage t is multiplied, one barrier per stage; 1: one buffer, two barriers per stage, half the LDS -> twice the workgroups per CU)
+template <bool FAST, int PA, int NJ, int NST>
 __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt_b3(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                        float* __restrict__ C, int ldc, int M, int N, int K,
                                                        const float* __restrict__ bias, int bias_rows, int accumulate, int relu) {
     static_assert(PA == 1 || FAST, "the deep prefetch is for the bounds-free path");
+    constexpr int BNW = 64 * NJ, QB = BNW / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // [stage][hi | lo][row][k] for A, then the same for B
     __bf16* As = (__bf16*)smem;
-    __bf16* Bs = As + 2 * 2 * BM * LDK16;
+    __bf16* Bs = As + NST * 2 * BM * LDK16;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int wm = (wave >> 2) * 64, wn = (wave & 3) * 32;   // 2 x 4 waves, each 64 x 32
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BNW;
+    const int wm = (wave >> 2) * 64, wn = (wave & 3) * 16 * NJ;   // 2 x 4 waves, each 64 x 16 NJ
     const int li = lane & 15, lq = lane >> 4;
-    f32x4 acc[4][2];
+    f32x4 acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
     const int sr = t >> 3, sk = (t & 7) * 4;       // staging: row sr + 64 q, k offset sk
     const bool a_al = (lda & 3) == 0 && ((size_t)A & 15) == 0, b_al = (ldb & 3) == 0 && ((size_t)B & 15) == 0;
-    f32x4 ra[PA][2], rb[2];
+    f32x4 ra[PA][2], rb[QB];
     const float* pa[2];
-    const float* pb[2];
+    const float* pb[QB];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        pa[q] = A + (size_t)min(m0 + sr + 64 * q, M - 1) * lda + sk;
-        pb[q] = B + (size_t)min(n0 + sr + 64 * q, N - 1) * ldb + sk;
-    }
+    for (int q = 0; q < 2; ++q) pa[q] = A + (size_t)min(m0 + sr + 64 * q, M - 1) * lda + sk;
+#pragma unroll
+    for (int q = 0; q < QB; ++q) pb[q] = B + (size_t)min(n0 + sr + 64 * q, N - 1) * ldb + sk;
     auto gload_a = [&](f32x4 (&r)[2], int k0) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt_b3(const float* __res
     };
     auto gload_b = [&](int k0) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < QB; ++q) {
             if constexpr (FAST) {
                 rb[q] = *(const f32x4*)(pb[q] + k0);
             } else {
@@ -205,35 +208,34 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt_b3(const float* __res
             }
         }
     };
-    auto split_store = [&](__bf16* tile, f32x4 v, int row) {   // tile = [hi | lo][row][k] of one stage
+    auto split_store = [&](__bf16* tile, int rows, f32x4 v, int row) {   // tile = [hi | lo][rows][k] of one stage
         const bf16x4 hi = __builtin_convertvector(v, bf16x4);
         const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
         *(bf16x4*)(tile + row * LDK16 + sk) = hi;
-        *(bf16x4*)(tile + BM * LDK16 + row * LDK16 + sk) = lo;
+        *(bf16x4*)(tile + rows * LDK16 + row * LDK16 + sk) = lo;
     };
     auto sstore = [&](int buf, const f32x4 (&r)[2]) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            split_store(As + buf * 2 * BM * LDK16, r[q], sr + 64 * q);
-            split_store(Bs + buf * 2 * BN * LDK16, rb[q], sr + 64 * q);
-        }
+        for (int q = 0; q < 2; ++q) split_store(As + buf * 2 * BM * LDK16, BM, r[q], sr + 64 * q);
+#pragma unroll
+        for (int q = 0; q < QB; ++q) split_store(Bs + buf * 2 * BNW * LDK16, BNW, rb[q], sr + 64 * q);
     };
     auto mfma_stage = [&](int buf) {
         const __bf16* at = As + buf * 2 * BM * LDK16;
-        const __bf16* bt = Bs + buf * 2 * BN * LDK16;
-        bf16x8 bh[2], bl[2];
+        const __bf16* bt = Bs + buf * 2 * BNW * LDK16;
+        bf16x8 bh[NJ], bl[NJ];
         // lane (li, lq) supplies k = 8 lq .. 8 lq + 7 of its row (the k index of an MFMA is free to permute): one b128 per operand
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             bh[j] = *(const bf16x8*)(bt + (wn + j * 16 + li) * LDK16 + 8 * lq);
-            bl[j] = *(const bf16x8*)(bt + BN * LDK16 + (wn + j * 16 + li) * LDK16 + 8 * lq);
+            bl[j] = *(const bf16x8*)(bt + BNW * LDK16 + (wn + j * 16 + li) * LDK16 + 8 * lq);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bf16x8 ah = *(const bf16x8*)(at + (wm + i * 16 + li) * LDK16 + 8 * lq);
             const bf16x8 al = *(const bf16x8*)(at + BM * LDK16 + (wm + i * 16 + li) * LDK16 + 8 * lq);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);   // the small terms first
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
@@ -250,12 +252,13 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt_b3(const float* __res
     for (int kt0 = 0; kt0 < nk; kt0 += PA) {
 #pragma unroll
         for (int u = 0; u < PA; ++u) {
-            const int kt = kt0 + u, buf = kt & 1;
+            const int kt = kt0 + u, buf = NST == 2 ? (kt & 1) : 0;
             if (kt < nk) {
                 if (kt + 1 < nk) gload_b((kt + 1) * BK);
                 if (kt + PA < nk) gload_a(ra[u], (kt + PA) * BK);     // slot u held stage kt: stored to LDS one iteration ago
                 mfma_stage(buf);
-                if (kt + 1 < nk) sstore(buf ^ 1, ra[(u + 1) % PA]);
+                if constexpr (NST == 1) __syncthreads();               // every wave is done reading the only buffer
+                if (kt + 1 < nk) sstore(NST == 2 ? (buf ^ 1) : 0, ra[(u + 1) % PA]);
                 __syncthreads();
             }
         }
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt_b3(const float* __res
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int n = n0 + wn + j * 16 + cn;
             if (n >= N) continue;
             const float bn = bias ? bias[n] : 0.0f;
@@ -489,7 +492,11 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_tn_b3(const float* __res
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm + 16 * i + cr + r;
+#ifdef MP_EXP_TN_NOATOMIC   // ablation (wrong sums): what do the fp32 atomics of the split-K epilogue cost?
+                if (m < M) C[(size_t)m * ldc + n] = acc[i][j][r];
+#else
                 if (m < M) atomicAdd(C + (size_t)m * ldc + n, acc[i][j][r]);
+#endif
             }
         }
     if (colsum != nullptr && blockIdx.y == 0) {   // A-staging threads with the same mg hold partial sums of the same 4 columns
@@ -523,18 +530,25 @@ extern "C" int mp_gemm_nt(const float* A, int lda, const float* B, int ldb, floa
     return (int)hipGetLastError();
 }
 
+#ifndef MP_NT_WIDE      // ablation switch: 1 = layers wider than 128 take the 128 x 256 single-stage tile (activation rows read once;
+#define MP_NT_WIDE 0    // 150 VGPRs, one workgroup per CU: 58 us per 50k x 256 x 256 product); 0 (default) = 128 x 128 two-stage: 49 us
+#endif
 extern "C" int mp_gemm_nt_bf16x3(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
                                  const float* bias, int bias_rows, int accumulate, int relu, void* stream) {
     if (M <= 0 || N <= 0) return 0;
-    constexpr int LDS_B3 = 2 * 2 * (BM + BN) * LDK16 * 2;   // 2 stages x (hi, lo) x (A, B) tiles of bf16
-    MP_LDS_ATTR((k_gemm_nt_b3<true, 1>), LDS_B3);
-    MP_LDS_ATTR((k_gemm_nt_b3<false, 1>), LDS_B3);
+    constexpr int LDS_22 = 2 * 2 * (BM + 128) * LDK16 * 2;   // 2 stages x (hi, lo) x (A tile + 128-row B tile) of bf16: 80 KB
+    constexpr int LDS_41 = 1 * 2 * (BM + 256) * LDK16 * 2;   // 1 stage, 256-row B tile: 60 KB
+    MP_LDS_ATTR((k_gemm_nt_b3<true, 1, 2, 2>), LDS_22);
+    MP_LDS_ATTR((k_gemm_nt_b3<false, 1, 2, 2>), LDS_22);
+    MP_LDS_ATTR((k_gemm_nt_b3<true, 1, 4, 1>), LDS_41);
+    MP_LDS_ATTR((k_gemm_nt_b3<false, 1, 4, 1>), LDS_41);
     const bool fast = (lda & 3) == 0 && (ldb & 3) == 0 && ((size_t)A & 15) == 0 && ((size_t)B & 15) == 0 && K % BK == 0;
-    const dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
-#define MP_NT_B3(F, P) hipLaunchKernelGGL((k_gemm_nt_b3<F, P>), grid, dim3(NT_THREADS), LDS_B3, (hipStream_t)stream, A, lda, B, ldb, C, \
-                                           ldc, M, N, K, bias, bias_rows, accumulate, relu)
-    if (fast) MP_NT_B3(true, 1);
-    else MP_NT_B3(false, 1);
+    const bool wide = MP_NT_WIDE && N > 128;
+    const dim3 grid((M + BM - 1) / BM, wide ? (N + 255) / 256 : (N + 127) / 128);
+#define MP_NT_B3(F, J, S, L) hipLaunchKernelGGL((k_gemm_nt_b3<F, 1, J, S>), grid, dim3(NT_THREADS), L, (hipStream_t)stream, A, lda, B, ldb, \
+                                                 C, ldc, M, N, K, bias, bias_rows, accumulate, relu)
+    if (wide) { if (fast) MP_NT_B3(true, 4, 1, LDS_41); else MP_NT_B3(false, 4, 1, LDS_41); }
+    else      { if (fast) MP_NT_B3(true, 2, 2, LDS_22); else MP_NT_B3(false, 2, 2, LDS_22); }
 #undef MP_NT_B3
     return (int)hipGetLastError();
 }
