@@ -580,8 +580,11 @@ extern "C" int mp_gemm_tn(const float* A, int lda, const float* B, int ldb, floa
 extern "C" int mp_gemm_tn_bf16x3(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
                                  float* colsum, int colsum_rows, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
+#ifndef MP_TN_WGS       // workgroups the contraction is split into (tiles x row slices): every slice adds its 128 x 128 partial to C with
+#define MP_TN_WGS 512   // fp32 atomics, so fewer slices = fewer atomics but less of the chip busy
+#endif
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    int slices = (512 + tiles - 1) / tiles;
+    int slices = (MP_TN_WGS + tiles - 1) / tiles;
     int rows = (K + slices - 1) / slices;
     rows = (rows + BK - 1) / BK * BK;
     if (rows < 4 * BK) rows = 4 * BK;

@@ -293,15 +293,20 @@ class Multiply(nn.Module):
             else:
                 if self._obb_mode_now() == "hull":
                     # hull on the host (Qhull, ~3 ms; the one extra device sync of this mode), search + box on the device
-                    from .obb import hull_search_inputs
-                    buf, nh, nn_, ne = hull_search_inputs(verts.cpu().numpy())
-                    hb = torch.from_numpy(buf).to(dev)
-                    o_n, o_e = 3 * nh, 3 * (nh + nn_)
-                    work = torch.empty(2 * nn_, dtype=torch.float64, device=dev)
-                    obb = torch.empty(16, **f32)
-                    hip.check(L.mp_obb_hull(hip.ptr(hb), nh, hip.ptr(hb[o_n:]), nn_, hip.ptr(hb[o_e:]), hip.ptr(hb[o_e + 3 * ne:]),
-                                            hip.ptr(hb[o_e + 6 * ne:]), ne, C.c_float(self.obb_inflate), hip.ptr(work),
-                                            hip.ptr(obb), st), "mp_obb_hull")
+                    from .obb import hull_search_inputs, obb_record
+                    vhost = verts.cpu().numpy()
+                    buf, nh, nn_, ne = hull_search_inputs(vhost)
+                    if nh > 4096:      # beyond the kernel's LDS tile (a body's hull has a few hundred vertices): the host statement
+                        obb = torch.from_numpy(obb_record(vhost, self.obb_inflate)).to(dev)
+                        buf = None
+                    hb = torch.from_numpy(buf).to(dev) if buf is not None else None
+                    if hb is not None:
+                        o_n, o_e = 3 * nh, 3 * (nh + nn_)
+                        work = torch.empty(2 * nn_, dtype=torch.float64, device=dev)
+                        obb = torch.empty(16, **f32)
+                        hip.check(L.mp_obb_hull(hip.ptr(hb), nh, hip.ptr(hb[o_n:]), nn_, hip.ptr(hb[o_e:]), hip.ptr(hb[o_e + 3 * ne:]),
+                                                hip.ptr(hb[o_e + 6 * ne:]), ne, C.c_float(self.obb_inflate), hip.ptr(work),
+                                                hip.ptr(obb), st), "mp_obb_hull")
                 else:
                     obb = torch.empty(16, **f32)
                     hip.check(L.mp_obb(hip.ptr(verts), C.c_float(self.obb_inflate), hip.ptr(obb), st), "mp_obb")
