@@ -1,44 +1,57 @@
-"""The prompt construction around Segment-Anything (multiply_amd/sam_prompts.py) against its line-by-line restatement
-(oracle/sam_oracle.py) under the same random stream, and the refresh loop end to end on a written sequence with a stand-in
-predictor (SAM itself is a third-party model that is not part of this repository)."""
+"""The prompt construction around Segment-Anything (multiply_amd/sam_prompts.py) against the REFERENCE's own
+SAMServer.get_sam_mask run on the same written sequences (tests/golden/sam_golden.npz, made by make_sam_golden.py with
+segment_anything / hydra / cv2 stubbed: the fixture holds every prompt the reference handed to the predictor, in order, and
+the mask file it wrote), and the refresh loop end to end on a written sequence with a stand-in predictor (SAM itself is a
+third-party model that is not part of this repository)."""
 import os
 
 import numpy as np
 import pytest
 
 from multiply_amd import sam_prompts as SP
-from oracle import sam_oracle as SO
+from tests.sam_standin import StandInPredictor
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sam_golden.npz")
 
 
-def scene(rs, H=60, W=88, P=3):
-    yy, xx = np.mgrid[:H, :W]
-    masks = np.zeros((P, H, W), dtype=bool)
-    joints = np.zeros((P, 29, 2), dtype=np.int32)
-    for p in range(P):
-        cx, cy = W * (0.25 + 0.25 * p), H * 0.5
-        masks[p] = (((xx - cx) / (0.14 * W)) ** 2 + ((yy - cy) / (0.4 * H)) ** 2) < 1
-        joints[p, :, 0] = np.clip(rs.normal(cx, 0.12 * W, 29), -5, W + 4).astype(np.int32)     # some off the mask, some off the image
-        joints[p, :, 1] = np.clip(rs.normal(cy, 0.3 * H, 29), -5, H + 4).astype(np.int32)
-    return masks, joints
-
-
-def test_prompts_match_the_restatement_under_the_same_random_stream():
-    rs = np.random.RandomState(0)
-    for trial in range(4):
-        masks, joints = scene(rs, P=2 + trial % 2)
-        if trial == 3:
-            joints[0, :27] = [[0, 0]] * 27                      # no key point on the mask: random fallback pixel
-        a, b = np.random.RandomState(42), np.random.RandomState(42)
-        for person in range(masks.shape[0]):
-            coords, labels = SP.point_prompts(masks, joints, person, a)
-            want = SO.person_prompts(masks, joints, person, b)
-            assert coords.shape == want[0].shape and np.array_equal(coords, want[0]), (trial, person)
-            assert np.array_equal(labels, want[1])
-            assert np.array_equal(SP.box_from_mask(masks[person]), want[2])
-            got_mask = SP.mask_prompt(masks[person])
-            assert got_mask.shape == (1, 256, 256) and np.array_equal(got_mask, want[3])
-            assert labels[:int(labels.sum())].all() and (labels[int(labels.sum()):] == 0).all() and (labels == 0).sum() >= 10
-        assert a.randint(0, 1 << 30) == b.randint(0, 1 << 30)   # both consumed the stream identically
+@pytest.mark.parametrize("case", ["wide", "tall", "square"])
+def test_prompts_and_mask_file_match_the_reference_run(case, tmp_path):
+    """the whole refresh (random stream seeded once, then per frame and person: fallback positives, the permutation, the ten
+    random negatives, the neighbours' key points; box; padded 256 x 256 mask logits; three rounds) reproduces what the
+    reference's sam_model.py:58-239 did on these inputs"""
+    from PIL import Image
+    from multiply_amd.config import to_config
+    g = np.load(GOLDEN)
+    images, masks, joints = g[f"{case}_images"], g[f"{case}_masks"], g[f"{case}_joints"]
+    start, end = (int(v) for v in g[f"{case}_range"])
+    root = tmp_path / "data" / "seq"
+    (root / "image").mkdir(parents=True)
+    for f in range(images.shape[0]):
+        Image.fromarray(images[f]).save(str(root / "image" / ("%04d.png" % f)))
+    stage = tmp_path / "run"
+    (stage / "stage_instance_mask" / "00050").mkdir(parents=True)
+    np.save(str(stage / "stage_instance_mask" / "00050" / "all_person_smpl_mask.npy"), masks[start:end])
+    np.save(str(stage / "stage_instance_mask" / "00050" / "2d_keypoint.npy"), joints[start:end])
+    pred = StandInPredictor()
+    server = SP.SAMServer(to_config(dict(data_root=str(tmp_path / "data"), data_dir="seq", start_frame=start, end_frame=end)),
+                          predictor=pred)
+    out = server.get_sam_mask(50, stage_dir=str(stage))
+    P = masks.shape[1]
+    assert len(pred.calls) == 3 * (end - start) * P
+    for k in range((end - start) * P):
+        first = pred.calls[3 * k]
+        want = g[f"{case}_coords_{k}"]
+        assert first["coords"].shape == want.shape and np.array_equal(first["coords"], want), (case, k)
+        assert np.array_equal(first["labels"], g[f"{case}_labels_{k}"]) and np.array_equal(first["box"], g[f"{case}_box_{k}"])
+        on = np.unpackbits(g[f"{case}_mask_on_{k}"])[:256 * 256].reshape(256, 256).astype(bool)
+        assert np.array_equal(first["mask_input"][0] > 0, on), (case, k)
+        assert np.array_equal(np.unique(first["mask_input"]), g[f"{case}_mask_vals_{k}"])           # fp32 logit(eps), logit(1 - eps)
+        for r in range(3):                                                                        # the logits fed back round to round
+            assert np.array_equal(pred.calls[3 * k + r]["coords"], want)
+            assert abs(float(pred.calls[3 * k + r]["mask_input"].astype(np.float64).mean()) - g[f"{case}_mask_mean_rounds_{k}"][r]) < 1e-6
+    want = g[f"{case}_written"]
+    assert out.shape == want.shape and out.dtype == want.dtype and np.allclose(out, want, atol=1e-5, rtol=0)
+    assert np.array_equal(np.load(str(stage / "stage_sam_mask" / "00050" / "sam_opt_mask.npy")), out)
 
 
 def test_mask_prompt_keeps_the_shape_of_the_mask():
