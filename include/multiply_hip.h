@@ -385,6 +385,24 @@ int mp_raster_zbuf(const float* verts, int n_verts, const int* faces, int n_face
                    int H, int W, unsigned long long* keys, int* big, float* zbuf, int* pix_to_face, float* bary,
                    void* stream);
 
+/* ---- soft silhouette render (code/lib/model/render.py:79-105, 121-133 softrender_multiple_meshes: pytorch3d's blurred
+ * MeshRasterizer + SoftPhongShader under white ambient light = softmax_rgb_blend of the interpolated vertex colours; consumer
+ * multiply_model.py:636-637, :721).  Two calls, because the length of the tile lists is only known after the count:
+ *   mp_raster_soft_bins  faces -> 8 x 8-pixel tiles: tile_n [T] scratch (T = ceil(H/8) ceil(W/8)), offsets [T + 1] exclusive
+ *                        offsets of the tile lists, offsets[T] = total entries (-1: more than INT_MAX)
+ *   mp_raster_soft       list [offsets[T]] scratch, colors [n_verts][3]; image [H][W][4] = RGB over the background + the
+ *                        silhouette 1 - prod(1 - prob); sel [H][W][faces_per_pixel] (optional): the selected faces of every
+ *                        pixel in no particular order, -1 padded.  faces_per_pixel <= 100.  cam_host / background_host
+ *                        (3 floats) IN HOST MEMORY; camera and pixel conventions of mp_raster_zbuf; distances are pytorch3d
+ *                        NDC units (the shorter image side spans [-1, 1]), blur_radius a SQUARED distance.
+ * pytorch3d is third party and unpinned: restated, see csrc/raster.hip. */
+int mp_raster_soft_bins(const float* verts, int n_verts, const int* faces, int n_faces, const float* cam_host, float z_clip,
+                        int H, int W, float blur_radius, int* tile_n, int* offsets, void* stream);
+int mp_raster_soft(const float* verts, int n_verts, const int* faces, int n_faces, const float* colors, const float* cam_host,
+                   float z_clip, int H, int W, float sigma, float gamma, float blur_radius, int faces_per_pixel, float znear,
+                   float zfar, const float* background_host, int* tile_n, const int* offsets, int* list, float* image, int* sel,
+                   void* stream);
+
 /* library / device info: returns the gfx arch string compiled in, and checks the current device */
 const char* mp_arch(void);
 int mp_device_ok(void);

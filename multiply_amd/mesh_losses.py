@@ -146,9 +146,12 @@ def get_depth_order_loss(model, inputs, epoch, loss_opt=None, meshes=None, draws
     fade = 1 - min(DEPTH_LOSS_MILESTONE, epoch) / DEPTH_LOSS_MILESTONE
     inter = loss_opt.get("interpenetration_loss_weight", 0.0) * fade * interpenetration_loss(vs, fs, draws=draws)
     sil_w = loss_opt.get("silhouette_weight", 0.0)
-    if sil_w != 0.0:
-        raise NotImplementedError("silhouette_weight != 0 needs the soft blend (render.Renderer.softrender_multiple_meshes)")
     sil = torch.zeros((), device=depth[0].device)
+    if sil_w != 0.0:                       # multiply_model.py:618-637, :656-668, :721 (the reference renders it even at weight 0)
+        cols = [torch.tensor(COLOR_DICT[p], device=v.device).repeat(v.shape[1], 1)[None] / 255.0 for p, v in enumerate(vs)]
+        rmap = 255 * renderer.softrender_multiple_meshes(vs, fs, cols)[0]
+        rgb = rmap[..., :3] * (rmap[..., [3]] / 255.0)
+        sil = sil_w * torch.nn.functional.mse_loss(gt_instance_map(inputs["org_sam_mask"], len(vs)), rgb) * fade
     order = depth_order_loss(depth, inputs["org_sam_mask"], epoch, loss_opt.get("depth_order_weight", 0.005))
     return order, sil, inter
 

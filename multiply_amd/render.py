@@ -9,9 +9,10 @@ pytorch3d for the K = 10 nearest faces and reads slot 0 only (multiply_model.py:
 
 `render_multiple_meshes` (hard vertex-colour image) is the nearest-face limit of pytorch3d's SoftPhongShader blend: exact
 where a pixel's second face is further than ~0.07 depth units behind the first (its blend weight is
-exp(-dz / (99 * 1e-4))), an approximation at thinner parts.  `softrender_multiple_meshes` (sigma = 5e-5, 100 faces per
-pixel) feeds only the silhouette term whose weight is 0 in every shipped config (confs/model/*.yaml silhouette_weight):
-not built, raises.
+exp(-dz / (99 * 1e-4))), an approximation at thinner parts.  `softrender_multiple_meshes` (sigma = 5e-5, gamma = 1e-4, 100
+faces per pixel; feeds the silhouette term of multiply_model.py:636-637, :721, whose weight is 0 in every shipped config) runs
+the blurred rasteriser + softmax blend of csrc/raster.hip (mp_raster_soft_bins, mp_raster_soft) and back-propagates into
+the vertices through a torch re-evaluation of the kernel's face selection.
 """
 import ctypes as C
 
@@ -21,6 +22,9 @@ import torch
 from . import hip
 
 Z_CLIP = 1e-6
+# render.py:79-86: BlendParams(sigma=5e-5, gamma=1e-4), blur_radius = log(1 / 1e-4 - 1) sigma (a squared NDC distance), 100 faces
+SOFT_SIGMA, SOFT_GAMMA, SOFT_K = 5e-5, 1e-4, 100
+SOFT_BLUR = float(np.log(1.0 / 1e-4 - 1.0) * SOFT_SIGMA)
 
 
 class Fragments:
@@ -64,6 +68,69 @@ def get_renderer(inputs):
     r = Renderer(img_size=[int(img_size[0]), int(img_size[1])], cam_intrinsic=K)
     r.set_camera(torch.tensor(R)[None].float(), torch.tensor(T)[None].float())
     return r
+
+
+def soft_blend_selected(verts, faces, colors, sel, R, T, focal, principal, H, W, chunk=8192):
+    """The soft blend in torch for the pixels that blend at least one face, GIVEN the face selection sel (H, W, K; -1 padded,
+    any order): verts (V, 3) world, faces (F, 3), colors (V, 3), R (3, 3) / T (3,) OpenCV world -> camera, focal / principal
+    (2,) in pixels.  -> act (n, 2) [row, col], rgba (n, 4); differentiable in verts and colors (pytorch3d back-propagates
+    through the distances, the clipped barycentrics and the depths of the selected faces)."""
+    dev = verts.device
+    act = (sel[..., 0] >= 0).nonzero(as_tuple=False)
+    if act.shape[0] == 0:
+        return act, torch.zeros(0, 4, device=dev) + 0.0 * verts.sum()
+    R, T = R.to(dev), T.to(dev)
+    sc = 2.0 / min(H, W)
+    dt = torch.float64 if verts.dtype == torch.float64 else torch.float32       # float64: the CPU tests' finite differences
+    R, T, focal, principal = R.to(dt), T.to(dt), focal.to(dt), principal.to(dt)
+    cam = verts.reshape(-1, 3).to(dt) @ R.t() + T
+    z = cam[:, 2]
+    sxy = torch.stack([focal[0] * cam[:, 0] / z + principal[0],
+                       focal[1] * cam[:, 1] / z + principal[1]], 1) * sc
+    faces = faces.reshape(-1, 3).long().to(dev)
+    cols = colors.reshape(-1, 3).to(device=dev, dtype=dt)
+    eps = 1e-10
+
+    def seg(p, a, b):
+        ba = b - a
+        l2 = (ba * ba).sum(-1)
+        t = (((p - a) * ba).sum(-1) / l2.clamp(min=1e-30)).clamp(0.0, 1.0)
+        q = a + t[..., None] * ba
+        return torch.where(l2 <= 1e-8, ((p - b) ** 2).sum(-1), ((p - q) ** 2).sum(-1))
+
+    def edge(p, a, b):
+        return (p[..., 0] - a[..., 0]) * (b[..., 1] - a[..., 1]) - (p[..., 1] - a[..., 1]) * (b[..., 0] - a[..., 0])
+
+    parts = []
+    for i in range(0, act.shape[0], chunk):
+        rc = act[i:i + chunk]
+        fsel = sel[rc[:, 0], rc[:, 1]].long()                                     # (n, K)
+        mask = fsel >= 0
+        tri = faces[fsel.clamp(min=0)]                                            # (n, K, 3)
+        p = (torch.stack([rc[:, 1], rc[:, 0]], 1).to(dt) + 0.5)[:, None, :] * sc   # (n, 1, 2)
+        v0, v1, v2 = sxy[tri[..., 0]], sxy[tri[..., 1]], sxy[tri[..., 2]]
+        z0, z1, z2 = z[tri[..., 0]], z[tri[..., 1]], z[tri[..., 2]]
+        a = edge(v2, v0, v1) + 1e-8
+        w0, w1, w2 = edge(p, v1, v2) / a, edge(p, v2, v0) / a, edge(p, v0, v1) / a
+        inside = (w0 > 0) & (w1 > 0) & (w2 > 0)
+        dist = torch.minimum(torch.minimum(seg(p, v0, v1), seg(p, v0, v2)), seg(p, v1, v2))
+        sd = torch.where(inside, -dist, dist)
+        t0, t1, t2 = w0 * z1 * z2, z0 * w1 * z2, z0 * z1 * w2
+        d = (t0 + t1 + t2).clamp(min=1e-8)
+        b = torch.stack([t0 / d, t1 / d, t2 / d], -1).clamp(min=0.0)
+        b = b / b.sum(-1, keepdim=True).clamp(min=1e-5)
+        pz = b[..., 0] * z0 + b[..., 1] * z1 + b[..., 2] * z2
+        tex = (b[..., None] * cols[tri]).sum(-2)                                   # (n, K, 3)
+        prob = torch.sigmoid(-sd / SOFT_SIGMA) * mask
+        alpha = torch.prod(1.0 - prob, dim=-1)
+        zinv = (100.0 - pz) / 99.0 * mask
+        zmax = zinv.max(dim=-1, keepdim=True).values.clamp(min=eps)
+        w = prob * torch.exp((zinv - zmax) / SOFT_GAMMA)
+        delta = torch.exp((eps - zmax) / SOFT_GAMMA).clamp(min=eps)
+        den = w.sum(-1, keepdim=True) + delta
+        rgb = ((w[..., None] * tex).sum(-2) + delta) / den                         # white background
+        parts.append(torch.cat([rgb, 1.0 - alpha[:, None]], 1))
+    return act, torch.cat(parts)
 
 
 class Renderer:
@@ -161,9 +228,58 @@ class Renderer:
         img[hit] = torch.cat([(frag.bary_coords[0, :, :, 0][hit][:, :, None] * c3).sum(1), torch.ones_like(c3[:, 0, :1])], 1)
         return img[None]
 
+    def soft_rasterize(self, verts, faces, colors, want_sel=False):
+        """csrc/raster.hip mp_raster_soft_bins + mp_raster_soft on one joined mesh: -> image (H, W, 4), and with want_sel the
+        (H, W, K) faces each pixel blended (-1 padded).  One host read (the length of the tile lists)."""
+        H, W = self.image_size
+        v = verts.detach().reshape(-1, 3).float().contiguous().to(self.device)
+        f = faces.reshape(-1, 3).to(device=self.device, dtype=torch.int32).contiguous()
+        c = colors.detach().reshape(-1, 3).float().contiguous().to(self.device)
+        if c.shape[0] != v.shape[0]:
+            raise ValueError("one colour per vertex")
+        T = ((H + 7) // 8) * ((W + 7) // 8)
+        tile_n = torch.empty(T, dtype=torch.int32, device=self.device)
+        offsets = torch.empty(T + 1, dtype=torch.int32, device=self.device)
+        cam = self._cam16()
+        L = hip.lib()
+        hip.check(L.mp_raster_soft_bins(hip.ptr(v), v.shape[0], hip.ptr(f), f.shape[0], C.cast(cam, C.c_void_p), Z_CLIP, H, W,
+                                        SOFT_BLUR, hip.ptr(tile_n), hip.ptr(offsets), hip.stream()), "mp_raster_soft_bins")
+        total = int(offsets[T])
+        if total < 0:
+            raise RuntimeError("soft render: the tile lists exceed 2^31 entries")
+        lst = torch.empty(max(total, 1), dtype=torch.int32, device=self.device)
+        image = torch.empty(H, W, 4, dtype=torch.float32, device=self.device)
+        sel = torch.empty(H, W, SOFT_K, dtype=torch.int32, device=self.device) if want_sel else None
+        bg = (C.c_float * 3)(1.0, 1.0, 1.0)                                       # BlendParams' default background
+        hip.check(L.mp_raster_soft(hip.ptr(v), v.shape[0], hip.ptr(f), f.shape[0], hip.ptr(c), C.cast(cam, C.c_void_p), Z_CLIP,
+                                   H, W, SOFT_SIGMA, SOFT_GAMMA, SOFT_BLUR, SOFT_K, 1.0, 100.0, C.cast(bg, C.c_void_p),
+                                   hip.ptr(tile_n), hip.ptr(offsets), hip.ptr(lst), hip.ptr(image),
+                                   hip.ptr(sel) if want_sel else None, hip.stream()), "mp_raster_soft")
+        return image, sel
+
+    def _soft_with_grad(self, verts, faces, colors, image, sel):
+        """the blend once more in torch with the kernel's face selection, so that d image / d vertices (and colours) exists;
+        the forward value stays the kernel's"""
+        H, W = self.image_size
+        act, soft = soft_blend_selected(verts, faces, colors, sel, self.cam_R[0], self.cam_T[0], self.focal_length[0],
+                                        self.principal_point[0], H, W)
+        lin = act[:, 0] * W + act[:, 1]
+        return image.reshape(-1, 4).index_add(0, lin, soft - soft.detach()).reshape(H, W, 4)
+
     def softrender_multiple_meshes(self, verts_list, faces_list, verts_colors_list):
-        raise NotImplementedError("the sigma = 5e-5 / 100-faces-per-pixel soft blend only feeds the silhouette term, whose "
-                                  "weight is 0 in every shipped config (silhouette_weight); not built")
+        """render.py:121-133: the meshes joined as one scene through the blurred rasteriser (sigma = 5e-5, gamma = 1e-4, 100
+        faces per pixel) and SoftPhongShader under white ambient light -> (1, H, W, 4): RGB = depth-softmax blend of the
+        interpolated vertex colours over white, A = 1 - prod(1 - sigmoid(-d / sigma)), the soft silhouette.  Differentiable
+        in the vertices and colours."""
+        nv = np.cumsum([0] + [v.reshape(-1, 3).shape[0] for v in verts_list])
+        verts = torch.cat([v.reshape(-1, 3).float() for v in verts_list])
+        faces = torch.cat([f.reshape(-1, 3).long() + int(o) for f, o in zip(faces_list, nv[:-1])])
+        cols = torch.cat([c.reshape(-1, 3).float() for c in verts_colors_list])
+        need_grad = torch.is_grad_enabled() and (verts.requires_grad or cols.requires_grad)
+        image, sel = self.soft_rasterize(verts, faces, cols, want_sel=need_grad)
+        if need_grad:
+            image = self._soft_with_grad(verts.to(self.device), faces, cols.to(self.device), image, sel)
+        return image[None]
 
     def render_mesh_recon(self, verts, faces, R=None, T=None, colors=None, mode="npat"):
         """render.py:161-208: shaded / normal / albedo / textured views side by side (along H), vertex normals as the

@@ -118,3 +118,96 @@ def test_projection_decomposition_matches_its_construction():
         from multiply_amd.render import decompose_projection
         K3, R3, c3 = decompose_projection(P)
         assert np.allclose(K3, K2) and np.allclose(R3, R2) and np.allclose(c3, c2)
+
+
+# ---- the soft silhouette render (oracle/raster_oracle.soft_render; multiply_amd.render.soft_blend_selected in torch) ----------
+SIGMA, GAMMA = 5e-5, 1e-4
+BLUR = np.log(1.0 / 1e-4 - 1.0) * SIGMA
+
+
+def test_soft_silhouette_of_a_fronto_parallel_triangle_is_the_sigmoid_of_the_squared_ndc_distance():
+    # triangle at z = 3 whose vertical right edge projects to x = 40.2 px: a pixel centre at distance d px outside has
+    # alpha = sigmoid(-(d * 2 / min(H, W))^2 / sigma), pixels well inside are opaque red, far pixels the white background
+    z, x_right_px = 3.0, 40.2
+    x1 = (x_right_px - CX) / FX * z
+    v = np.array([[-0.5, -0.6, z], [x1, -0.6, z], [x1, 0.55, z]])
+    red = np.tile([[1.0, 0.0, 0.0]], (3, 1))
+    r = 24                                                    # a row inside the edge's vertical extent
+    for faces in ([[0, 1, 2]], [[2, 1, 0]]):                  # either winding
+        img = RO.soft_render(v, faces, red, EYE, ZERO, FX, FY, CX, CY, H, W)
+        for c in (40, 41):                                    # centres at 40.5 and 41.5: 0.3 and 1.3 px outside
+            d = (c + 0.5 - x_right_px) * 2.0 / min(H, W)
+            want = 1.0 / (1.0 + np.exp(d * d / SIGMA))
+            assert abs(img[r, c, 3] - want) < 1e-9, (c, img[r, c, 3], want)
+            # the COLOUR is the face's however small its probability (the background's weight delta is 1e-10 once any face is
+            # blended): only the alpha channel carries the silhouette, which is why the caller multiplies the two (:668)
+            assert np.allclose(img[r, c, :3], [1, 1e-10 / (want + 1e-10), 1e-10 / (want + 1e-10)], rtol=1e-6, atol=0)
+        assert BLUR < ((42.5 - x_right_px) * 2.0 / min(H, W)) ** 2                             # beyond the blur radius: untouched
+        assert np.allclose(img[r, 42], [1, 1, 1, 0], atol=0) and np.allclose(img[0, 0], [1, 1, 1, 0], atol=0)
+        assert np.allclose(img[r, 35], [1, 0, 0, 1], atol=1e-9)                               # 4 px inside: the face colour, opaque
+        d_in = (x_right_px - 39.5) * 2.0 / min(H, W)                                          # 0.7 px inside: prob above one half
+        assert abs(img[r, 39, 3] - 1.0 / (1.0 + np.exp(-d_in * d_in / SIGMA))) < 1e-9
+
+
+def test_soft_blend_weights_follow_depth_and_keep_the_nearest_faces_only():
+    # three coincident big triangles at depths 3.00, 3.02, 3.5 in red, green, blue: inside all of them every prob is 1, so
+    # rgb = sum_k exp((zinv_k - zinv_max) / gamma) colour_k / (sum + delta); K = 2 drops the blue one entirely
+    tri = np.array([[-3.0, -3.0, 1.0], [3.0, -3.0, 1.0], [0.0, 3.0, 1.0]])
+    depths = [3.0, 3.02, 3.5]
+    v = np.concatenate([tri * [d, d, d] for d in depths])
+    faces = [[0, 1, 2], [3, 4, 5], [6, 7, 8]]
+    cols = np.repeat(np.eye(3), 3, axis=0)
+    idx, zbuf, dists, bary = RO.soft_fragments(v, faces, EYE, ZERO, FX, FY, CX, CY, H, W, BLUR, 3)
+    assert (idx[24, 32] == [0, 1, 2]).all() and np.allclose(zbuf[24, 32], depths)
+    img = RO.soft_render(v, faces, cols, EYE, ZERO, FX, FY, CX, CY, H, W, K=3)
+    zinv = (100.0 - np.array(depths)) / 99.0
+    w = np.exp((zinv - zinv.max()) / GAMMA)
+    delta = max(np.exp((1e-10 - zinv.max()) / GAMMA), 1e-10)
+    assert np.allclose(img[24, 32, :3], (w + delta) / (w.sum() + delta), rtol=1e-9) and img[24, 32, 3] == 1.0
+    assert 0.1 < w[1] < 0.2 and w[2] < 1e-20                  # 0.02 behind: a visible share; 0.5 behind: none
+    idx2 = RO.soft_fragments(v, faces, EYE, ZERO, FX, FY, CX, CY, H, W, BLUR, 2)[0]
+    assert (idx2[24, 32] == [0, 1]).all()
+    # K smaller than the candidates also changes the silhouette product: one face outside by 0.3 px behind two covering ones
+    assert np.allclose(bary[24, 32].sum(-1), 1.0)
+
+
+def test_torch_soft_blend_matches_the_restatement_and_its_gradient_a_finite_difference():
+    import torch
+    from multiply_amd.render import soft_blend_selected
+    rs = np.random.RandomState(3)
+    v, f = uv_sphere([0.05, -0.02, 3.0], 0.45, n_lat=8, n_lon=12)
+    v2, f2 = uv_sphere([0.35, 0.1, 3.6], 0.5, n_lat=7, n_lon=10)
+    verts, faces = np.concatenate([v, v2]), np.concatenate([f, f2 + len(v)])
+    cols = np.concatenate([np.tile([[1.0, 0, 0]], (len(v), 1)), np.tile([[0, 1.0, 0]], (len(v2), 1))]) * rs.uniform(0.5, 1, (len(verts), 1))
+    Rm = np.array([[np.cos(0.1), 0, np.sin(0.1)], [0, 1, 0], [-np.sin(0.1), 0, np.cos(0.1)]])
+    Tv = np.array([0.02, -0.01, 0.1])
+    K = 6                                                        # fewer slots than candidates at many pixels
+    blur = BLUR
+    idx, zbuf, dists, bary = RO.soft_fragments(verts, faces, Rm, Tv, FX, FY, CX, CY, H, W, blur, K)
+    fc = cols[faces]
+    tex = (bary[..., None] * fc[np.maximum(idx, 0)]).sum(-2) * (idx >= 0)[..., None]
+    want = RO.softmax_rgb_blend(idx, zbuf, dists, tex, SIGMA, GAMMA)
+    assert (idx[..., K - 1] >= 0).sum() > 50 and ((idx[..., 0] >= 0) & (idx[..., K - 1] < 0)).sum() > 50   # full and partly filled lists
+    tv = torch.tensor(verts, dtype=torch.float64, requires_grad=True)
+    args = (torch.tensor(faces), torch.tensor(cols), torch.tensor(idx), torch.tensor(Rm), torch.tensor(Tv),
+            torch.tensor([FX, FY]), torch.tensor([CX, CY]), H, W)
+    act, got = soft_blend_selected(tv, *args, chunk=300)
+    assert act.shape[0] == int((idx[..., 0] >= 0).sum())
+    assert np.abs(got.detach().numpy() - want[act[:, 0].numpy(), act[:, 1].numpy()]).max() < 1e-9
+    assert np.allclose(want[idx[..., 0] < 0], [1, 1, 1, 0])
+    # d (weighted image sum) / d vertex coordinates against a central difference of the torch blend at a FIXED selection
+    wgt = torch.tensor(rs.normal(size=(act.shape[0], 4)))
+    (got * wgt).sum().backward()
+    g = tv.grad.numpy()
+    assert np.abs(g).max() > 1e-3
+    order = np.argsort(-np.abs(g).reshape(-1))[:6]
+    for flat in order:
+        i, j = divmod(int(flat), 3)
+        h = 1e-7
+        vals = []
+        for s in (+1, -1):
+            vv = verts.copy()
+            vv[i, j] += s * h
+            vals.append(float((soft_blend_selected(torch.tensor(vv), *args)[1] * wgt).sum()))
+        fd = (vals[0] - vals[1]) / (2 * h)
+        assert abs(fd - g[i, j]) < 2e-4 * max(1.0, abs(fd)), (i, j, fd, g[i, j])

@@ -322,3 +322,132 @@ def test_vertex_colour_renders_of_a_scene():
     assert float((nrm.norm(dim=1) - 1).abs().max()) < 0.05         # interpolated unit vertex normals
     centre = views[0, H:2 * H][int(24.2), int(31.7 - 0.15 * 60 / 2.5)]
     assert float(centre[0]) < 0.1                                  # facing the camera: normal z = -1 -> channel 0 (z) ~ 0
+
+
+def _soft_scene(rs, n_soup=250):
+    """two tessellated spheres (dense small faces, front and back layers) + a triangle soup with a few big faces"""
+    v1, f1 = uv_sphere([-0.25, 0.05, 3.0], 0.55, n_lat=14, n_lon=24)
+    v2, f2 = uv_sphere([0.35, -0.1, 3.5], 0.6, n_lat=12, n_lon=20)
+    ctr = rs.uniform(-1.2, 1.2, (n_soup, 1, 3)) * [1, 0.8, 0.5] + [0, 0, 3.2]
+    size = np.where(rs.uniform(size=(n_soup, 1, 1)) < 0.05, 0.8, 0.08)
+    vs = (ctr + rs.normal(size=(n_soup, 3, 3)) * size).reshape(-1, 3)
+    vs[:6, 2] -= 7.0                                                               # behind the camera
+    fs = np.arange(3 * n_soup).reshape(n_soup, 3)
+    verts = np.concatenate([v1, v2, vs])
+    faces = np.concatenate([f1, f2 + len(v1), fs + len(v1) + len(v2)])
+    cols = np.concatenate([np.tile([[1.0, 0, 0]], (len(v1), 1)), np.tile([[0, 1.0, 0]], (len(v2), 1)), rs.uniform(0, 1, (len(vs), 3))])
+    return verts, faces, cols
+
+
+@pytest.mark.parametrize("H,W,K", [(48, 64, 100), (60, 44, 100), (48, 64, 5)])
+def test_soft_render_matches_the_restatement(H, W, K):
+    """mp_raster_soft_bins + mp_raster_soft against oracle/raster_oracle.soft_render (float64): the silhouette channel, the
+    blended colours and the per-pixel face selection, wide / tall images, and a small K that forces evictions."""
+    import ctypes as C
+    from multiply_amd import hip, render
+    rs = np.random.RandomState(5)
+    verts, faces, cols = _soft_scene(rs)
+    Kc = np.array([[75.0, 0, W / 2 - 0.7], [0, 70.0, H / 2 + 0.4], [0, 0, 1.0]])
+    ang = 0.15
+    R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.0]])
+    T = np.array([0.03, -0.02, 0.2])
+    r = make_renderer(Kc, R, T, H, W)
+    render_K = render.SOFT_K
+    render.SOFT_K = K
+    try:
+        img, sel = r.soft_rasterize(torch.tensor(verts).float(), torch.tensor(faces), torch.tensor(cols).float(), want_sel=True)
+    finally:
+        render.SOFT_K = render_K
+    torch.cuda.synchronize()
+    img, sel = img.cpu().numpy().astype(np.float64), np.sort(sel.cpu().numpy(), axis=-1)
+    blur = render.SOFT_BLUR
+    idx, zbuf, dists, bary = RO.soft_fragments(verts, faces, R, T, Kc[0, 0], Kc[1, 1], Kc[0, 2], Kc[1, 2], H, W, blur, K)
+    want = RO.soft_render(verts, faces, cols, R, T, Kc[0, 0], Kc[1, 1], Kc[0, 2], Kc[1, 2], H, W, K=K)
+    same_set = (np.sort(idx, axis=-1) == sel).all(-1)
+    n_full = int((idx[..., K - 1] >= 0).sum())
+    ea, ec = np.abs(img[..., 3] - want[..., 3]), np.abs(img[..., :3] - want[..., :3]).max(-1)
+    print(f"[parity] soft render {H}x{W} K={K}: {int((idx[..., 0] >= 0).sum())} blended pixels ({n_full} with full lists), selection "
+          f"differs on {(~same_set).sum()}; alpha max {ea.max():.2e} mean {ea.mean():.2e}; rgb max {ec.max():.2e} mean {ec.mean():.2e} "
+          f"(pixels with the same selection: alpha {ea[same_set].max():.2e}, rgb {ec[same_set].max():.2e})")
+    assert (idx[..., 0] >= 0).mean() > 0.3 and (K == 100 or n_full > 100)
+    # float32 vs float64 may flip the selection when the list is full: a pixel outside two faces that share an edge gets the SAME
+    # clipped depth from both (an exact tie in float64, broken by face id), and which of them is evicted changes the product
+    assert (~same_set).mean() < 0.01 and (K < 100 or same_set.all())
+    assert ea[same_set].max() < 2e-4 and ea[same_set].mean() < 2e-5
+    # weights are exp(zinv / 1e-4) of a float32 zinv ~ 0.97: 8e-4 relative per weight
+    assert ec[same_set].max() < 5e-3 and ec[same_set].mean() < 2e-4
+    assert np.allclose(img[(idx[..., 0] < 0) & same_set], [1, 1, 1, 0], atol=0)                 # untouched pixels: white, transparent
+
+
+def test_soft_render_back_propagates_into_the_vertices_and_feeds_the_silhouette_loss():
+    """Renderer.softrender_multiple_meshes: forward = the kernel's image whether or not a gradient is asked for; the gradient
+    = autograd through the torch blend of the kernel's selection, checked against the float64 CPU evaluation of the same
+    selection; and get_depth_order_loss's silhouette term against the restatement's image."""
+    from multiply_amd import render
+    rs = np.random.RandomState(6)
+    H, W = 40, 52
+    v1, f1 = uv_sphere([-0.2, 0.0, 3.0], 0.5, n_lat=10, n_lon=16)
+    v2, f2 = uv_sphere([0.3, 0.05, 3.4], 0.55, n_lat=9, n_lon=14)
+    Kc = np.array([[60.0, 0, 25.3], [0, 58.0, 19.6], [0, 0, 1.0]])
+    R, T = np.eye(3), np.array([0.0, 0.0, 0.1])
+    r = make_renderer(Kc, R, T, H, W)
+    tv = [torch.tensor(v1).float().cuda()[None].requires_grad_(True), torch.tensor(v2).float().cuda()[None].requires_grad_(True)]
+    tf = [torch.tensor(f1).cuda()[None], torch.tensor(f2).cuda()[None]]
+    tc = [torch.tensor([[1.0, 0, 0]]).repeat(len(v1), 1).cuda()[None], torch.tensor([[0, 1.0, 0]]).repeat(len(v2), 1).cuda()[None]]
+    with torch.no_grad():
+        plain = r.softrender_multiple_meshes(tv, tf, tc)
+    img = r.softrender_multiple_meshes(tv, tf, tc)
+    assert img.shape == (1, H, W, 4) and torch.equal(img.detach(), plain) and img.requires_grad
+    wgt = torch.tensor(rs.normal(size=(H, W, 4))).float().cuda()
+    (img[0] * wgt).sum().backward()
+    torch.cuda.synchronize()
+    verts = np.concatenate([v1, v2]); faces = np.concatenate([f1, f2 + len(v1)])
+    cols = np.concatenate([np.tile([[1.0, 0, 0]], (len(v1), 1)), np.tile([[0, 1.0, 0]], (len(v2), 1))])
+    want = RO.soft_render(verts, faces, cols, R, T, Kc[0, 0], Kc[1, 1], Kc[0, 2], Kc[1, 2], H, W)
+    e = np.abs(plain[0].cpu().numpy() - want)
+    assert e[..., 3].max() < 2e-4 and e[..., :3].max() < 5e-3
+    _, sel = r.soft_rasterize(torch.tensor(verts).float(), torch.tensor(faces), torch.tensor(cols).float(), want_sel=True)
+    cv = torch.tensor(verts, dtype=torch.float64, requires_grad=True)
+    act, soft = render.soft_blend_selected(cv, torch.tensor(faces), torch.tensor(cols), sel.cpu(), torch.tensor(R), torch.tensor(T),
+                                           torch.tensor([Kc[0, 0], Kc[1, 1]]), torch.tensor([Kc[0, 2], Kc[1, 2]]), H, W)
+    (soft * wgt.cpu().double()[act[:, 0], act[:, 1]]).sum().backward()
+    got = torch.cat([tv[0].grad[0], tv[1].grad[0]]).cpu().double()
+    rel = float((got - cv.grad).abs().max() / cv.grad.abs().max())
+    print(f"[grad parity] d soft image / d vertices: float32 device autograd vs float64 of the same selection, rel-to-max {rel:.2e} "
+          f"(|grad| max {float(cv.grad.abs().max()):.3e})")
+    assert float(cv.grad.abs().max()) > 1.0 and rel < 2e-2          # exp(zinv / 1e-4) of a float32 zinv: ~1e-3 per weight
+
+
+def test_silhouette_term_of_the_depth_order_loss():
+    from multiply_amd import mesh_losses as ML
+    from multiply_amd.mesh import canonical_mesh
+    from tests.test_render_gpu import build
+    H, W = 48, 64
+    model, _, inp = build(H=H, W=W)
+    gin = {k: (t.cuda() if torch.is_tensor(t) else t) for k, t in inp.items()}
+    Kp = gin["intrinsics"][0].double().clone()
+    Kp[0, 2] += 0.5; Kp[1, 2] += 0.5
+    gin["P"] = (Kp @ torch.linalg.inv(gin["pose"][0].double()))[None].float()
+    gin["img_size"] = (H, W)
+    rs = np.random.RandomState(1)
+    gin["org_sam_mask"] = torch.tensor(rs.normal(0, 4.0, (1, H, W, 2))).float().cuda()
+    meshes = [canonical_mesh(model, p, cond=gin["smpl_pose"][0, p, 3:] / np.pi, res_up=1) for p in range(2)]
+    trans = gin["smpl_trans"].clone().requires_grad_(True)
+    opt = {"depth_order_weight": 0.1, "silhouette_weight": 0.3}
+    order, sil, inter = ML.get_depth_order_loss(model, dict(gin, smpl_trans=trans), 100, opt, meshes=meshes)
+    sil.backward()
+    r = ML.get_renderer(gin)
+    with torch.no_grad():
+        vs, fs, _ = ML.posed_meshes(model, gin, meshes=meshes)
+    verts = np.concatenate([v[0].cpu().numpy() for v in vs]).astype(np.float64)
+    nv = np.cumsum([0] + [v.shape[1] for v in vs])
+    faces = np.concatenate([f[0].cpu().numpy() + o for f, o in zip(fs, nv[:-1])])
+    cols = np.concatenate([np.tile(np.array([ML.COLOR_DICT[p]]) / 255.0, (v.shape[1], 1)) for p, v in enumerate(vs)])
+    fx, fy = r.focal_length[0].tolist(); cx, cy = r.principal_point[0].tolist()
+    img = RO.soft_render(verts, faces, cols, r.cam_R[0].numpy().astype(np.float64), r.cam_T[0].numpy().astype(np.float64),
+                         fx, fy, cx, cy, H, W)
+    gt = ML.gt_instance_map(gin["org_sam_mask"], 2).cpu().numpy().astype(np.float64)
+    want = 0.3 * np.mean((gt - 255 * img[..., :3] * img[..., 3:]) ** 2) * (1 - 100 / 1000)
+    print(f"[parity] silhouette loss {float(sil):.4f} vs restatement {want:.4f}; |d/d trans| {float(trans.grad.abs().max()):.3e}")
+    assert abs(float(sil) - want) < 2e-3 * want and want > 10.0
+    assert torch.isfinite(trans.grad).all() and float(trans.grad.abs().max()) > 0

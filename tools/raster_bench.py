@@ -33,3 +33,33 @@ for name, (nlat, nlon) in (("13.8 k faces (SMPL size)", (60, 116)), ("65 k faces
     alg = f.shape[0] * 48 + H * W * 40
     print(f"{name:26s} {f.shape[0]:7d} faces  {ms:6.3f} ms / mesh (host-timed)   covered {100 * cover:4.1f} % of the frame   "
           f"algorithmic {alg / 1e6:5.1f} MB -> {alg / ms / 1e6:6.1f} GB/s")
+
+# the soft silhouette render of a three-body scene (render.softrender_multiple_meshes: sigma 5e-5, 100 faces per pixel)
+print()
+for name, (nlat, nlon) in (("3 x 13.8 k faces", (60, 116)), ("3 x 65 k faces", (128, 256))):
+    vl, fl, cl = [], [], []
+    for p, cx in enumerate((-0.55, 0.0, 0.5)):
+        v, f = uv_sphere([cx, -0.007, 0.15 * p], 0.38, nlat, nlon)
+        vl.append(torch.tensor(v).float().cuda()[None]); fl.append(torch.tensor(f).cuda()[None])
+        cl.append(torch.tensor([[1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0]][p]).repeat(v.shape[0], 1).cuda()[None])
+    with torch.no_grad():
+        for _ in range(2):
+            img = r.softrender_multiple_meshes(vl, fl, cl)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 5
+        for _ in range(n):
+            img = r.softrender_multiple_meshes(vl, fl, cl)
+        torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    a = img[0, :, :, 3]
+    print(f"soft render {name:18s} {ms:8.2f} ms / scene (host-timed, incl. the one host read)   silhouette > 0.5 on "
+          f"{100 * float((a > 0.5).float().mean()):4.1f} % of the frame, partial (0.01 .. 0.99) on {100 * float(((a > 0.01) & (a < 0.99)).float().mean()):4.2f} %")
+vg = [v.clone().requires_grad_(True) for v in vl]
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+img = r.softrender_multiple_meshes(vg, fl, cl)
+(img[0, :, :, 3].mean()).backward()
+torch.cuda.synchronize()
+print(f"soft render with gradient (3 x 65 k faces): {1e3 * (time.perf_counter() - t0):8.1f} ms forward + backward, "
+      f"|d mean(alpha) / d verts| max {max(float(v.grad.abs().max()) for v in vg):.3e}, peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
