@@ -7,12 +7,11 @@ with an OpenCV world->camera pose, and per-mesh depth maps shaped like pytorch3d
 the nearest face in slot 0 and -1 where nothing is hit -- that back-propagate into the vertices.  The reference asks
 pytorch3d for the K = 10 nearest faces and reads slot 0 only (multiply_model.py:641, :882); this class returns K = 1.
 
-`render_multiple_meshes` (hard vertex-colour image) is the nearest-face limit of pytorch3d's SoftPhongShader blend: exact
-where a pixel's second face is further than ~0.07 depth units behind the first (its blend weight is
-exp(-dz / (99 * 1e-4))), an approximation at thinner parts.  `softrender_multiple_meshes` (sigma = 5e-5, gamma = 1e-4, 100
-faces per pixel; feeds the silhouette term of multiply_model.py:636-637, :721, whose weight is 0 in every shipped config) runs
-the blurred rasteriser + softmax blend of csrc/raster.hip (mp_raster_soft_bins, mp_raster_soft) and back-propagates into
-the vertices through a torch re-evaluation of the kernel's face selection.
+`render_multiple_meshes` (hard rasteriser, 10 faces per pixel, SoftPhongShader with the default blend parameters) and
+`softrender_multiple_meshes` (sigma = 5e-5, gamma = 1e-4, 100 faces per pixel; feeds the silhouette term of
+multiply_model.py:636-637, :721, whose weight is 0 in every shipped config) run the (blurred) rasteriser + softmax blend of
+csrc/raster.hip (mp_raster_soft_bins, mp_raster_soft); the soft one back-propagates into the vertices through a torch
+re-evaluation of the kernel's face selection.
 """
 import ctypes as C
 
@@ -25,6 +24,7 @@ Z_CLIP = 1e-6
 # render.py:79-86: BlendParams(sigma=5e-5, gamma=1e-4), blur_radius = log(1 / 1e-4 - 1) sigma (a squared NDC distance), 100 faces
 SOFT_SIGMA, SOFT_GAMMA, SOFT_K = 5e-5, 1e-4, 100
 SOFT_BLUR = float(np.log(1.0 / 1e-4 - 1.0) * SOFT_SIGMA)
+HARD_K = 10                                  # render.py:58-59: faces_per_pixel of the hard rasteriser
 
 
 class Fragments:
@@ -212,25 +212,30 @@ class Renderer:
             out.append(self._depth_with_grad(v, f, frag) if (torch.is_grad_enabled() and v.requires_grad) else frag.zbuf)
         return out
 
-    def render_multiple_meshes(self, verts_list, faces_list, verts_colors_list):
-        """render.py:107-119: the meshes joined as one scene, vertex colours under white ambient light -> (1, H, W, 4) RGBA
-        over a white background (nearest-face limit of the blend, see the module docstring)."""
+    def _join(self, verts_list, faces_list, verts_colors_list):
+        """join_meshes_as_scene: one vertex / face / colour table"""
         nv = np.cumsum([0] + [v.reshape(-1, 3).shape[0] for v in verts_list])
         verts = torch.cat([v.reshape(-1, 3).float() for v in verts_list])
         faces = torch.cat([f.reshape(-1, 3).long() + int(o) for f, o in zip(faces_list, nv[:-1])])
-        cols = torch.cat([c.reshape(-1, 3).float() for c in verts_colors_list]).to(self.device)
-        frag = self.rasterize(verts, faces)
-        p2f = frag.pix_to_face[0, :, :, 0]
-        hit = p2f >= 0
-        img = torch.ones(*self.image_size, 4, dtype=torch.float32, device=self.device)
-        img[..., 3] = 0.0
-        c3 = cols[faces.to(self.device)[p2f[hit]]]                                   # (N, 3 corners, 3)
-        img[hit] = torch.cat([(frag.bary_coords[0, :, :, 0][hit][:, :, None] * c3).sum(1), torch.ones_like(c3[:, 0, :1])], 1)
-        return img[None]
+        cols = torch.cat([c.reshape(-1, 3).float() for c in verts_colors_list])
+        return verts, faces, cols
 
-    def soft_rasterize(self, verts, faces, colors, want_sel=False):
+    def render_multiple_meshes(self, verts_list, faces_list, verts_colors_list):
+        """render.py:107-119: the meshes joined as one scene through the hard rasteriser (blur radius 0, the 10 nearest
+        covering faces per pixel) and SoftPhongShader under a white ambient light with BlendParams' defaults (sigma = gamma
+        = 1e-4) -> (1, H, W, 4) RGBA over white: the depth-softmax of the covering faces' colours -- the nearest face's
+        unless another lies within ~0.05 depth units -- and A = 1 - prod(1 - sigmoid(d^2 / sigma)) over them (d = the pixel
+        centre's NDC distance to the face outline: below 1 where the faces are small).  No gradient (visualisation)."""
+        verts, faces, cols = self._join(verts_list, faces_list, verts_colors_list)
+        with torch.no_grad():
+            return self.soft_rasterize(verts, faces, cols, sigma=1e-4, gamma=1e-4, blur=0.0, K=HARD_K)[0][None]
+
+    def soft_rasterize(self, verts, faces, colors, want_sel=False, sigma=None, gamma=None, blur=None, K=None):
         """csrc/raster.hip mp_raster_soft_bins + mp_raster_soft on one joined mesh: -> image (H, W, 4), and with want_sel the
-        (H, W, K) faces each pixel blended (-1 padded).  One host read (the length of the tile lists)."""
+        (H, W, K) faces each pixel blended (-1 padded).  One host read (the length of the tile lists).  Defaults: the soft
+        renderer's sigma / gamma / blur radius / faces per pixel."""
+        sigma, gamma = SOFT_SIGMA if sigma is None else sigma, SOFT_GAMMA if gamma is None else gamma
+        blur, K = SOFT_BLUR if blur is None else blur, SOFT_K if K is None else K
         H, W = self.image_size
         v = verts.detach().reshape(-1, 3).float().contiguous().to(self.device)
         f = faces.reshape(-1, 3).to(device=self.device, dtype=torch.int32).contiguous()
@@ -243,16 +248,16 @@ class Renderer:
         cam = self._cam16()
         L = hip.lib()
         hip.check(L.mp_raster_soft_bins(hip.ptr(v), v.shape[0], hip.ptr(f), f.shape[0], C.cast(cam, C.c_void_p), Z_CLIP, H, W,
-                                        SOFT_BLUR, hip.ptr(tile_n), hip.ptr(offsets), hip.stream()), "mp_raster_soft_bins")
+                                        blur, hip.ptr(tile_n), hip.ptr(offsets), hip.stream()), "mp_raster_soft_bins")
         total = int(offsets[T])
         if total < 0:
             raise RuntimeError("soft render: the tile lists exceed 2^31 entries")
         lst = torch.empty(max(total, 1), dtype=torch.int32, device=self.device)
         image = torch.empty(H, W, 4, dtype=torch.float32, device=self.device)
-        sel = torch.empty(H, W, SOFT_K, dtype=torch.int32, device=self.device) if want_sel else None
+        sel = torch.empty(H, W, K, dtype=torch.int32, device=self.device) if want_sel else None
         bg = (C.c_float * 3)(1.0, 1.0, 1.0)                                       # BlendParams' default background
         hip.check(L.mp_raster_soft(hip.ptr(v), v.shape[0], hip.ptr(f), f.shape[0], hip.ptr(c), C.cast(cam, C.c_void_p), Z_CLIP,
-                                   H, W, SOFT_SIGMA, SOFT_GAMMA, SOFT_BLUR, SOFT_K, 1.0, 100.0, C.cast(bg, C.c_void_p),
+                                   H, W, sigma, gamma, blur, K, 1.0, 100.0, C.cast(bg, C.c_void_p),
                                    hip.ptr(tile_n), hip.ptr(offsets), hip.ptr(lst), hip.ptr(image),
                                    hip.ptr(sel) if want_sel else None, hip.stream()), "mp_raster_soft")
         return image, sel
@@ -271,10 +276,7 @@ class Renderer:
         faces per pixel) and SoftPhongShader under white ambient light -> (1, H, W, 4): RGB = depth-softmax blend of the
         interpolated vertex colours over white, A = 1 - prod(1 - sigmoid(-d / sigma)), the soft silhouette.  Differentiable
         in the vertices and colours."""
-        nv = np.cumsum([0] + [v.reshape(-1, 3).shape[0] for v in verts_list])
-        verts = torch.cat([v.reshape(-1, 3).float() for v in verts_list])
-        faces = torch.cat([f.reshape(-1, 3).long() + int(o) for f, o in zip(faces_list, nv[:-1])])
-        cols = torch.cat([c.reshape(-1, 3).float() for c in verts_colors_list])
+        verts, faces, cols = self._join(verts_list, faces_list, verts_colors_list)
         need_grad = torch.is_grad_enabled() and (verts.requires_grad or cols.requires_grad)
         image, sel = self.soft_rasterize(verts, faces, cols, want_sel=need_grad)
         if need_grad:

@@ -141,9 +141,12 @@ def softmax_rgb_blend(idx, zbuf, dists, texels, sigma, gamma, background=(1.0, 1
     return np.concatenate([rgb, 1.0 - alpha[..., None]], -1)
 
 
-def soft_render(verts, faces, colors, R, T, fx, fy, cx, cy, H, W, sigma=5e-5, gamma=1e-4, K=100):
-    """render.py:121-133 for the joined scene: vertex colours `colors` (V, 3) -> (H, W, 4)"""
-    blur = np.log(1.0 / 1e-4 - 1.0) * sigma
+def soft_render(verts, faces, colors, R, T, fx, fy, cx, cy, H, W, sigma=5e-5, gamma=1e-4, K=100, blur=None):
+    """render.py:121-133 for the joined scene: vertex colours `colors` (V, 3) -> (H, W, 4).  blur = None: the soft
+    renderer's log(1/1e-4 - 1) sigma; render.py:107-119 (render_multiple_meshes) is the same blend with sigma = 1e-4 (the
+    BlendParams default), K = 10 and blur = 0: only faces that cover the pixel centre, for which the barycentric clipping
+    pytorch3d then switches off is the identity."""
+    blur = np.log(1.0 / 1e-4 - 1.0) * sigma if blur is None else blur
     idx, zbuf, dists, bary = soft_fragments(verts, faces, R, T, fx, fy, cx, cy, H, W, blur, K)
     fc = np.asarray(colors, np.float64)[np.asarray(faces, np.int64)]            # (F, 3 corners, 3)
     tex = (bary[..., None] * fc[np.maximum(idx, 0)]).sum(-2)                     # interpolate_face_attributes

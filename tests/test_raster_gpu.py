@@ -295,7 +295,8 @@ def test_depth_refinement_stage_on_a_written_sequence(tmp_path):
 
 def test_vertex_colour_renders_of_a_scene():
     """render_multiple_meshes / render_mesh_recon (render.py:107-119, 161-208): two coloured spheres joined as one scene ->
-    RGBA over white; the nearer sphere hides the farther one; normal / shaded views stack along the height."""
+    RGBA over white = the SoftPhong blend of the (up to 10) faces covering each pixel, against the float64 restatement; the
+    nearer sphere hides the farther one; normal / shaded views stack along the height."""
     H, W = 48, 64
     K = np.array([[60.0, 0, 31.7], [0, 60.0, 24.2], [0, 0, 1.0]])
     r = make_renderer(K, np.eye(3), np.array([0.0, 0.0, 3.0]), H, W)
@@ -313,9 +314,19 @@ def test_vertex_colour_renders_of_a_scene():
     is_b = (zb > 0) & ~is_a
     empty = (za < 0) & (zb < 0)
     assert bool(is_a.any()) and bool(is_b.any()) and bool(((za > 0) & (zb > 0)).any())       # they overlap in the image
-    assert torch.allclose(img[0][is_a], torch.tensor([1.0, 0, 0, 1]).cuda(), atol=1e-5)
-    assert torch.allclose(img[0][is_b], torch.tensor([0, 0, 1.0, 1]).cuda(), atol=1e-5)
+    # colours: the nearest sphere's (the other one is >= 0.3 depth units behind: weight exp(-30)); alpha = 1 - prod(1 - prob) of
+    # the covering faces, each prob >= 1/2, two or more of them (front and back of a sphere)
+    assert torch.allclose(img[0][is_a][:, :3], torch.tensor([1.0, 0, 0]).cuda(), atol=1e-5)
+    assert torch.allclose(img[0][is_b][:, :3], torch.tensor([0, 0, 1.0]).cuda(), atol=1e-5)
+    assert float(img[0][is_a | is_b][:, 3].min()) >= 0.75 - 1e-6 and float(img[0][is_a | is_b][:, 3].max()) <= 1.0
     assert torch.equal(img[0][empty], torch.tensor([1.0, 1, 1, 0]).cuda().expand(int(empty.sum()), 4))
+    verts, faces = np.concatenate([va, vb]), np.concatenate([fa, fb + len(va)])
+    cols = np.concatenate([np.tile([[1.0, 0, 0]], (len(va), 1)), np.tile([[0, 0, 1.0]], (len(vb), 1))])
+    want = RO.soft_render(verts, faces, cols, np.eye(3), np.array([0.0, 0.0, 3.0]), 60.0, 60.0, 31.7, 24.2, H, W, sigma=1e-4,
+                          gamma=1e-4, K=10, blur=0.0)
+    err = np.abs(img[0].cpu().numpy() - want)
+    print(f"[parity] SoftPhong image of the hard rasteriser vs restatement: alpha max {err[..., 3].max():.2e}, rgb max {err[..., :3].max():.2e}")
+    assert np.quantile(err[..., 3], 0.99) < 2e-4 and err[..., :3].max() < 5e-3 and (err[..., 3] > 1e-2).mean() < 0.01
     views = r.render_mesh_recon(t(va)[None], torch.tensor(fa).cuda()[None], colors=red[None], mode="npa")
     assert views.shape == (1, 3 * H, W, 4)
     nrm = views[0, H:2 * H][za > 0][:, [2, 1, 0]] * 2 - 1         # stack = [phong | normal | albedo]; normals stored as (z, y, x) * 0.5 + 0.5
