@@ -390,7 +390,9 @@ int mp_raster_zbuf(const float* verts, int n_verts, const int* faces, int n_face
  * multiply_model.py:636-637, :721).  Two calls, because the length of the tile lists is only known after the count:
  *   mp_raster_soft_bins  faces -> 8 x 8-pixel tiles: tile_n [T] scratch (T = ceil(H/8) ceil(W/8)), offsets [T + 1] exclusive
  *                        offsets of the tile lists, offsets[T] = total entries (-1: more than INT_MAX)
- *   mp_raster_soft       list [offsets[T]] scratch, colors [n_verts][3]; image [H][W][4] = RGB over the background + the
+ *   mp_raster_soft       tile_n / offsets as mp_raster_soft_bins left them for the SAME mesh, camera, image size and
+ *                        blur_radius (tile_n all zero again: it counts the list fill); list [offsets[T]] scratch, colors
+ *                        [n_verts][3]; image [H][W][4] = RGB over the background + the
  *                        silhouette 1 - prod(1 - prob); sel [H][W][faces_per_pixel] (optional): the selected faces of every
  *                        pixel in no particular order, -1 padded.  faces_per_pixel <= 100.  cam_host / background_host
  *                        (3 floats) IN HOST MEMORY; camera and pixel conventions of mp_raster_zbuf; distances are pytorch3d
