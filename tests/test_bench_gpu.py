@@ -54,7 +54,7 @@ def test_gpus_flag_starts_the_ranks_and_reports_strong_scaling():
 
 def test_two_ranks_over_rccl_when_the_box_has_two_gpus():
     """the SAME command on the backend the driver's multi-GPU runs use ("nccl" = RCCL over xGMI): one rank per GPU, the image
-    all_gather and the flat gradient all-reduce as real device collectives.  A one-GPU box cannot run it -- said loudly, not
+    all_gather, the sampler's convergence vote and the bucketed gradient all-reduce as real device collectives.  A one-GPU box cannot run it -- said loudly, not
     silently replaced by the gloo variant above."""
     import torch
     if torch.cuda.device_count() < 2:
@@ -64,7 +64,8 @@ def test_two_ranks_over_rccl_when_the_box_has_two_gpus():
         pytest.skip(msg)
     d = _run(["--gpus", "2", "--res", "64", "--steps", "2", "--warmup", "1", "--train-steps", "2", "--train-warmup", "1"])
     assert d["n_gpus"] == 2 and d["collective_backend"] == "nccl" and d["value"] > 0
-    assert d["train_iter"]["rays_per_iter_per_gpu"] == 256 and d["train_iter"]["gpu_ms"]["allreduce"] > 0
+    # the gradient buckets are reduced while the backward runs: the "allreduce" phase is only what is left after it returned
+    assert d["train_iter"]["rays_per_iter_per_gpu"] == 256 and d["train_iter"]["gpu_ms"]["allreduce"] >= 0
 
 
 def test_world_size_mismatch_is_refused():
