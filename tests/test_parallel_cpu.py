@@ -94,6 +94,54 @@ def test_two_rank_gradient_allreduce():
     assert all(ok for _, ok in res)
 
 
+def _bucket_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    groups = [[torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(5))],       # "person 0"
+              [torch.nn.Parameter(torch.zeros(2, 2))],                                            # "person 1"
+              []]                                                                                  # an empty group: no collective
+    grads = {}
+    sync = parallel.BucketedGradientSync()
+    for gi, params in enumerate(groups):             # groups retire one after the other, as the adjoint sweep finishes them
+        gs = [torch.full(p.shape, float((rank + 1) * (gi + 1) * (i + 1)), dtype=torch.float64 if i else torch.float32)
+              for i, p in enumerate(params)]
+        for p, g in zip(params, gs):
+            grads[id(p)] = g
+        sync.retire(params, gs)
+    extra = torch.nn.Parameter(torch.zeros(2))       # a gradient that never went through a bucket stays as it is
+    grads[id(extra)] = torch.full((2,), 5.0 + rank)
+    pending = len(sync.pending)
+    out = sync.finish(grads)
+    ok = pending == 2 and sync.pending == []
+    for gi, params in enumerate(groups):
+        for i, p in enumerate(params):
+            want = torch.full(p.shape, 1.5 * (gi + 1) * (i + 1))          # mean over the two ranks of (rank + 1) * ...
+            ok = ok and out[id(p)].shape == p.shape and torch.allclose(out[id(p)].float(), want, atol=1e-6)
+            ok = ok and out[id(p)].dtype == (torch.float64 if i else torch.float32)        # handed back in the gradient's dtype
+    ok = ok and torch.equal(out[id(extra)], torch.full((2,), 5.0 + rank))
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok))
+
+
+def test_bucketed_gradient_sync_averages_every_retired_group():
+    """parallel.BucketedGradientSync as TrainGraph.backward drives it: one asynchronous all-reduce per retired group, finish()
+    waits and hands the AVERAGED gradients back by parameter identity (shape and dtype kept), untouched entries pass through"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
+
+
 def _sharded_sync_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
