@@ -286,6 +286,143 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_nt_b3(const float* __res
         }
 }
 
+// ---- the same product for the 256-deep layers as a PERSISTENT workgroup (K == 256, 16 B aligned operands) ------------------
+// The tiled kernel above runs the 63k x 256 x 256 products of a training iteration in 45 us: ~20 us that do not depend on K
+// (first-load latency and epilogue of every tile, exposed with two workgroups per CU) + an LDS-bound K loop (a 64 x 32 wave
+// tile reads 12 operand fragments per 24 MFMAs; profiles/r03_gemm_shape_sweep.txt).  Here one workgroup per CU keeps the
+// weights of its 128 columns IN REGISTERS for the whole launch -- lane (li, lq) of a wave holds, for its 2 column blocks and
+// the 8 stages, the hi and lo halves of 8 consecutive k of its column: 8 x 2 x 2 x 4 = 128 VGPRs, loaded and split once --
+// and walks the row tiles blockIdx.x, blockIdx.x + gridDim.x, ...: only the activation rows stream, fetched FOUR stages ahead
+// through a register ring ACROSS tile boundaries (the next tile's first stages are in flight during the epilogue), split into
+// the two-stage LDS tile as above.  Per stage a wave reads 8 fragments (A only) for 24 MFMAs: the loop is MFMA-bound.
+constexpr int NKP = 8;            // stages of the 256-deep contraction
+__global__ __launch_bounds__(NT_THREADS, 1) void k_gemm_nt_b3p(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                        int ldb, float* __restrict__ C, int ldc, int M, int N,
+                                                        const float* __restrict__ bias, int bias_rows, int relu, int row_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* As = (__bf16*)smem;                              // [stage][hi | lo][row][k]
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int n0 = blockIdx.y * 128;
+    const int wm = (wave >> 2) * 64, wn = (wave & 3) * 32;   // 2 x 4 waves, each 64 x 32
+    const int li = lane & 15, lq = lane >> 4;
+    // the wave's weights: column n0 + wn + 16 j + li, k = 32 kt + 8 lq .. + 7 (columns past N: the last valid one, never stored)
+    bf16x8 bh[NKP][2], bl[NKP][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float* pb = B + (size_t)min(n0 + wn + j * 16 + li, N - 1) * ldb + 8 * lq;
+#pragma unroll
+        for (int kt = 0; kt < NKP; ++kt) {
+            const f32x4 v0 = *(const f32x4*)(pb + kt * BK), v1 = *(const f32x4*)(pb + kt * BK + 4);
+            const bf16x4 h0 = __builtin_convertvector(v0, bf16x4), h1 = __builtin_convertvector(v1, bf16x4);
+            const bf16x4 l0 = __builtin_convertvector(v0 - __builtin_convertvector(h0, f32x4), bf16x4);
+            const bf16x4 l1 = __builtin_convertvector(v1 - __builtin_convertvector(h1, f32x4), bf16x4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bh[kt][j][e] = h0[e]; bh[kt][j][4 + e] = h1[e];
+                bl[kt][j][e] = l0[e]; bl[kt][j][4 + e] = l1[e];
+            }
+        }
+    }
+    const int sr = t >> 3, sk = (t & 7) * 4;                 // staging: row sr + 64 q, k offset sk
+    auto split_store = [&](__bf16* tile, f32x4 v, int row) {
+        const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+        const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
+        *(bf16x4*)(tile + row * LDK16 + sk) = hi;
+        *(bf16x4*)(tile + BM * LDK16 + row * LDK16 + sk) = lo;
+    };
+    auto sstore = [&](int buf, const f32x4 (&r)[2]) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) split_store(As + buf * 2 * BM * LDK16, r[q], sr + 64 * q);
+    };
+    // element offsets of the staging thread's two rows (kept as offsets from the kernel argument: pointers copied between
+    // tiles lose their address space and become flat loads, which every LDS wait would then also wait for)
+    auto tile_offs = [&](int tile, size_t (&o)[2]) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) o[q] = (size_t)min(tile * BM + sr + 64 * q, M - 1) * lda + sk;
+    };
+    // The loop below holds NO conditional memory operation (the next tile's rows are fetched even when there is none: the last
+    // tile's again; no accumulate path; the bias is read here): hipcc's s_waitcnt bookkeeping merges the outstanding-load counts
+    // of all paths into the smallest, and with `if (has_next)` loads it waited for all but one load at every stage.
+    const int GX = gridDim.x;
+    if ((int)blockIdx.x >= row_tiles) return;
+    const int ntile = (row_tiles - (int)blockIdx.x + GX - 1) / GX;
+    const int cn = lane & 15, cr = (lane >> 4) * 4;
+    float bn[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bn[j] = bias ? bias[min(n0 + wn + j * 16 + cn, N - 1)] : 0.0f;
+    int tile = blockIdx.x;
+    size_t pc[2], pn[2];                                     // this tile's rows, the next tile's rows
+    tile_offs(tile, pc);
+    tile_offs(ntile > 1 ? tile + GX : tile, pn);
+    f32x4 ra[4][2];
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) ra[s_][q] = *(const f32x4*)(A + pc[q] + s_ * BK);
+    sstore(0, ra[0]);
+    __syncthreads();
+    for (int it = 0; it < ntile; ++it) {
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int kt = 0; kt < NKP; ++kt) {
+            const int buf = kt & 1;
+            // stage kt + 4 into the ring slot stage kt left (its rows went to LDS one stage ago): this tile's, or the next tile's
+#if !(MP_EXP_NTP & 4)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                ra[kt & 3][q] = kt + 4 < NKP ? *(const f32x4*)(A + pc[q] + (kt + 4) * BK) : *(const f32x4*)(A + pn[q] + (kt + 4 - NKP) * BK);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            const __bf16* at = As + buf * 2 * BM * LDK16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16x8 ah = *(const bf16x8*)(at + (wm + i * 16 + li) * LDK16 + 8 * lq);
+                const bf16x8 al = *(const bf16x8*)(at + BM * LDK16 + (wm + i * 16 + li) * LDK16 + 8 * lq);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+#if MP_EXP_NTP & 2
+                    acc[i][j][0] += (float)al[0] + (float)ah[1] + (float)bh[kt][j][0] + (float)bl[kt][j][1];
+#else
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[kt][j], acc[i][j], 0, 0, 0);   // the small terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[kt][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[kt][j], acc[i][j], 0, 0, 0);
+#endif
+                }
+            }
+            sstore(buf ^ 1, ra[(kt + 1) & 3]);               // stage kt + 1 (kt = 7: the next tile's first)
+            __syncthreads();
+        }
+        // D: col = lane&15 (n), row = 4*(lane>>4)+reg (m)
+        const int m0 = tile * BM;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn + j * 16 + cn;
+                if (n >= N) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm + i * 16 + cr + r;
+                    if (m >= M) continue;
+                    float v = acc[i][j][r];
+                    if (m < bias_rows) v += bn[j];
+                    if (relu) v = fmaxf(v, 0.0f);
+#if MP_EXP_NTP & 1
+                    if (v == 123.456f)
+#endif
+                    C[(size_t)m * ldc + n] = v;
+                }
+            }
+        tile += GX;
+        pc[0] = pn[0]; pc[1] = pn[1];
+        tile_offs(it + 2 < ntile ? tile + GX : tile, pn);
+    }
+}
+
 // C[M,N] += sum_r A[r,m] B[r,n]; block = 128x128 tile of C x one slice of the rows
 // FAST: aligned operands, M and N multiples of the tile: only the row-slice bound remains in the loop
 template <bool FAST>
@@ -530,6 +667,12 @@ extern "C" int mp_gemm_nt(const float* A, int lda, const float* B, int ldb, floa
     return (int)hipGetLastError();
 }
 
+#ifndef MP_EXP_NTP
+#define MP_EXP_NTP 0
+#endif
+#ifndef MP_NT_PERSIST   // 1 = the 256-deep products of enough rows take the persistent weights-in-registers kernel (k_gemm_nt_b3p)
+#define MP_NT_PERSIST 0
+#endif
 #ifndef MP_NT_WIDE      // ablation switch: 1 = layers wider than 128 take the 128 x 256 single-stage tile (activation rows read once;
 #define MP_NT_WIDE 0    // 150 VGPRs, one workgroup per CU: 58 us per 50k x 256 x 256 product); 0 (default) = 128 x 128 two-stage: 49 us
 #endif
@@ -543,6 +686,18 @@ extern "C" int mp_gemm_nt_bf16x3(const float* A, int lda, const float* B, int ld
     MP_LDS_ATTR((k_gemm_nt_b3<true, 1, 4, 1>), LDS_41);
     MP_LDS_ATTR((k_gemm_nt_b3<false, 1, 4, 1>), LDS_41);
     const bool fast = (lda & 3) == 0 && (ldb & 3) == 0 && ((size_t)A & 15) == 0 && ((size_t)B & 15) == 0 && K % BK == 0;
+    // the persistent kernel: 256-deep products whose last 128-column block is at least half used, enough row tiles to go round
+    const int row_tiles = (M + BM - 1) / BM, col_blocks = (N + 127) / 128;
+    if (MP_NT_PERSIST && fast && !accumulate && K == NKP * BK && (N % 128 == 0 || N % 128 >= 64) && row_tiles * col_blocks >= 256) {
+        constexpr int LDS_P = 2 * 2 * BM * LDK16 * 2;         // two stages x (hi, lo) x the 128-row activation tile of bf16: 40 KB
+        MP_LDS_ATTR(k_gemm_nt_b3p, LDS_P);
+        int gx = 256 / col_blocks;                            // one workgroup per CU
+        if (gx > row_tiles) gx = row_tiles;
+        if (gx < 1) gx = 1;
+        hipLaunchKernelGGL(k_gemm_nt_b3p, dim3(gx, col_blocks), dim3(NT_THREADS), LDS_P, (hipStream_t)stream, A, lda, B, ldb, C, ldc,
+                           M, N, bias, bias_rows, relu, row_tiles);
+        return (int)hipGetLastError();
+    }
     const bool wide = MP_NT_WIDE && N > 128;
     const dim3 grid((M + BM - 1) / BM, wide ? (N + 255) / 256 : (N + 127) / 128);
 #define MP_NT_B3(F, J, S, L) hipLaunchKernelGGL((k_gemm_nt_b3<F, 1, J, S>), grid, dim3(NT_THREADS), L, (hipStream_t)stream, A, lda, B, ldb, \

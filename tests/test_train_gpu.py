@@ -36,7 +36,8 @@ def test_gemms(precision, monkeypatch):
     monkeypatch.setattr(T, "TRAIN_PRECISION", precision)
     tol_nt, tol_tn = (2e-6, 2e-5) if precision == "f32" else (3e-5, 3e-5)
     torch.manual_seed(0)
-    for (M, N, K) in [(1000, 257, 39), (4097, 256, 256), (300, 3, 256), (129, 130, 17)]:
+    # the last two: one person's sample rows of a training iteration (ragged last row tile; a partly filled column block)
+    for (M, N, K) in [(1000, 257, 39), (4097, 256, 256), (300, 3, 256), (129, 130, 17), (63001, 256, 256), (33000, 217, 256)]:
         A = torch.randn(M, K, device="cuda"); B = torch.randn(N, K, device="cuda"); b = torch.randn(N, device="cuda")
         Cm = torch.empty(M, N, device="cuda")
         T.gemm_nt(T._p(A), K, T._p(B), K, T._p(Cm), N, M, N, K, T._p(b), M // 2)
