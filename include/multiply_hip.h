@@ -325,6 +325,32 @@ int mp_tr_pe_grad_bwd(const float* x, int P, int L, const float* dgrad, const fl
 int mp_tr_copy_cols(const float* src, int lds, int c0s, float* dst, int ldd, int c0d, long long rows, int C, float scale,
                     int accumulate, void* stream);
 
+/* ---- layer-FUSED training kernels of the foreground ImplicitNet (csrc/tfuse.hip) -----------------------------------------
+ * Replace, for the shipped network shape (8 x 256 softplus layers, skip connection into layer 4, 39 Fourier features, 257
+ * outputs), the per-layer GEMM + element-wise chain of the reverse-over-reverse SDF net (networks.py:160-181 under
+ * autograd with create_graph, multiply.py:620-661): a workgroup keeps 128 points on chip across the whole layer chain
+ * (activations = MFMA B operands in registers, split-bf16 weights through an LDS ring by DMA) and writes only what the
+ * weight-gradient contractions (mp_gemm_tn_bf16x3) and the adjoint sweep read back.
+ *   mp_tf_sdf_pack : W[9] (effective fp32 weights, row-major [out][in]: in = 108 for layer 0, 256 otherwise), B[9] (biases;
+ *                    B[0] = layer 0's bias with the conditioning hoisted in) -> wpack (pack_bytes of mp_tf_sdf_sizes: split
+ *                    bf16 fragment tiles of W_l, W_l^T in consumption order) and bias_all [9][288] (pack-row order).
+ *                    W and B are device arrays of 9 device pointers.
+ *   arena          : floats as reported by mp_tf_sdf_sizes(P, &arena_floats, &pack_bytes), PL = 256 P:
+ *                      AB(l) l=0..7 [2P][256] at l*2PL          rows [0,P) dZ_l (bwd), rows [P,2P) V_l (fwd)
+ *                      BB(l) l=1..8 [2P][256] at 16PL+(l-1)*2PL rows [0,P) X_l (fwd: layer l's input), rows [P,2P) dT_l (bwd)
+ *                      U(l)  l=0..6 [P][256]  at 32PL+l*PL ;  dS(l) l=0..7 [P][256] at 39PL+l*PL
+ *                      BB0 [2P][39] at 47PL: rows [0,P) Fourier features (caller, before fwd), rows [P,2P) dG (caller, before bwd)
+ *                      G [P][39] at 47PL+78P: d sdf / d Fourier features (fwd)
+ *                    columns >= 217 of X_4 and dT_4 (the re-injected Fourier features of the skip connection, times 1/sqrt 2)
+ *                    are NOT written by the kernels: the caller copies them from BB0 (mp_tr_copy_cols).
+ *   mp_tf_sdf_fwd  : out [P][257] = last layer (col 0 sdf, cols 1.. features), G, and the stashes
+ *   mp_tf_sdf_bwd  : dz8 [P][257] (adjoint of out), dG in BB0 -> dZ_l, dT_l stashes; dw8 [256] += the gradient sweep's
+ *                    contribution to the gradient of the last layer's sdf row (V_7 = sigma'_7 (.) w8) */
+int mp_tf_sdf_sizes(int P, long long* arena_floats, long long* pack_bytes);
+int mp_tf_sdf_pack(const float* const* W, const float* const* B, void* wpack, float* bias_all, void* stream);
+int mp_tf_sdf_fwd(const void* wpack, const float* bias_all, const float* w8, float* arena, int P, float* out, void* stream);
+int mp_tf_sdf_bwd(const void* wpack, const float* w8, float* arena, int P, const float* dz8, float* dw8, void* stream);
+
 /* ---- in / off-surface flags (multiply.py:153-167; training, current_epoch < 250) -------------------------------
  * signed distance of canonical points to a triangle mesh given as face_verts [F][3][3] (= mesh_face_vertices_list[p]):
  * |d| = distance to the closest triangle, negative inside (ray-casting parity), then per ray (n_s consecutive points)

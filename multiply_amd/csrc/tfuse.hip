@@ -1,0 +1,681 @@
+// Layer-FUSED training kernels of the foreground ImplicitNet (the reverse-over-reverse formulation of multiply_amd/train.py
+// ImplicitTrainRev; reference: code/lib/model/networks.py:160-181 evaluated under torch autograd with create_graph=True,
+// code/lib/model/multiply.py:620-661, optimiser step code/multiply_model.py:212-222).
+//
+// The unfused path runs one GEMM + separate element-wise passes per layer, every activation matrix round-tripping HBM in fp32
+// (6 products + 5 passes per layer and person).  Here a workgroup keeps a tile of 128 points ON CHIP across the whole layer
+// chain, exactly like the inference kernels of mlp_core.hpp do: the activations of a wave's 16 points are the MFMA's B operand
+// and never leave the register file (the next layer's operand registers are written by the activation code of the previous one,
+// through the same K-slot permutation), the weights stream global -> LDS by DMA (global_load_lds, 3-slot ring of 32-row chunks,
+// shared by the 8 waves).  Arithmetic: the split-bfloat16 product of gemm.hip (x = hi + lo, three v_mfma_f32_16x16x32_bf16 per
+// block: lo.hi + hi.lo + hi.hi, fp32 accumulation, ~2^-16 per product, the range of fp32); activations are computed in fp32.
+//
+//   k_tf_sdf_fwd : value sweep  Z_l = W_l X_l + b_l, X_{l+1} = softplus(Z_l)            (l = 0..8, skip connection at 4)
+//                  then the gradient sweep  V_7 = s_7 (.) w8,  T_l = W_l^T V_l,  V_{l-1} = s_{l-1} (.) T_l   (l = 7..1),
+//                  G = W_0[:, :39]^T V_0 + (the Fourier rows of T_4)      (d sdf / d PE; J_PE^T is applied by mp_tr_pe_grad_fwd)
+//   k_tf_sdf_bwd : the adjoint of both sweeps w.r.t. the activations (the data path):
+//                  ascending   dV_0 = W_0[:, :39] dG,  (dU_l, dS_l) = adj(s_l, U_l, dV_l),  dV_{l+1} = W_{l+1} dT_{l+1}
+//                  descending  dX_l = W_l^T dZ_l,  dZ_{l-1} = s_{l-1} (.) dX_l + dS_{l-1}
+// What leaves the chip is what the WEIGHT-gradient contractions need (X_l, V_l from the forward, dZ_l, dT_l from the backward:
+// row-major fp32 [points][256], consumed by mp_gemm_tn_bf16x3 with K = 2 P: [dZ_l; V_l]^T [X_l; dT_l]) and what the adjoint
+// needs (U_l = the gradient sweep's pre-sigmoid rows; dS_l between the two backward sweeps).  sigma' and sigma'' are re-derived
+// from the stored X_{l+1} = softplus(Z_l):  1 - sigma' = exp(-100 X),  sigma'' = 100 sigma' (1 - sigma').
+//
+// Specialised for the shipped foreground network (confs/model/*.yaml: 8 x 256, skip_in [4], multires 6, d_in 3, 257 outputs):
+// multiply_amd/train.py falls back to the layer-wise HIP path (ImplicitTrainRev) for any other shape.
+// Entry points: include/multiply_hip.h (mp_tf_*).
+#include <hip/hip_runtime.h>
+#include "../../include/multiply_hip.h"
+#include "common.hpp"
+#include "mlp_core.hpp"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TF_WAVES = 8, TF_THREADS = 64 * TF_WAVES, TF_PTS = 16 * TF_WAVES;   // 128 points per workgroup
+constexpr int TILE_B = 1024;                  // one 16 x 32 bf16 A tile in fragment order [lane][8]
+constexpr int CH_REG = 2 * 8 * 2 * TILE_B;    // register-fed part of a chunk: [row block][K step][hi | lo] = 32 KiB
+constexpr int CH_IN = 2 * 2 * 2 * TILE_B;     // input-fed part (Fourier features, 64 slots): [row block][K step][hi | lo] = 8 KiB
+constexpr int CH_BYTES = CH_REG + CH_IN;      // 40 KiB
+constexpr int RING = 3;
+constexpr int BIN_BYTES = 4096;               // per wave: the input-fed B fragments [K step][hi | lo][lane][8]
+constexpr int LDS_BYTES = RING * CH_BYTES + TF_WAVES * BIN_BYTES + 256 * 4;
+constexpr float K2 = 144.26950408889634f;     // 100 log2(e): softplus_100 in base 2
+constexpr float R2 = 0.70710678118654752f;    // the skip connection's 1/sqrt(2)
+constexpr int E_PE = 39, OUT3 = 217, BIAS_LD = 288, HID = 256;
+
+// ---- chunk stream layout (40 KiB chunks of 32 output rows) --------------------------------------------------------------------
+//   0 .. 72   value orientation W_l, l = 0..8 (8 chunks each; layer 8 = 256 feature rows, then the sdf row: 9 chunks)
+//  73 .. 130  transposed W_l^T, l = 7..1 (8 chunks each; l = 4: 10 chunks, the last two = its 39 Fourier rows)
+// 131 .. 132  W_0[:, :39]^T (39 rows)
+// 133 .. 196  a second run for the backward's descending sweep: W_8[1:]^T, then W_l^T for l = 7..1, 8 chunks each
+// The forward consumes 0 .. 132 in order; the backward 0 .. 63, then 133 .. 196.
+constexpr int CH_WT7 = 73, CH_WT4 = 97, CH_WT3 = 107, CH_G0 = 131, CH_WT8B = 133, CH_WTB = 141, CH_TOTAL = 197;
+constexpr int FWD_CHUNKS = 133, BWD_CHUNKS = 128, BWD_SHIFT = CH_WT8B - 64;
+
+__device__ __forceinline__ int slot_feature(int ks, int g, int e) { return 32 * ks + (e < 4 ? 4 * g + e : 16 + 4 * g + e - 4); }
+
+// value of pack element: chunk, local row r (0..31), register-fed K feature f (0..255) or (f < 0) input slot s (0..63)
+__device__ float pack_value(const float* const* __restrict__ W, int chunk, int r, int f, int s) {
+    const bool reg = f >= 0;
+    if (chunk <= 72) {                                   // value orientation
+        const int l = chunk == 72 ? 8 : chunk >> 3, R = chunk == 72 ? 256 + r : 32 * (chunk & 7) + r;
+        int o;
+        if (l < 8) { o = R; if (R >= (l == 3 ? OUT3 : HID)) return 0.f; }
+        else { if (R > 256) return 0.f; o = R < 256 ? R + 1 : 0; }
+        const int in_dim = l == 0 ? 108 : HID;
+        if (reg) {
+            if (l == 0) return 0.f;
+            if (l == 4 && f >= OUT3) return 0.f;
+            return W[l][(size_t)o * in_dim + f];
+        }
+        if (s >= E_PE) return 0.f;
+        if (l == 0) return W[0][(size_t)o * in_dim + s];
+        if (l == 4) return W[4][(size_t)o * in_dim + OUT3 + s] * R2;
+        return 0.f;
+    }
+    if (!reg) return 0.f;
+    int l, c;
+    if (chunk < CH_WT4) { l = 7 - (chunk - CH_WT7) / 8; c = (chunk - CH_WT7) % 8; }
+    else if (chunk < CH_WT3) { l = 4; c = chunk - CH_WT4; }
+    else if (chunk < CH_G0) { l = 3 - (chunk - CH_WT3) / 8; c = (chunk - CH_WT3) % 8; }
+    else if (chunk < CH_WT8B) { l = 0; c = chunk - CH_G0; }
+    else if (chunk < CH_WTB) { l = 8; c = chunk - CH_WT8B; }
+    else { l = 7 - (chunk - CH_WTB) / 8; c = (chunk - CH_WTB) % 8; }
+    const int R = 32 * c + r;
+    if (l == 0) return R < E_PE ? W[0][(size_t)f * 108 + R] : 0.f;            // W_0[:, :39]^T
+    if (l == 8) return W[8][(size_t)(f + 1) * HID + R];                        // W_8[1:]^T
+    if (f >= (l == 3 ? OUT3 : HID)) return 0.f;                                // K = the layer's outputs
+    if (l == 4) {
+        int i;
+        if (R < HID) { if (R >= OUT3) return 0.f; i = R; }
+        else { if (R - HID >= E_PE) return 0.f; i = OUT3 + R - HID; }
+        return W[4][(size_t)f * HID + i] * R2;
+    }
+    return W[l][(size_t)f * HID + R];
+}
+
+__global__ __launch_bounds__(512) void k_tf_pack(const float* const* __restrict__ W, const float* const* __restrict__ B,
+                                                 __bf16* __restrict__ wpack, float* __restrict__ bias_all) {
+    const int chunk = blockIdx.x;
+    __bf16* dst = wpack + (size_t)chunk * (CH_BYTES / 2);
+    for (int idx = threadIdx.x; idx < 2 * 10 * 64 * 8; idx += 512) {
+        const int e = idx & 7, lane = (idx >> 3) & 63, kk = (idx >> 9) % 10, mb = idx / 5120;
+        const int r = 16 * mb + (lane & 15), g = lane >> 4;
+        float v;
+        size_t o;
+        if (kk < 8) {
+            v = pack_value(W, chunk, r, slot_feature(kk, g, e), -1);
+            o = (size_t)((mb * 8 + kk) * 2) * 512 + lane * 8 + e;
+        } else {
+            v = pack_value(W, chunk, r, -1, 32 * (kk - 8) + 8 * g + e);
+            o = (size_t)(CH_REG / 2) + (size_t)((mb * 2 + (kk - 8)) * 2) * 512 + lane * 8 + e;
+        }
+        const __bf16 hi = (__bf16)v;
+        dst[o] = hi;
+        dst[o + 512] = (__bf16)(v - (float)hi);
+    }
+    if (chunk < 9) {                                      // the biases in pack-row order
+        const int l = chunk;
+        for (int r = threadIdx.x; r < BIAS_LD; r += 512) {
+            float b = 0.f;
+            if (l < 8) { if (r < (l == 3 ? OUT3 : HID)) b = B[l][r]; }
+            else if (r <= 256) b = B[8][r < 256 ? r + 1 : 0];
+            bias_all[l * BIAS_LD + r] = b;
+        }
+    }
+}
+
+// ---- stash arena (floats), P points: PL = P * 256 -------------------------------------------------------------------------------
+//   AB(l) l = 0..7 : [2P][256]  rows [0,P) = dZ_l (backward), rows [P,2P) = V_l (forward)          at  l * 2 PL
+//   BB(l) l = 1..8 : [2P][256]  rows [0,P) = X_l (forward),   rows [P,2P) = dT_l (backward)        at  16 PL + (l-1) * 2 PL
+//   U(l)  l = 0..6 : [P][256]   the gradient sweep's rows before the sigmoid factor                at  32 PL + l PL
+//   dS(l) l = 0..7 : [P][256]   sigma'' (.) U (.) dV between the backward's two sweeps               at  39 PL + l PL
+//   BB0            : [2P][39]   rows [0,P) = the Fourier features, rows [P,2P) = dG                at  47 PL
+//   G              : [P][39]                                                                       at  47 PL + 78 P
+struct TfArgs {
+    const char* wpack;
+    const float* bias;     // [9][288]
+    const float* w8;       // [256]: the sdf row of the last layer
+    float* arena;
+    float* out;            // fwd: [P][257]
+    const float* dz8;      // bwd: [P][257]
+    float* dw8;            // bwd: [256] +=  (gradient of the sdf row)
+    int P;
+};
+__host__ __device__ inline size_t off_AB(size_t PL, int l) { return (size_t)l * 2 * PL; }
+__host__ __device__ inline size_t off_BB(size_t PL, int l) { return 16 * PL + (size_t)(l - 1) * 2 * PL; }
+__host__ __device__ inline size_t off_U(size_t PL, int l) { return 32 * PL + (size_t)l * PL; }
+__host__ __device__ inline size_t off_dS(size_t PL, int l) { return 39 * PL + (size_t)l * PL; }
+__host__ __device__ inline size_t off_BB0(size_t PL) { return 47 * PL; }
+__host__ __device__ inline size_t off_G(size_t PL, size_t P) { return 47 * PL + 78 * P; }
+
+struct BReg { bf16x8 h[8], l[8]; };
+__device__ __forceinline__ bf16x8 zero_frag() { return __builtin_bit_cast(bf16x8, (f32x4){0.f, 0.f, 0.f, 0.f}); }
+
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+    const f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+    const bf16x4 ha = __builtin_convertvector(a, bf16x4), hb = __builtin_convertvector(b, bf16x4);
+    const bf16x4 la = __builtin_convertvector(a - __builtin_convertvector(ha, f32x4), bf16x4);
+    const bf16x4 lb = __builtin_convertvector(b - __builtin_convertvector(hb, f32x4), bf16x4);
+    hi = __builtin_shufflevector(ha, hb, 0, 1, 2, 3, 4, 5, 6, 7);
+    lo = __builtin_shufflevector(la, lb, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+struct Ctx {
+    const char* wpack;
+    char* ring;
+    char* binf;        // this wave's input-fragment block
+    float* redf;       // [256] per-workgroup column sums (backward)
+    int wave, lane, g, j;
+    bool late;         // second wave of its SIMD: barrier between the products and the activation code of a chunk
+    int ci, ring_pos, n_total, src_shift;
+    bool valid;
+    size_t row;        // 256 * (clamped) point index
+    size_t prow;       // (clamped) point index
+};
+
+// pieces [wl, wl + nw, ...) of chunk k into ring slot `slot`
+template <int NW>
+__device__ __forceinline__ void tf_issue(const Ctx& cx, int k, int slot, int wl) {
+    const int ku = __builtin_amdgcn_readfirstlane(k), wu = __builtin_amdgcn_readfirstlane(wl);
+    const int src = ku < 64 ? ku : ku + cx.src_shift;
+    const bool has_reg = src >= 8, has_in = src < 8 || (src >= 32 && src < 40);
+    const char* s = mp::uniform_ptr(cx.wpack) + (size_t)src * CH_BYTES + wu * TILE_B;
+    const unsigned d = __builtin_amdgcn_readfirstlane(mp::lds_offset(cx.ring)) + __builtin_amdgcn_readfirstlane(slot) * CH_BYTES +
+                       wu * TILE_B;
+    if (has_reg) {
+#pragma unroll
+        for (int i = 0; i < 32 / NW; ++i) mp::lds_dma_16(s + i * NW * TILE_B, cx.lane * 16, d + i * NW * TILE_B);
+    }
+    if (has_in) {
+#pragma unroll
+        for (int i = 0; i < 8 / NW; ++i) mp::lds_dma_16(s + CH_REG + i * NW * TILE_B, cx.lane * 16, d + CH_REG + i * NW * TILE_B);
+    }
+}
+
+#define TF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+
+// the products of one chunk: acc[mb] (16 rows x 16 points) += W tile . activations, K = 256 from registers (+ 64 from the input)
+template <bool HAS_IN>
+__device__ __forceinline__ void tf_mma(const Ctx& cx, bool use_reg, bool use_in, const BReg& B, f32x4 (&acc)[2]) {
+    const char* slot = cx.ring + cx.ring_pos * CH_BYTES + cx.lane * 16;
+    if (use_reg) {
+        // A fragments one K step ahead in a two-deep register queue: q[.][2 mb + half].  Pinned with sched_barrier: left alone,
+        // hipcc sinks every ds_read to just before its MFMA and drains lgkmcnt(0) sixteen times per chunk.
+        bf16x8 q[2][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) q[0][t] = *(const bf16x8*)(slot + (((t >> 1) * 8 + 0) * 2 + (t & 1)) * TILE_B);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            if (ks + 1 < 8) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    q[(ks + 1) & 1][t] = *(const bf16x8*)(slot + (((t >> 1) * 8 + ks + 1) * 2 + (t & 1)) * TILE_B);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 (&a)[4] = q[ks & 1];       // a[0] = hi of row block 0, a[1] = lo, a[2] = hi of row block 1, a[3] = lo
+            // the small terms first; the two row blocks alternate so that no MFMA waits for the one before it
+            acc[0] = TF_MFMA(a[1], B.h[ks], acc[0]);
+            acc[1] = TF_MFMA(a[3], B.h[ks], acc[1]);
+            acc[0] = TF_MFMA(a[0], B.l[ks], acc[0]);
+            acc[1] = TF_MFMA(a[2], B.l[ks], acc[1]);
+            acc[0] = TF_MFMA(a[0], B.h[ks], acc[0]);
+            acc[1] = TF_MFMA(a[2], B.h[ks], acc[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if constexpr (HAS_IN) {
+        if (use_in) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 bh = *(const bf16x8*)(cx.binf + (ks * 2 + 0) * TILE_B + cx.lane * 16);
+                const bf16x8 bl = *(const bf16x8*)(cx.binf + (ks * 2 + 1) * TILE_B + cx.lane * 16);
+                bf16x8 ah[2], al[2];
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    ah[mb] = *(const bf16x8*)(slot + CH_REG + ((mb * 2 + ks) * 2 + 0) * TILE_B);
+                    al[mb] = *(const bf16x8*)(slot + CH_REG + ((mb * 2 + ks) * 2 + 1) * TILE_B);
+                }
+                acc[0] = TF_MFMA(al[0], bh, acc[0]);
+                acc[1] = TF_MFMA(al[1], bh, acc[1]);
+                acc[0] = TF_MFMA(ah[0], bl, acc[0]);
+                acc[1] = TF_MFMA(ah[1], bl, acc[1]);
+                acc[0] = TF_MFMA(ah[0], bh, acc[0]);
+                acc[1] = TF_MFMA(ah[1], bh, acc[1]);
+            }
+        }
+    }
+}
+
+// One layer = up to MAXC chunks of 32 output rows.  Per chunk: prefetch of what the activation code reads, the products, the
+// chunk barrier, the activation code (Epi::run), which also writes K step c of the NEXT layer's operand.  Waves 0..3 ("early",
+// one per SIMD) pass the barrier behind their activation code, waves 4..7 ("late") between products and activation code: the
+// two waves of a SIMD run in anti-phase, one wave's VALU / memory work beside the other's MFMAs (mlp_core.hpp run_layer_pp).
+// Ring protocol: behind barrier(ci) every wave is done with chunk ci's products, so the late waves refill its slot with chunk
+// ci + 3 and wait for those pieces before barrier(ci + 1); chunk ci + 3 is first read behind barrier(ci + 2).
+template <class Epi, int MAXC, bool HAS_IN>
+__device__ __forceinline__ void tf_layer(Ctx& cx, Epi& ep, int n_chunk, bool use_reg, bool use_in, BReg& Bcur, BReg& Bnext) {
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        if (c < n_chunk) {
+            ep.prefetch(cx, c);
+            f32x4 acc[2];
+            ep.init(cx, c, acc);
+            tf_mma<HAS_IN>(cx, use_reg, use_in, Bcur, acc);
+            if (cx.late) {
+                mp::dma_wait_all();
+                __syncthreads();
+                if (cx.ci + RING < cx.n_total) tf_issue<4>(cx, cx.ci + RING, cx.ring_pos, cx.wave - 4);
+            }
+            ep.run(cx, c, acc, Bnext);
+            if (!cx.late) __syncthreads();
+            ++cx.ci;
+            cx.ring_pos = cx.ring_pos + 1 == RING ? 0 : cx.ring_pos + 1;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { Bcur.h[k] = Bnext.h[k]; Bcur.l[k] = Bnext.l[k]; }
+}
+
+__device__ __forceinline__ f32x4 ld4g(const float* p) { return *(const f32x4*)p; }
+// 1 - sigma'(Z) = exp(-100 softplus(Z)) from the stored activation x = scale * softplus(Z), kx = 100 log2(e) / scale
+// (clamped at x = 0: columns 217.. of X_4 hold the re-injected Fourier features, which may be negative -- those columns only ever
+// meet zero weights, but 2^(+144) = inf times a zero weight would be a NaN inside the MFMA)
+__device__ __forceinline__ float one_minus_sig(float x, float kx) { return __builtin_amdgcn_exp2f(__builtin_fminf(-(x * kx), 0.0f)); }
+
+__device__ __forceinline__ void ctx_setup(Ctx& cx, char* smem, const char* wpack, int P, int n_total, int src_shift) {
+    cx.wpack = wpack;
+    cx.ring = smem;
+    cx.wave = threadIdx.x >> 6;
+    cx.lane = threadIdx.x & 63;
+    cx.g = cx.lane >> 4;
+    cx.j = cx.lane & 15;
+    cx.binf = smem + RING * CH_BYTES + cx.wave * BIN_BYTES;
+    cx.redf = (float*)(smem + RING * CH_BYTES + TF_WAVES * BIN_BYTES);
+    cx.late = __builtin_amdgcn_readfirstlane(cx.wave) >= TF_WAVES / 2;
+    cx.ci = 0;
+    cx.ring_pos = 0;
+    cx.n_total = n_total;
+    cx.src_shift = src_shift;
+    const int pt = blockIdx.x * TF_PTS + cx.wave * 16 + cx.j;
+    cx.valid = pt < P;
+    cx.prow = (size_t)(pt < P ? pt : P - 1);
+    cx.row = cx.prow * HID;
+}
+
+// the wave's input-fed B fragments (64 K slots in natural order, 39 used) of src [P][39] into its LDS block
+__device__ __forceinline__ void build_bin(const Ctx& cx, const float* __restrict__ src) {
+    const float* p = src + cx.prow * E_PE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int s = 32 * ks + 8 * cx.g + e;
+            v[e] = s < E_PE ? p[s] : 0.0f;
+        }
+        bf16x8 hi, lo;
+        split8(v, hi, lo);
+        *(bf16x8*)(cx.binf + (ks * 2 + 0) * TILE_B + cx.lane * 16) = hi;
+        *(bf16x8*)(cx.binf + (ks * 2 + 1) * TILE_B + cx.lane * 16) = lo;
+    }
+}
+
+__device__ __forceinline__ void tf_prologue(Ctx& cx) {
+#pragma unroll
+    for (int k = 0; k < RING; ++k) tf_issue<TF_WAVES>(cx, k, k, cx.wave);
+    mp::dma_wait_all();
+    __syncthreads();
+}
+
+// ================================================================================================================ forward
+// value sweep: softplus layers (and the linear last layer)
+struct EpiA {
+    const float* bias;     // this layer's biases, pack-row order
+    float* xout;           // X_{l+1} rows (row-major [P][256])
+    float osc;             // scale / K2 of the stored activation (layer 3: 1/sqrt(2): the skip connection's factor)
+    bool linear;           // layer 8: rows -> out [P][257]
+    float* out;
+    __device__ __forceinline__ void prefetch(const Ctx&, int) {}
+    __device__ __forceinline__ void init(const Ctx& cx, int c, f32x4 (&acc)[2]) {
+        acc[0] = ld4g(bias + 32 * c + 4 * cx.g);
+        acc[1] = ld4g(bias + 32 * c + 16 + 4 * cx.g);
+    }
+    __device__ __forceinline__ void run(const Ctx& cx, int c, const f32x4 (&acc)[2], BReg& Bn) {
+        if (linear) {
+            if (cx.valid) {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 32 * c + 16 * mb + 4 * cx.g + i;
+                        if (r <= 256) out[cx.prow * 257 + (r < 256 ? r + 1 : 0)] = acc[mb][i];
+                    }
+            }
+            return;
+        }
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float t = acc[e >> 2][e & 3] * K2;
+            const float u = __builtin_amdgcn_exp2f(-__builtin_fabsf(t));
+            x[e] = (__builtin_fmaxf(t, 0.0f) + __builtin_amdgcn_logf(1.0f + u)) * osc;
+        }
+        if (cx.valid) {
+            float* p = xout + cx.row + 32 * c + 4 * cx.g;
+            *(f32x4*)p = (f32x4){x[0], x[1], x[2], x[3]};
+            *(f32x4*)(p + 16) = (f32x4){x[4], x[5], x[6], x[7]};
+        }
+        if (c < 8) split8(x, Bn.h[c], Bn.l[c]);
+    }
+};
+
+// gradient sweep: V_{l-1} = sigma'_{l-1} (.) T_l
+struct EpiB {
+    const float* xin;      // X_l rows: sigma'_{l-1} is derived from them
+    float kx;
+    float* uout;           // U_{l-1}
+    float* vout;           // V_{l-1}
+    bool final;            // the 39-row product with W_0^T: accumulators start from the Fourier rows of T_4, result -> G
+    float* gout;           // [P][39]
+    f32x4 px[2];
+    __device__ __forceinline__ void prefetch(const Ctx& cx, int c) {
+        if (!final && c < 8) {
+            px[0] = ld4g(xin + cx.row + 32 * c + 4 * cx.g);
+            px[1] = ld4g(xin + cx.row + 32 * c + 16 + 4 * cx.g);
+        }
+    }
+    __device__ __forceinline__ void init(const Ctx& cx, int c, f32x4 (&acc)[2]) {
+        acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (final && c < 2) {
+            acc[0] = *(const f32x4*)(cx.binf + (c * 2 + 0) * TILE_B + cx.lane * 16);
+            acc[1] = *(const f32x4*)(cx.binf + (c * 2 + 1) * TILE_B + cx.lane * 16);
+        }
+    }
+    __device__ __forceinline__ void run(const Ctx& cx, int c, const f32x4 (&acc)[2], BReg& Bn) {
+        if (final) {
+            if (cx.valid && c < 2) {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 32 * c + 16 * mb + 4 * cx.g + i;
+                        if (r < E_PE) gout[cx.prow * E_PE + r] = acc[mb][i];
+                    }
+            }
+            return;
+        }
+        if (c >= 8) {   // layer 4's Fourier rows: parked in the wave's LDS block until the final product
+            *(f32x4*)(cx.binf + ((c - 8) * 2 + 0) * TILE_B + cx.lane * 16) = acc[0];
+            *(f32x4*)(cx.binf + ((c - 8) * 2 + 1) * TILE_B + cx.lane * 16) = acc[1];
+            return;
+        }
+        float u[8], v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            u[e] = acc[e >> 2][e & 3];
+            v[e] = (1.0f - one_minus_sig(px[e >> 2][e & 3], kx)) * u[e];
+        }
+        if (cx.valid) {
+            float* pu = uout + cx.row + 32 * c + 4 * cx.g;
+            float* pv = vout + cx.row + 32 * c + 4 * cx.g;
+            *(f32x4*)pu = (f32x4){u[0], u[1], u[2], u[3]};
+            *(f32x4*)(pu + 16) = (f32x4){u[4], u[5], u[6], u[7]};
+            *(f32x4*)pv = (f32x4){v[0], v[1], v[2], v[3]};
+            *(f32x4*)(pv + 16) = (f32x4){v[4], v[5], v[6], v[7]};
+        }
+        split8(v, Bn.h[c], Bn.l[c]);
+    }
+};
+
+__global__ __launch_bounds__(TF_THREADS) void k_tf_sdf_fwd(TfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Ctx cx;
+    ctx_setup(cx, smem, a.wpack, a.P, FWD_CHUNKS, 0);
+    const size_t PL = (size_t)a.P * HID;
+    build_bin(cx, a.arena + off_BB0(PL));
+    tf_prologue(cx);
+    BReg Bcur, Bnext;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { Bcur.h[k] = Bcur.l[k] = Bnext.h[k] = Bnext.l[k] = zero_frag(); }
+    // ---- value sweep
+    for (int l = 0; l <= 8; ++l) {
+        EpiA ep;
+        ep.bias = a.bias + l * BIAS_LD;
+        ep.xout = a.arena + off_BB(PL, l < 8 ? l + 1 : 8);
+        ep.osc = (l == 3 ? R2 : 1.0f) / K2;
+        ep.linear = l == 8;
+        ep.out = a.out;
+        tf_layer<EpiA, 9, true>(cx, ep, l == 8 ? 9 : 8, l > 0, l == 0 || l == 4, Bcur, Bnext);
+    }
+    // ---- top of the gradient sweep: V_7 = sigma'_7 (.) w8, from X_8 (still the operand registers of layer 8)
+    {
+        float* vout = a.arena + off_AB(PL, 7) + PL;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const f32x4 w0 = ld4g(a.w8 + 32 * ks + 4 * cx.g), w1 = ld4g(a.w8 + 32 * ks + 16 + 4 * cx.g);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x = (float)Bcur.h[ks][e] + (float)Bcur.l[ks][e];
+                v[e] = (1.0f - one_minus_sig(x, K2)) * (e < 4 ? w0[e & 3] : w1[e & 3]);
+            }
+            if (cx.valid) {
+                float* pv = vout + cx.row + 32 * ks + 4 * cx.g;
+                *(f32x4*)pv = (f32x4){v[0], v[1], v[2], v[3]};
+                *(f32x4*)(pv + 16) = (f32x4){v[4], v[5], v[6], v[7]};
+            }
+            split8(v, Bcur.h[ks], Bcur.l[ks]);
+        }
+    }
+    // ---- gradient sweep
+    for (int l = 7; l >= 0; --l) {
+        EpiB ep;
+        ep.final = l == 0;
+        ep.xin = a.arena + off_BB(PL, l > 0 ? l : 1);
+        ep.kx = l == 4 ? K2 / R2 : K2;
+        ep.uout = a.arena + off_U(PL, l > 0 ? l - 1 : 0);
+        ep.vout = a.arena + off_AB(PL, l > 0 ? l - 1 : 0) + PL;
+        ep.gout = a.arena + off_G(PL, a.P);
+        tf_layer<EpiB, 10, false>(cx, ep, l == 4 ? 10 : (l == 0 ? 2 : 8), true, false, Bcur, Bnext);
+    }
+}
+
+// ================================================================================================================ backward
+// sum over the 16 points of a wave (lanes j = 0..15 of each group g) of 8 per-lane values -> LDS column sums
+__device__ __forceinline__ void col_reduce(const Ctx& cx, int c, float (&r)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float v = r[e];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 8);
+        r[e] = v;
+    }
+    if (cx.j == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(cx.redf + 32 * c + (e < 4 ? 4 * cx.g + e : 16 + 4 * cx.g + e - 4), r[e]);
+    }
+}
+
+// ascending sweep: dV_l arrives in the accumulators;  dU = s (.) dV,  dS = s'' (.) U (.) dV,  dT_{l+1} = scale * dU
+struct EpiC {
+    const float* xin;      // X_{l+1} rows
+    float kx;
+    const float* uin;      // U_l rows; top layer (7): the row vector w8
+    float* dtout;          // dT_{l+1} rows (null at the top)
+    float* dsout;          // dS_l rows
+    float osc;
+    bool top;
+    f32x4 px[2], pu[2];
+    __device__ __forceinline__ void prefetch(const Ctx& cx, int c) {
+        const int col = 32 * c + 4 * cx.g;
+        px[0] = ld4g(xin + cx.row + col);
+        px[1] = ld4g(xin + cx.row + col + 16);
+        if (top) {
+            pu[0] = ld4g(uin + col);
+            pu[1] = ld4g(uin + col + 16);
+        } else {
+            pu[0] = ld4g(uin + cx.row + col);
+            pu[1] = ld4g(uin + cx.row + col + 16);
+        }
+    }
+    __device__ __forceinline__ void init(const Ctx&, int, f32x4 (&acc)[2]) {
+        acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __device__ __forceinline__ void run(const Ctx& cx, int c, const f32x4 (&acc)[2], BReg& Bn) {
+        float du[8], ds[8], dt[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float dv = acc[e >> 2][e & 3];
+            const float q = one_minus_sig(px[e >> 2][e & 3], kx), s1 = 1.0f - q;
+            du[e] = s1 * dv;
+            ds[e] = 100.0f * s1 * q * pu[e >> 2][e & 3] * dv;
+            dt[e] = du[e] * osc;
+        }
+        if (cx.valid) {
+            float* ps = dsout + cx.row + 32 * c + 4 * cx.g;
+            *(f32x4*)ps = (f32x4){ds[0], ds[1], ds[2], ds[3]};
+            *(f32x4*)(ps + 16) = (f32x4){ds[4], ds[5], ds[6], ds[7]};
+        }
+        if (top) {
+            if (!cx.valid) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) du[e] = 0.0f;
+            }
+            col_reduce(cx, c, du);
+            return;
+        }
+        if (cx.valid) {
+            float* pt = dtout + cx.row + 32 * c + 4 * cx.g;
+            *(f32x4*)pt = (f32x4){dt[0], dt[1], dt[2], dt[3]};
+            *(f32x4*)(pt + 16) = (f32x4){dt[4], dt[5], dt[6], dt[7]};
+        }
+        split8(dt, Bn.h[c], Bn.l[c]);
+    }
+};
+
+// descending sweep: dX_l arrives in the accumulators;  dZ_{l-1} = s_{l-1} (.) dX_l + dS_{l-1}
+struct EpiD {
+    const float* xin;      // X_l rows
+    float kx;
+    const float* dsin;     // dS_{l-1} rows
+    float* dzout;          // dZ_{l-1} rows
+    bool first;            // layer 8: accumulators start from w8 (x) d sdf (the sdf column of dZ_8 is a rank-1 term)
+    const float* w8;
+    float dsdf;
+    f32x4 px[2], pd[2];
+    __device__ __forceinline__ void prefetch(const Ctx& cx, int c) {
+        const int col = 32 * c + 4 * cx.g;
+        px[0] = ld4g(xin + cx.row + col);
+        px[1] = ld4g(xin + cx.row + col + 16);
+        pd[0] = ld4g(dsin + cx.row + col);
+        pd[1] = ld4g(dsin + cx.row + col + 16);
+    }
+    __device__ __forceinline__ void init(const Ctx& cx, int c, f32x4 (&acc)[2]) {
+        acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (first) {
+            acc[0] = ld4g(w8 + 32 * c + 4 * cx.g) * dsdf;
+            acc[1] = ld4g(w8 + 32 * c + 16 + 4 * cx.g) * dsdf;
+        }
+    }
+    __device__ __forceinline__ void run(const Ctx& cx, int c, const f32x4 (&acc)[2], BReg& Bn) {
+        float dz[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            dz[e] = (1.0f - one_minus_sig(px[e >> 2][e & 3], kx)) * acc[e >> 2][e & 3] + pd[e >> 2][e & 3];
+        if (cx.valid) {
+            float* pz = dzout + cx.row + 32 * c + 4 * cx.g;
+            *(f32x4*)pz = (f32x4){dz[0], dz[1], dz[2], dz[3]};
+            *(f32x4*)(pz + 16) = (f32x4){dz[4], dz[5], dz[6], dz[7]};
+        }
+        split8(dz, Bn.h[c], Bn.l[c]);
+    }
+};
+
+__global__ __launch_bounds__(TF_THREADS) void k_tf_sdf_bwd(TfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Ctx cx;
+    ctx_setup(cx, smem, a.wpack, a.P, BWD_CHUNKS, BWD_SHIFT);
+    const size_t PL = (size_t)a.P * HID;
+    build_bin(cx, a.arena + off_BB0(PL) + (size_t)a.P * E_PE);     // dG
+    if (threadIdx.x < 256) cx.redf[threadIdx.x] = 0.0f;
+    tf_prologue(cx);
+    BReg Bcur, Bnext;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { Bcur.h[k] = Bcur.l[k] = Bnext.h[k] = Bnext.l[k] = zero_frag(); }
+    // ---- ascending: the adjoint of the gradient sweep
+    for (int l = 0; l <= 7; ++l) {
+        EpiC ep;
+        ep.xin = a.arena + off_BB(PL, l + 1);
+        ep.kx = l == 3 ? K2 / R2 : K2;
+        ep.top = l == 7;
+        ep.uin = l == 7 ? a.w8 : a.arena + off_U(PL, l);
+        ep.dtout = a.arena + off_BB(PL, l < 7 ? l + 1 : 8) + PL;
+        ep.dsout = a.arena + off_dS(PL, l);
+        ep.osc = l == 3 ? R2 : 1.0f;
+        tf_layer<EpiC, 8, true>(cx, ep, 8, l > 0, l == 0 || l == 4, Bcur, Bnext);
+    }
+    // ---- descending: the adjoint of the value sweep, from dZ_8 [P][257] = (d sdf | d features)
+    const float* dzp = a.dz8 + cx.prow * 257;
+    const float dsdf = dzp[0];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = dzp[1 + slot_feature(ks, cx.g, e)];
+        split8(v, Bcur.h[ks], Bcur.l[ks]);
+    }
+    for (int l = 8; l >= 1; --l) {
+        EpiD ep;
+        ep.xin = a.arena + off_BB(PL, l);
+        ep.kx = l == 4 ? K2 / R2 : K2;
+        ep.dsin = a.arena + off_dS(PL, l - 1);
+        ep.dzout = a.arena + off_AB(PL, l - 1);
+        ep.first = l == 8;
+        ep.w8 = a.w8;
+        ep.dsdf = dsdf;
+        tf_layer<EpiD, 8, false>(cx, ep, 8, true, false, Bcur, Bnext);
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) atomicAdd(a.dw8 + threadIdx.x, cx.redf[threadIdx.x]);
+}
+
+}  // namespace
+
+extern "C" int mp_tf_sdf_sizes(int P, long long* arena_floats, long long* pack_bytes) {
+    if (arena_floats) *arena_floats = (long long)P * (47LL * HID + 3 * E_PE);
+    if (pack_bytes) *pack_bytes = (long long)CH_TOTAL * CH_BYTES;
+    return 0;
+}
+
+extern "C" int mp_tf_sdf_pack(const float* const* W, const float* const* B, void* wpack, float* bias_all, void* stream) {
+    hipLaunchKernelGGL(k_tf_pack, dim3(CH_TOTAL), dim3(512), 0, (hipStream_t)stream, W, B, (__bf16*)wpack, bias_all);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_tf_sdf_fwd(const void* wpack, const float* bias_all, const float* w8, float* arena, int P, float* out,
+                             void* stream) {
+    if (P <= 0) return 0;
+    MP_LDS_ATTR(k_tf_sdf_fwd, LDS_BYTES);
+    TfArgs a{(const char*)wpack, bias_all, w8, arena, out, nullptr, nullptr, P};
+    hipLaunchKernelGGL(k_tf_sdf_fwd, dim3((P + TF_PTS - 1) / TF_PTS), dim3(TF_THREADS), LDS_BYTES, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_tf_sdf_bwd(const void* wpack, const float* w8, float* arena, int P, const float* dz8, float* dw8,
+                             void* stream) {
+    if (P <= 0) return 0;
+    MP_LDS_ATTR(k_tf_sdf_bwd, LDS_BYTES);
+    TfArgs a{(const char*)wpack, nullptr, w8, arena, nullptr, dz8, dw8, P};
+    hipLaunchKernelGGL(k_tf_sdf_bwd, dim3((P + TF_PTS - 1) / TF_PTS), dim3(TF_THREADS), LDS_BYTES, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}

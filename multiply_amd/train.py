@@ -345,6 +345,146 @@ class ImplicitTrainRev:
         return [g for lw in self.lins for g in lw.param_grads()]
 
 
+class LinP(LinW):
+    """LinW with PERSISTENT device buffers (effective weights, gradient accumulators): the fused kernels' pointer tables are built
+    once per network instead of once per iteration.  refresh() re-resolves the weight norm and zeroes the accumulators."""
+
+    def __init__(self, lin):
+        self.lin = lin
+        self.wn = hasattr(lin, "weight_g")
+        v = lin.weight_v if self.wn else lin.weight
+        self.out_dim, self.in_dim = v.shape
+        dev = v.device
+        self.W = torch.empty(self.out_dim, self.in_dim, dtype=F32, device=dev)
+        self.WT = None
+        self.dW = torch.zeros(self.out_dim, self.in_dim, dtype=F32, device=dev)
+        self.db = torch.zeros(self.out_dim, dtype=F32, device=dev)
+        self.refresh()
+
+    def refresh(self):
+        lin = self.lin
+        self.v = (lin.weight_v if self.wn else lin.weight).detach().contiguous()
+        self.g = lin.weight_g.detach().reshape(-1).contiguous() if self.wn else None
+        self.b = lin.bias.detach().contiguous()
+        _chk(hip.lib().mp_tr_wn_fwd(_p(self.v), _p(self.g), self.out_dim, self.in_dim, _p(self.W), None, hip.stream()),
+             "mp_tr_wn_fwd")
+        self.dW.zero_()
+        self.db.zero_()
+
+    def param_grads(self):
+        gs = super().param_grads()
+        gs[-1] = self.db.clone()          # the accumulator itself lives on: never hand it to autograd
+        return gs
+
+
+def fused_sdf_supported(net):
+    """the network shape csrc/tfuse.hip is specialised for: the shipped foreground ImplicitNet (confs/model/*.yaml)"""
+    return (net.d_in == 3 and net.multires == 6 and list(net.skip_in) == [4] and net.num_layers - 1 == 9 and net.cond_dim == 69
+            and list(net.dims[1:-1]) == [256] * 8 and net.dims[-1] == 257)
+
+
+class FusedSDFState:
+    """Per-network device state of the layer-fused training kernels (csrc/tfuse.hip): persistent effective weights, the split-bf16
+    chunk stream, the bias table and the pointer tables mp_tf_sdf_pack reads."""
+
+    def __init__(self, net):
+        self.net = net
+        self.lins = [LinP(l) for l in net.layers()]
+        dev = self.lins[0].W.device
+        arena, pack = C.c_longlong(0), C.c_longlong(0)
+        _chk(hip.lib().mp_tf_sdf_sizes(1, C.byref(arena), C.byref(pack)), "mp_tf_sdf_sizes")
+        self.arena_per_point = int(arena.value)
+        self.wpack = torch.empty(int(pack.value), dtype=torch.uint8, device=dev)
+        self.bias_all = torch.empty(9 * 288, dtype=F32, device=dev)
+        self.b0 = torch.empty(256, dtype=F32, device=dev)
+        self.wtab = _table([lw.W for lw in self.lins], dev)
+        self._btab_key, self.btab = None, None
+
+    def refresh(self, cond_vec):
+        L, st = hip.lib(), hip.stream()
+        net, lins = self.net, self.lins
+        for lw in lins:
+            lw.refresh()
+        lw0 = lins[0]
+        _chk(L.mp_tr_hoist_fwd(_p(lw0.W), 256, lw0.in_dim, _p(lw0.b), net.embed_dim, net.cond_dim, _p(cond_vec), _p(self.b0), st),
+             "mp_tr_hoist_fwd")
+        bs = [self.b0] + [lw.b for lw in lins[1:]]
+        key = tuple(b.data_ptr() for b in bs)
+        if key != self._btab_key:
+            self._btab_key, self.btab = key, _table(bs, self.b0.device)
+        _chk(L.mp_tf_sdf_pack(_p(self.wtab), _p(self.btab), _p(self.wpack), _p(self.bias_all), st), "mp_tf_sdf_pack")
+        return self
+
+
+def fused_sdf_state(net):
+    st = net.__dict__.get("_mp_tfuse")
+    if st is None:
+        st = net.__dict__["_mp_tfuse"] = FusedSDFState(net)
+    return st
+
+
+class ImplicitTrainFused(ImplicitTrainRev):
+    """ImplicitTrainRev's arithmetic (value sweep + gradient sweep, and the adjoint of both) on the LAYER-FUSED kernels of
+    csrc/tfuse.hip: two launches instead of ~90 per person -- mp_tf_sdf_fwd (both forward sweeps) and mp_tf_sdf_bwd (the adjoint
+    w.r.t. the activations) -- plus one weight-gradient contraction per layer over [dZ_l; V_l]^T [X_l; dT_l] (K = 2 P rows).
+    Same interface: self.out [P][257], self.grad [P][3], backward(dZ_last, dgrad) -> d cond.  The adjoint of the input points
+    (pose optimisation) is not produced here: TrainGraph takes ImplicitTrainRev when it is needed."""
+
+    def __init__(self, net, x, cond_vec):
+        L, st = hip.lib(), hip.stream()
+        assert fused_sdf_supported(net)
+        self.net, self.x, self.cond = net, x, cond_vec
+        self.P = P = x.shape[0]
+        self.E = E = net.embed_dim
+        dev = x.device
+        self.fs = fs = fused_sdf_state(net).refresh(cond_vec)
+        self.lins, self.nl = fs.lins, len(fs.lins)
+        self.arena = torch.empty(fs.arena_per_point * P, dtype=F32, device=dev)
+        PL = 256 * P
+        self.o_AB = lambda l: l * 2 * PL
+        self.o_BB = lambda l: 16 * PL + (l - 1) * 2 * PL
+        self.o_BB0 = 47 * PL
+        self.o_G = 47 * PL + 2 * E * P
+        r2 = 1.0 / math.sqrt(2.0)
+        _chk(L.mp_tr_pe(_p(x), 3, P, net.multires, 0, C.c_float(1.0), off(self.arena, self.o_BB0), E, 0, st), "mp_tr_pe")
+        self.out = torch.empty(P, 257, dtype=F32, device=dev)
+        self.w8 = fs.lins[8].W                          # row 0 = the sdf row of the last layer
+        _chk(L.mp_tf_sdf_fwd(_p(fs.wpack), _p(fs.bias_all), _p(self.w8), _p(self.arena), P, _p(self.out), st), "mp_tf_sdf_fwd")
+        # the skip connection re-injects the Fourier features into layer 4's input (times 1/sqrt 2): columns 217.. of X_4
+        _chk(L.mp_tr_copy_cols(off(self.arena, self.o_BB0), E, 0, off(self.arena, self.o_BB(4)), 256, 256 - E, P, E, C.c_float(r2), 0,
+                               st), "mp_tr_copy_cols")
+        self.grad = torch.empty(P, 3, dtype=F32, device=dev)
+        _chk(L.mp_tr_pe_grad_fwd(_p(x), P, net.multires, off(self.arena, self.o_G), E, _p(self.grad), st), "mp_tr_pe_grad_fwd")
+
+    def backward(self, dZ_last, dgrad, want_dx=False):
+        assert not want_dx, "the fused SDF kernels do not produce the adjoint of the input points"
+        L, st = hip.lib(), hip.stream()
+        net, P, E, lins, fs, A = self.net, self.P, self.E, self.lins, self.fs, self.arena
+        dev = dZ_last.device
+        r2 = 1.0 / math.sqrt(2.0)
+        PL = 256 * P
+        dG = off(A, self.o_BB0 + E * P)
+        _chk(L.mp_tr_pe_grad_bwd(_p(self.x), P, net.multires, _p(dgrad), off(A, self.o_G), E, dG, E, None, st), "mp_tr_pe_grad_bwd")
+        dw8 = torch.zeros(256, dtype=F32, device=dev)
+        _chk(L.mp_tf_sdf_bwd(_p(fs.wpack), _p(self.w8), _p(A), P, _p(dZ_last), _p(dw8), st), "mp_tf_sdf_bwd")
+        _chk(L.mp_tr_copy_cols(dG, E, 0, off(A, self.o_BB(4) + PL), 256, 256 - E, P, E, C.c_float(r2), 0, st), "mp_tr_copy_cols")
+        # weight gradients: both sweeps' contributions of a layer in ONE contraction over 2 P rows (bias gradient: the first P)
+        lw0 = lins[0]
+        gemm_tn(off(A, self.o_AB(0)), 256, off(A, self.o_BB0), E, _p(lw0.dW), lw0.in_dim, 256, E, 2 * P, _p(lw0.db), P)
+        for l in range(1, 8):
+            lw = lins[l]
+            gemm_tn(off(A, self.o_AB(l)), 256, off(A, self.o_BB(l)), 256, _p(lw.dW), lw.in_dim, lw.out_dim, lw.in_dim, 2 * P,
+                    _p(lw.db), P)
+        lw8 = lins[8]
+        gemm_tn(_p(dZ_last), 257, off(A, self.o_BB(8)), 256, _p(lw8.dW), 256, 257, 256, P, _p(lw8.db), P)
+        lw8.dW[0] += dw8
+        _chk(L.mp_tr_hoist_bwd(_p(lw0.db), 256, lw0.in_dim, E, net.cond_dim, _p(self.cond), _p(lw0.dW), st), "mp_tr_hoist_bwd")
+        dcond = torch.zeros(net.cond_dim, dtype=F32, device=dev)
+        gemm_tn(_p(lw0.db), 1, off(lw0.W, E), lw0.in_dim, _p(dcond), net.cond_dim, 1, net.cond_dim, 256)
+        self.dx = None
+        return dcond
+
+
 class RenderTrain:
     """RenderingNet (networks.py:263-312): mode 'pose_no_view' (inputs XA = [x_c, n] (6), feat) or 'nerf_frame_encoding'
     (XA = PE_4(view) (27), feat).  feat is read in place from the SDF net's last layer (ld 257, column 1..)."""
@@ -436,7 +576,8 @@ class RenderTrain:
 # Training-mode Multiply.forward (multiply.py:174-588, `self.training` branches) as ONE autograd node
 # ======================================================================================================================
 N_EIKONAL = 512          # multiply.py:324
-SDF_TRAIN_MODE = __import__("os").environ.get("MP_SDF_TRAIN_MODE", "reverse")   # 'reverse' (ImplicitTrainRev) | 'forward' 
+# 'fused' (ImplicitTrainFused: layer-fused kernels, default) | 'reverse' (ImplicitTrainRev, layer by layer) | 'forward'
+SDF_TRAIN_MODE = __import__("os").environ.get("MP_SDF_TRAIN_MODE", "fused")
 
 
 def _table(ts, dev):
@@ -525,8 +666,14 @@ class TrainGraph:
             # eikonal points near the canonical surface (multiply.py:322-327, sampler.py:84-108 with global_ratio 0)
             vc = server.verts_c.reshape(-1, 3)
             X[npts:] = vc[dr["eik_idx"]] + dr["eik_noise"] * m.sampler.local_sigma
-            rev = SDF_TRAIN_MODE == "reverse"
-            it = ImplicitTrainRev(imp, X, pp["cond"]) if rev else ImplicitTrain(imp, X, pp["cond"], fwd=True)
+            mode = SDF_TRAIN_MODE
+            if mode == "fused" and (self.pose_grad or TRAIN_PRECISION != "bf16x3" or not fused_sdf_supported(imp)):
+                mode = "reverse"      # the fused kernels: split-bf16 arithmetic, the shipped network shape, no d x_c
+            rev = mode != "forward"
+            if mode == "fused":
+                it = ImplicitTrainFused(imp, X, pp["cond"])
+            else:
+                it = ImplicitTrainRev(imp, X, pp["cond"]) if rev else ImplicitTrain(imp, X, pp["cond"], fwd=True)
             gptr = _p(it.grad) if rev else None
             XA = torch.empty(npts, 6, **f32); nrm = torch.empty(npts, 3, **f32); sdf = torch.empty(npts, **f32)
             _chk(L.mp_tr_shade_in_fwd(_p(it.out), Pt, npts, _p(X), _p(jinv), _p(XA), _p(nrm), _p(sdf), gptr, st),
