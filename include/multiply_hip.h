@@ -269,7 +269,8 @@ int mp_tr_softplus_bwd(const float* Z, int ldz, int rows, int C, int P, float sc
 int mp_tr_relu_bwd(const float* H, int ldh, int rows, int C, const float* dH, int lddh, float* dZ, int lddz, void* stream);
 /* last ImplicitNet layer Z8 [4P][257] -> sdf, normals (multiply.py:606,661) and the colour-net input XA [n][6] = [x_c, n];
  * the adjoint writes column 0 of a zero-initialised dZ8 (d sdf on value rows, d grad on tangent rows).
- * grad / dgrad (optional, [P][3]): d sdf / d x given separately instead of as tangent rows (reverse-over-reverse net) */
+ * grad / dgrad (optional, [P][3]): d sdf / d x given separately instead of as tangent rows (reverse-over-reverse net); with them
+ * Z8 / dZ8 may be NULL (the fused SDF kernels hand sdf / d sdf over as vectors: sdf_out is then not written, dsdf not copied) */
 int mp_tr_shade_in_fwd(const float* Z8, int P, int n_pts, const float* xc, const float* jinv, float* XR, float* nrm,
                        float* sdf, const float* grad, void* stream);
 int mp_tr_shade_in_bwd(const float* Z8, int P, int n_pts, const float* jinv, const float* dXR, const float* dsdf,
@@ -283,6 +284,20 @@ int mp_tr_sigmoid_bwd(const float* Y, const float* dY, long long n, float* dZ, v
 int mp_tr_wn_fwd(const float* v, const float* g, int out_dim, int in_dim, float* W, float* WT, void* stream);
 int mp_tr_wn_bwd(const float* v, const float* g, int out_dim, int in_dim, const float* dW, float* dv, float* dg,
                  void* stream);
+/* The same for many layers in ONE launch each: descs = DEVICE array of n_desc records, rows of all layers concatenated (row0 =
+ * first row of a layer in that range, ascending; total_rows = their sum).  fwd reads v, g (NULL: plain weight) and writes W, WT
+ * (WT may be NULL); bwd reads v, g and dW = acc_base + dW_off and writes dv = grad_base + dv_off, dg = grad_base + dg_off
+ * (offsets in floats: the per-iteration accumulator / gradient buffers move, the table does not). */
+typedef struct {
+    const float* v;
+    const float* g;
+    float* W;
+    float* WT;
+    long long dW_off, dv_off, dg_off;
+    int out_dim, in_dim, row0, pad_;
+} MpWnDesc;
+int mp_tr_wn_fwd_multi(const MpWnDesc* descs, int n_desc, int total_rows, void* stream);
+int mp_tr_wn_bwd_multi(const MpWnDesc* descs, int n_desc, int total_rows, const float* acc_base, float* grad_base, void* stream);
 /* per-call constant conditioning folded into the bias: b2 = b + W[:, c0:c0+n] vec ; adjoint dW[:, c0:c0+n] += db2 vec^T */
 int mp_tr_hoist_fwd(const float* W, int out_dim, int in_dim, const float* b, int c0, int n, const float* vec, float* b2,
                     void* stream);
@@ -343,13 +358,31 @@ int mp_tr_copy_cols(const float* src, int lds, int c0s, float* dst, int ldd, int
  *                      G [P][39] at 47PL+78P: d sdf / d Fourier features (fwd)
  *                    columns >= 217 of X_4 and dT_4 (the re-injected Fourier features of the skip connection, times 1/sqrt 2)
  *                    are NOT written by the kernels: the caller copies them from BB0 (mp_tr_copy_cols).
- *   mp_tf_sdf_fwd  : out [P][257] = last layer (col 0 sdf, cols 1.. features), G, and the stashes
- *   mp_tf_sdf_bwd  : dz8 [P][257] (adjoint of out), dG in BB0 -> dZ_l, dT_l stashes; dw8 [256] += the gradient sweep's
- *                    contribution to the gradient of the last layer's sdf row (V_7 = sigma'_7 (.) w8) */
+ *   mp_tf_sdf_fwd  : feat [P][256] and sdf [P] = the last layer's outputs (the reference's column 0 = sdf, columns 1.. = features),
+ *                    G, and the stashes
+ *   mp_tf_sdf_bwd  : dfeat [P][256], dsdf [P] (adjoints of feat / sdf), dG in BB0 -> dZ_l, dT_l stashes;
+ *                    dw8 [256] += gradient of the last layer's sdf ROW (the gradient sweep's V_7 = sigma'_7 (.) w8 and the value
+ *                    sweep's sum of d sdf . X_8), db8 [1] += gradient of its sdf BIAS */
 int mp_tf_sdf_sizes(int P, long long* arena_floats, long long* pack_bytes);
 int mp_tf_sdf_pack(const float* const* W, const float* const* B, void* wpack, float* bias_all, void* stream);
-int mp_tf_sdf_fwd(const void* wpack, const float* bias_all, const float* w8, float* arena, int P, float* out, void* stream);
-int mp_tf_sdf_bwd(const void* wpack, const float* w8, float* arena, int P, const float* dz8, float* dw8, void* stream);
+int mp_tf_sdf_fwd(const void* wpack, const float* bias_all, const float* w8, float* arena, int P, float* feat, float* sdf,
+                  void* stream);
+int mp_tf_sdf_bwd(const void* wpack, const float* w8, float* arena, int P, const float* dfeat, const float* dsdf, float* dw8,
+                  float* db8, void* stream);
+
+/* The foreground RenderingNet ('pose_no_view', networks.py:263-312: 270 -> 4 x 256 ReLU -> 3, sigmoid) on the same skeleton:
+ *   mp_tf_col_pack : W[5] (effective weights, layer 0 = [256][270]: columns 0..5 x_c / normal, 6..13 pose embedding, 14.. features),
+ *                    B[5] (B[0] with the pose embedding hoisted in) -> wpack, bias_all [5][288]
+ *   stash          : 8 n 256 floats: H(l) l=0..3 [n][256] at l*256n (ReLU outputs), dZ(l) l=0..3 at (4+l)*256n (their adjoints)
+ *   mp_tf_col_fwd  : feat [n][256] (row stride 256), xa [n][6] -> rgb [n][3], H stashes
+ *   mp_tf_col_bwd  : drgb, rgb [n][3], w4 = W_4 [3][256] -> dfeat [n][256], dxa [n][6], dz4 [n][3] (adjoint of the last layer's
+ *                    pre-activations), dZ stashes.  Weight gradients: dW_l = dZ_l^T H_{l-1} etc. by mp_gemm_tn_bf16x3. */
+int mp_tf_col_sizes(int n, long long* stash_floats, long long* pack_bytes);
+int mp_tf_col_pack(const float* const* W, const float* const* B, void* wpack, float* bias_all, void* stream);
+int mp_tf_col_fwd(const void* wpack, const float* bias_all, float* stash, const float* feat, const float* xa, int n, float* rgb,
+                  void* stream);
+int mp_tf_col_bwd(const void* wpack, float* stash, const float* w4, const float* rgb, const float* drgb, int n, float* dfeat,
+                  float* dxa, float* dz4, void* stream);
 
 /* ---- in / off-surface flags (multiply.py:153-167; training, current_epoch < 250) -------------------------------
  * signed distance of canonical points to a triangle mesh given as face_verts [F][3][3] (= mesh_face_vertices_list[p]):

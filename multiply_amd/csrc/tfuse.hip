@@ -42,7 +42,7 @@ constexpr int CH_IN = 2 * 2 * 2 * TILE_B;     // input-fed part (Fourier feature
 constexpr int CH_BYTES = CH_REG + CH_IN;      // 40 KiB
 constexpr int RING = 3;
 constexpr int BIN_BYTES = 4096;               // per wave: the input-fed B fragments [K step][hi | lo][lane][8]
-constexpr int LDS_BYTES = RING * CH_BYTES + TF_WAVES * BIN_BYTES + 256 * 4;
+constexpr int LDS_BYTES = RING * CH_BYTES + TF_WAVES * BIN_BYTES + 272 * 4;
 constexpr float K2 = 144.26950408889634f;     // 100 log2(e): softplus_100 in base 2
 constexpr float R2 = 0.70710678118654752f;    // the skip connection's 1/sqrt(2)
 constexpr int E_PE = 39, OUT3 = 217, BIAS_LD = 288, HID = 256;
@@ -98,8 +98,8 @@ __device__ float pack_value(const float* const* __restrict__ W, int chunk, int r
     return W[l][(size_t)f * HID + R];
 }
 
-__global__ __launch_bounds__(512) void k_tf_pack(const float* const* __restrict__ W, const float* const* __restrict__ B,
-                                                 __bf16* __restrict__ wpack, float* __restrict__ bias_all) {
+template <class F>
+__device__ __forceinline__ void pack_chunk(const float* const* __restrict__ W, __bf16* __restrict__ wpack, F value) {
     const int chunk = blockIdx.x;
     __bf16* dst = wpack + (size_t)chunk * (CH_BYTES / 2);
     for (int idx = threadIdx.x; idx < 2 * 10 * 64 * 8; idx += 512) {
@@ -108,16 +108,22 @@ __global__ __launch_bounds__(512) void k_tf_pack(const float* const* __restrict_
         float v;
         size_t o;
         if (kk < 8) {
-            v = pack_value(W, chunk, r, slot_feature(kk, g, e), -1);
+            v = value(W, chunk, r, slot_feature(kk, g, e), -1);
             o = (size_t)((mb * 8 + kk) * 2) * 512 + lane * 8 + e;
         } else {
-            v = pack_value(W, chunk, r, -1, 32 * (kk - 8) + 8 * g + e);
+            v = value(W, chunk, r, -1, 32 * (kk - 8) + 8 * g + e);
             o = (size_t)(CH_REG / 2) + (size_t)((mb * 2 + (kk - 8)) * 2) * 512 + lane * 8 + e;
         }
         const __bf16 hi = (__bf16)v;
         dst[o] = hi;
         dst[o + 512] = (__bf16)(v - (float)hi);
     }
+}
+
+__global__ __launch_bounds__(512) void k_tf_pack(const float* const* __restrict__ W, const float* const* __restrict__ B,
+                                                 __bf16* __restrict__ wpack, float* __restrict__ bias_all) {
+    pack_chunk(W, wpack, pack_value);
+    const int chunk = blockIdx.x;
     if (chunk < 9) {                                      // the biases in pack-row order
         const int l = chunk;
         for (int r = threadIdx.x; r < BIAS_LD; r += 512) {
@@ -141,9 +147,12 @@ struct TfArgs {
     const float* bias;     // [9][288]
     const float* w8;       // [256]: the sdf row of the last layer
     float* arena;
-    float* out;            // fwd: [P][257]
-    const float* dz8;      // bwd: [P][257]
-    float* dw8;            // bwd: [256] +=  (gradient of the sdf row)
+    float* feat;           // fwd: [P][256] feature rows of the last layer
+    float* sdf;            // fwd: [P]
+    const float* dfeat;    // bwd: [P][256]
+    const float* dsdf;     // bwd: [P]
+    float* dw8;            // bwd: [256] +=  gradient of the last layer's sdf row
+    float* db8;            // bwd: [1] +=  gradient of its bias
     int P;
 };
 __host__ __device__ inline size_t off_AB(size_t PL, int l) { return (size_t)l * 2 * PL; }
@@ -169,10 +178,12 @@ struct Ctx {
     const char* wpack;
     char* ring;
     char* binf;        // this wave's input-fragment block
-    float* redf;       // [256] per-workgroup column sums (backward)
+    float* redf;       // [257] per-workgroup column sums (backward)
     int wave, lane, g, j;
     bool late;         // second wave of its SIMD: barrier between the products and the activation code of a chunk
-    int ci, ring_pos, n_total, src_shift;
+    int ci, ring_pos, n_total;
+    int split_at, src_shift;            // stream position k -> chunk k (k < split_at) or k + src_shift
+    int noreg_hi, in0_lo, in0_hi, in1_lo, in1_hi;   // chunks below noreg_hi have no register-fed part; two chunk ranges have an input-fed part
     bool valid;
     size_t row;        // 256 * (clamped) point index
     size_t prow;       // (clamped) point index
@@ -182,8 +193,8 @@ struct Ctx {
 template <int NW>
 __device__ __forceinline__ void tf_issue(const Ctx& cx, int k, int slot, int wl) {
     const int ku = __builtin_amdgcn_readfirstlane(k), wu = __builtin_amdgcn_readfirstlane(wl);
-    const int src = ku < 64 ? ku : ku + cx.src_shift;
-    const bool has_reg = src >= 8, has_in = src < 8 || (src >= 32 && src < 40);
+    const int src = ku < cx.split_at ? ku : ku + cx.src_shift;
+    const bool has_reg = src >= cx.noreg_hi, has_in = (src >= cx.in0_lo && src < cx.in0_hi) || (src >= cx.in1_lo && src < cx.in1_hi);
     const char* s = mp::uniform_ptr(cx.wpack) + (size_t)src * CH_BYTES + wu * TILE_B;
     const unsigned d = __builtin_amdgcn_readfirstlane(mp::lds_offset(cx.ring)) + __builtin_amdgcn_readfirstlane(slot) * CH_BYTES +
                        wu * TILE_B;
@@ -287,7 +298,7 @@ __device__ __forceinline__ f32x4 ld4g(const float* p) { return *(const f32x4*)p;
 // meet zero weights, but 2^(+144) = inf times a zero weight would be a NaN inside the MFMA)
 __device__ __forceinline__ float one_minus_sig(float x, float kx) { return __builtin_amdgcn_exp2f(__builtin_fminf(-(x * kx), 0.0f)); }
 
-__device__ __forceinline__ void ctx_setup(Ctx& cx, char* smem, const char* wpack, int P, int n_total, int src_shift) {
+__device__ __forceinline__ void ctx_setup(Ctx& cx, char* smem, const char* wpack, int P, int n_total, int split_at, int src_shift) {
     cx.wpack = wpack;
     cx.ring = smem;
     cx.wave = threadIdx.x >> 6;
@@ -300,7 +311,9 @@ __device__ __forceinline__ void ctx_setup(Ctx& cx, char* smem, const char* wpack
     cx.ci = 0;
     cx.ring_pos = 0;
     cx.n_total = n_total;
+    cx.split_at = split_at;
     cx.src_shift = src_shift;
+    cx.noreg_hi = 8; cx.in0_lo = 0; cx.in0_hi = 8; cx.in1_lo = 32; cx.in1_hi = 40;     // the SDF net's stream (colour kernels override)
     const int pt = blockIdx.x * TF_PTS + cx.wave * 16 + cx.j;
     cx.valid = pt < P;
     cx.prow = (size_t)(pt < P ? pt : P - 1);
@@ -308,15 +321,15 @@ __device__ __forceinline__ void ctx_setup(Ctx& cx, char* smem, const char* wpack
 }
 
 // the wave's input-fed B fragments (64 K slots in natural order, 39 used) of src [P][39] into its LDS block
-__device__ __forceinline__ void build_bin(const Ctx& cx, const float* __restrict__ src) {
-    const float* p = src + cx.prow * E_PE;
+__device__ __forceinline__ void build_bin(const Ctx& cx, const float* __restrict__ src, int n_in = E_PE) {
+    const float* p = src + cx.prow * n_in;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int s = 32 * ks + 8 * cx.g + e;
-            v[e] = s < E_PE ? p[s] : 0.0f;
+            v[e] = s < n_in ? p[s] : 0.0f;
         }
         bf16x8 hi, lo;
         split8(v, hi, lo);
@@ -338,8 +351,9 @@ struct EpiA {
     const float* bias;     // this layer's biases, pack-row order
     float* xout;           // X_{l+1} rows (row-major [P][256])
     float osc;             // scale / K2 of the stored activation (layer 3: 1/sqrt(2): the skip connection's factor)
-    bool linear;           // layer 8: rows -> out [P][257]
-    float* out;
+    bool linear;           // layer 8: rows 0..255 -> feat [P][256], row 256 -> sdf [P]
+    float* feat;
+    float* sdf;
     __device__ __forceinline__ void prefetch(const Ctx&, int) {}
     __device__ __forceinline__ void init(const Ctx& cx, int c, f32x4 (&acc)[2]) {
         acc[0] = ld4g(bias + 32 * c + 4 * cx.g);
@@ -348,13 +362,13 @@ struct EpiA {
     __device__ __forceinline__ void run(const Ctx& cx, int c, const f32x4 (&acc)[2], BReg& Bn) {
         if (linear) {
             if (cx.valid) {
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int r = 32 * c + 16 * mb + 4 * cx.g + i;
-                        if (r <= 256) out[cx.prow * 257 + (r < 256 ? r + 1 : 0)] = acc[mb][i];
-                    }
+                if (c < 8) {
+                    float* p = feat + cx.row + 32 * c + 4 * cx.g;
+                    *(f32x4*)p = acc[0];
+                    *(f32x4*)(p + 16) = acc[1];
+                } else if (cx.g == 0) {
+                    sdf[cx.prow] = acc[0][0];
+                }
             }
             return;
         }
@@ -436,7 +450,7 @@ struct EpiB {
 __global__ __launch_bounds__(TF_THREADS) void k_tf_sdf_fwd(TfArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Ctx cx;
-    ctx_setup(cx, smem, a.wpack, a.P, FWD_CHUNKS, 0);
+    ctx_setup(cx, smem, a.wpack, a.P, FWD_CHUNKS, FWD_CHUNKS, 0);
     const size_t PL = (size_t)a.P * HID;
     build_bin(cx, a.arena + off_BB0(PL));
     tf_prologue(cx);
@@ -450,7 +464,8 @@ __global__ __launch_bounds__(TF_THREADS) void k_tf_sdf_fwd(TfArgs a) {
         ep.xout = a.arena + off_BB(PL, l < 8 ? l + 1 : 8);
         ep.osc = (l == 3 ? R2 : 1.0f) / K2;
         ep.linear = l == 8;
-        ep.out = a.out;
+        ep.feat = a.feat;
+        ep.sdf = a.sdf;
         tf_layer<EpiA, 9, true>(cx, ep, l == 8 ? 9 : 8, l > 0, l == 0 || l == 4, Bcur, Bnext);
     }
     // ---- top of the gradient sweep: V_7 = sigma'_7 (.) w8, from X_8 (still the operand registers of layer 8)
@@ -568,7 +583,7 @@ struct EpiD {
     float kx;
     const float* dsin;     // dS_{l-1} rows
     float* dzout;          // dZ_{l-1} rows
-    bool first;            // layer 8: accumulators start from w8 (x) d sdf (the sdf column of dZ_8 is a rank-1 term)
+    bool first;            // layer 8: accumulators start from w8 (x) d sdf (a rank-1 term); also sums d sdf . X_8
     const float* w8;
     float dsdf;
     f32x4 px[2], pd[2];
@@ -598,16 +613,22 @@ struct EpiD {
             *(f32x4*)(pz + 16) = (f32x4){dz[4], dz[5], dz[6], dz[7]};
         }
         split8(dz, Bn.h[c], Bn.l[c]);
+        if (first) {            // the value sweep's part of the sdf row's gradient: sum over points of d sdf . X_8
+            float r[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = cx.valid ? dsdf * px[e >> 2][e & 3] : 0.0f;
+            col_reduce(cx, c, r);
+        }
     }
 };
 
 __global__ __launch_bounds__(TF_THREADS) void k_tf_sdf_bwd(TfArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Ctx cx;
-    ctx_setup(cx, smem, a.wpack, a.P, BWD_CHUNKS, BWD_SHIFT);
+    ctx_setup(cx, smem, a.wpack, a.P, BWD_CHUNKS, 64, BWD_SHIFT);
     const size_t PL = (size_t)a.P * HID;
     build_bin(cx, a.arena + off_BB0(PL) + (size_t)a.P * E_PE);     // dG
-    if (threadIdx.x < 256) cx.redf[threadIdx.x] = 0.0f;
+    if (threadIdx.x < 257) cx.redf[threadIdx.x] = 0.0f;
     tf_prologue(cx);
     BReg Bcur, Bnext;
 #pragma unroll
@@ -625,14 +646,20 @@ __global__ __launch_bounds__(TF_THREADS) void k_tf_sdf_bwd(TfArgs a) {
         tf_layer<EpiC, 8, true>(cx, ep, 8, l > 0, l == 0 || l == 4, Bcur, Bnext);
     }
     // ---- descending: the adjoint of the value sweep, from dZ_8 [P][257] = (d sdf | d features)
-    const float* dzp = a.dz8 + cx.prow * 257;
-    const float dsdf = dzp[0];
+    const float dsdf = a.dsdf[cx.prow];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = dzp[1 + slot_feature(ks, cx.g, e)];
+        const f32x4 v0 = ld4g(a.dfeat + cx.row + 32 * ks + 4 * cx.g), v1 = ld4g(a.dfeat + cx.row + 32 * ks + 16 + 4 * cx.g);
+        const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         split8(v, Bcur.h[ks], Bcur.l[ks]);
+    }
+    {   // the last layer's sdf bias gradient: sum over the workgroup's points of d sdf
+        float t = (cx.valid && cx.g == 0) ? dsdf : 0.0f;
+        t += __shfl_xor(t, 1);
+        t += __shfl_xor(t, 2);
+        t += __shfl_xor(t, 4);
+        t += __shfl_xor(t, 8);
+        if (cx.lane == 0) atomicAdd(cx.redf + 256, t);
     }
     for (int l = 8; l >= 1; --l) {
         EpiD ep;
@@ -647,6 +674,205 @@ __global__ __launch_bounds__(TF_THREADS) void k_tf_sdf_bwd(TfArgs a) {
     }
     __syncthreads();
     if (threadIdx.x < 256) atomicAdd(a.dw8 + threadIdx.x, cx.redf[threadIdx.x]);
+    if (threadIdx.x == 256) atomicAdd(a.db8, cx.redf[256]);
+}
+
+// ================================================================================================================ colour net
+// RenderingNet, mode 'pose_no_view' (networks.py:263-312): [x_c, n (6: input-fed) | pose embedding (8: hoisted into the bias) |
+// features (256: register-fed, read from the SDF kernel's feat rows)] -> 4 x (256, ReLU) -> 3 -> sigmoid.  Same skeleton, ReLU.
+// chunk stream: 0..7 layer 0; 8..31 layers 1..3; 32 layer 4 (3 rows);  33..56 W_l^T for l = 3, 2, 1; 57..64 W_0[:, 14:270]^T
+// (rows = the 256 feature columns); 65 W_0[:, 0:6]^T (6 rows).  Forward: 0..32; backward: 33..65.
+constexpr int COL_FWD = 33, COL_TOTAL = 66, COL_IN = 6, COL_FEAT0 = 14, COL_K0 = 270;
+__device__ float pack_value_col(const float* const* __restrict__ W, int chunk, int r, int f, int s) {
+    const bool reg = f >= 0;
+    if (chunk < COL_FWD) {
+        const int l = chunk < 32 ? chunk >> 3 : 4, R = chunk < 32 ? 32 * (chunk & 7) + r : r;
+        if (R >= (l < 4 ? HID : 3)) return 0.f;
+        if (reg) return l == 0 ? W[0][(size_t)R * COL_K0 + COL_FEAT0 + f] : W[l][(size_t)R * HID + f];
+        return (l == 0 && s < COL_IN) ? W[0][(size_t)R * COL_K0 + s] : 0.f;
+    }
+    if (!reg) return 0.f;
+    if (chunk < 57) { const int l = 3 - (chunk - 33) / 8, R = 32 * ((chunk - 33) % 8) + r; return W[l][(size_t)f * HID + R]; }
+    if (chunk < 65) { const int R = 32 * (chunk - 57) + r; return W[0][(size_t)f * COL_K0 + COL_FEAT0 + R]; }
+    return r < COL_IN ? W[0][(size_t)f * COL_K0 + r] : 0.f;
+}
+__global__ __launch_bounds__(512) void k_tf_pack_col(const float* const* __restrict__ W, const float* const* __restrict__ B,
+                                                     __bf16* __restrict__ wpack, float* __restrict__ bias_all) {
+    pack_chunk(W, wpack, pack_value_col);
+    const int l = blockIdx.x;
+    if (l < 5)
+        for (int r = threadIdx.x; r < BIAS_LD; r += 512) bias_all[l * BIAS_LD + r] = r < (l < 4 ? HID : 3) ? B[l][r] : 0.f;
+}
+
+// stash (floats), n points: H(l) l = 0..3 [n][256] at l * 256 n (layer l's ReLU output); dZ(l) l = 0..3 at (4 + l) * 256 n
+struct ColArgs {
+    const char* wpack;
+    const float* bias;     // [5][288]
+    float* stash;
+    const float* feat;     // [n][256]
+    const float* xa;       // [n][6]
+    float* rgb;            // fwd out / bwd in: [n][3]
+    const float* drgb;     // bwd: [n][3]
+    const float* w4;       // bwd: W_4 [3][256]
+    float* dfeat;          // bwd: [n][256]
+    float* dxa;            // bwd: [n][6]
+    float* dz4;            // bwd: [n][3]  (adjoint of the last layer's pre-activations, for its weight gradient)
+    int n;
+};
+
+struct EpiR {
+    const float* bias;
+    float* hout;
+    bool last;
+    float* rgb;
+    __device__ __forceinline__ void prefetch(const Ctx&, int) {}
+    __device__ __forceinline__ void init(const Ctx& cx, int c, f32x4 (&acc)[2]) {
+        acc[0] = ld4g(bias + 32 * c + 4 * cx.g);
+        acc[1] = ld4g(bias + 32 * c + 16 + 4 * cx.g);
+    }
+    __device__ __forceinline__ void run(const Ctx& cx, int c, const f32x4 (&acc)[2], BReg& Bn) {
+        if (last) {
+            if (cx.valid && c == 0 && cx.g == 0) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) rgb[cx.prow * 3 + a] = 1.0f / (1.0f + expf(-acc[0][a]));
+            }
+            return;
+        }
+        float h[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = __builtin_fmaxf(acc[e >> 2][e & 3], 0.0f);
+        if (cx.valid) {
+            float* p = hout + cx.row + 32 * c + 4 * cx.g;
+            *(f32x4*)p = (f32x4){h[0], h[1], h[2], h[3]};
+            *(f32x4*)(p + 16) = (f32x4){h[4], h[5], h[6], h[7]};
+        }
+        if (c < 8) split8(h, Bn.h[c], Bn.l[c]);
+    }
+};
+
+__global__ __launch_bounds__(TF_THREADS) void k_tf_col_fwd(ColArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Ctx cx;
+    ctx_setup(cx, smem, a.wpack, a.n, COL_FWD, COL_FWD, 0);
+    cx.noreg_hi = 0; cx.in0_lo = 0; cx.in0_hi = 8; cx.in1_lo = cx.in1_hi = 0;
+    const size_t NL = (size_t)a.n * HID;
+    build_bin(cx, a.xa, COL_IN);
+    tf_prologue(cx);
+    BReg Bcur, Bnext;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const f32x4 v0 = ld4g(a.feat + cx.row + 32 * ks + 4 * cx.g), v1 = ld4g(a.feat + cx.row + 32 * ks + 16 + 4 * cx.g);
+        const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        split8(v, Bcur.h[ks], Bcur.l[ks]);
+        Bnext.h[ks] = Bnext.l[ks] = zero_frag();
+    }
+    for (int l = 0; l <= 4; ++l) {
+        EpiR ep;
+        ep.bias = a.bias + l * BIAS_LD;
+        ep.hout = a.stash + (size_t)(l < 4 ? l : 3) * NL;
+        ep.last = l == 4;
+        ep.rgb = a.rgb;
+        tf_layer<EpiR, 8, true>(cx, ep, l == 4 ? 1 : 8, true, l == 0, Bcur, Bnext);
+    }
+}
+
+// backward: dH_{l-1} arrives in the accumulators; dZ_{l-1} = [H_{l-1} > 0] dH_{l-1};  last product: d feat (256 rows) and d XA (6)
+struct EpiRb {
+    const float* hin;
+    float* dzout;
+    bool final;
+    float* dfeat;
+    float* dxa;
+    f32x4 ph[2];
+    __device__ __forceinline__ void prefetch(const Ctx& cx, int c) {
+        if (!final) {
+            ph[0] = ld4g(hin + cx.row + 32 * c + 4 * cx.g);
+            ph[1] = ld4g(hin + cx.row + 32 * c + 16 + 4 * cx.g);
+        }
+    }
+    __device__ __forceinline__ void init(const Ctx&, int, f32x4 (&acc)[2]) {
+        acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __device__ __forceinline__ void run(const Ctx& cx, int c, const f32x4 (&acc)[2], BReg& Bn) {
+        if (final) {
+            if (cx.valid) {
+                if (c < 8) {
+                    float* p = dfeat + cx.row + 32 * c + 4 * cx.g;
+                    *(f32x4*)p = acc[0];
+                    *(f32x4*)(p + 16) = acc[1];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (4 * cx.g + i < COL_IN) dxa[cx.prow * COL_IN + 4 * cx.g + i] = acc[0][i];
+                }
+            }
+            return;
+        }
+        float dz[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dz[e] = ph[e >> 2][e & 3] > 0.0f ? acc[e >> 2][e & 3] : 0.0f;
+        if (cx.valid) {
+            float* p = dzout + cx.row + 32 * c + 4 * cx.g;
+            *(f32x4*)p = (f32x4){dz[0], dz[1], dz[2], dz[3]};
+            *(f32x4*)(p + 16) = (f32x4){dz[4], dz[5], dz[6], dz[7]};
+        }
+        if (c < 8) split8(dz, Bn.h[c], Bn.l[c]);
+    }
+};
+
+__global__ __launch_bounds__(TF_THREADS) void k_tf_col_bwd(ColArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Ctx cx;
+    ctx_setup(cx, smem, a.wpack, a.n, COL_TOTAL - COL_FWD, 0, COL_FWD);
+    cx.noreg_hi = 0; cx.in0_lo = cx.in0_hi = cx.in1_lo = cx.in1_hi = 0;
+    const size_t NL = (size_t)a.n * HID;
+    tf_prologue(cx);
+    BReg Bcur, Bnext;
+    // the sigmoid and the 3-row last layer by hand: dz4 = d rgb . rgb (1 - rgb);  dH_3 = W_4^T dz4;  dZ_3 = [H_3 > 0] dH_3
+    float dz4[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float y = a.rgb[cx.prow * 3 + k];
+        dz4[k] = a.drgb[cx.prow * 3 + k] * y * (1.0f - y);
+    }
+    if (cx.valid && cx.g == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a.dz4[cx.prow * 3 + k] = dz4[k];
+    }
+    {
+        const float* h3 = a.stash + 3 * NL + cx.row;
+        float* dz3 = a.stash + 7 * NL + cx.row;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int col = 32 * ks + 4 * cx.g;
+            const f32x4 h0 = ld4g(h3 + col), h1 = ld4g(h3 + col + 16);
+            f32x4 d0 = (f32x4){0.f, 0.f, 0.f, 0.f}, d1 = d0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                d0 += ld4g(a.w4 + k * HID + col) * dz4[k];
+                d1 += ld4g(a.w4 + k * HID + col + 16) * dz4[k];
+            }
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = h0[e] > 0.0f ? d0[e] : 0.0f; v[4 + e] = h1[e] > 0.0f ? d1[e] : 0.0f; }
+            if (cx.valid) {
+                *(f32x4*)(dz3 + col) = (f32x4){v[0], v[1], v[2], v[3]};
+                *(f32x4*)(dz3 + col + 16) = (f32x4){v[4], v[5], v[6], v[7]};
+            }
+            split8(v, Bcur.h[ks], Bcur.l[ks]);
+            Bnext.h[ks] = Bnext.l[ks] = zero_frag();
+        }
+    }
+    for (int l = 3; l >= 0; --l) {
+        EpiRb ep;
+        ep.final = l == 0;
+        ep.hin = a.stash + (size_t)(l > 0 ? l - 1 : 0) * NL;
+        ep.dzout = a.stash + (size_t)(4 + (l > 0 ? l - 1 : 0)) * NL;
+        ep.dfeat = a.dfeat;
+        ep.dxa = a.dxa;
+        tf_layer<EpiRb, 9, false>(cx, ep, l == 0 ? 9 : 8, true, false, Bcur, Bnext);
+    }
 }
 
 }  // namespace
@@ -662,20 +888,49 @@ extern "C" int mp_tf_sdf_pack(const float* const* W, const float* const* B, void
     return (int)hipGetLastError();
 }
 
-extern "C" int mp_tf_sdf_fwd(const void* wpack, const float* bias_all, const float* w8, float* arena, int P, float* out,
-                             void* stream) {
+extern "C" int mp_tf_sdf_fwd(const void* wpack, const float* bias_all, const float* w8, float* arena, int P, float* feat,
+                             float* sdf, void* stream) {
     if (P <= 0) return 0;
     MP_LDS_ATTR(k_tf_sdf_fwd, LDS_BYTES);
-    TfArgs a{(const char*)wpack, bias_all, w8, arena, out, nullptr, nullptr, P};
+    TfArgs a{(const char*)wpack, bias_all, w8, arena, feat, sdf, nullptr, nullptr, nullptr, nullptr, P};
     hipLaunchKernelGGL(k_tf_sdf_fwd, dim3((P + TF_PTS - 1) / TF_PTS), dim3(TF_THREADS), LDS_BYTES, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 
-extern "C" int mp_tf_sdf_bwd(const void* wpack, const float* w8, float* arena, int P, const float* dz8, float* dw8,
-                             void* stream) {
+extern "C" int mp_tf_sdf_bwd(const void* wpack, const float* w8, float* arena, int P, const float* dfeat, const float* dsdf,
+                             float* dw8, float* db8, void* stream) {
     if (P <= 0) return 0;
     MP_LDS_ATTR(k_tf_sdf_bwd, LDS_BYTES);
-    TfArgs a{(const char*)wpack, nullptr, w8, arena, nullptr, dz8, dw8, P};
+    TfArgs a{(const char*)wpack, nullptr, w8, arena, nullptr, nullptr, dfeat, dsdf, dw8, db8, P};
     hipLaunchKernelGGL(k_tf_sdf_bwd, dim3((P + TF_PTS - 1) / TF_PTS), dim3(TF_THREADS), LDS_BYTES, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_tf_col_sizes(int n, long long* stash_floats, long long* pack_bytes) {
+    if (stash_floats) *stash_floats = (long long)n * 8 * HID;
+    if (pack_bytes) *pack_bytes = (long long)COL_TOTAL * CH_BYTES;
+    return 0;
+}
+
+extern "C" int mp_tf_col_pack(const float* const* W, const float* const* B, void* wpack, float* bias_all, void* stream) {
+    hipLaunchKernelGGL(k_tf_pack_col, dim3(COL_TOTAL), dim3(512), 0, (hipStream_t)stream, W, B, (__bf16*)wpack, bias_all);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_tf_col_fwd(const void* wpack, const float* bias_all, float* stash, const float* feat, const float* xa, int n,
+                             float* rgb, void* stream) {
+    if (n <= 0) return 0;
+    MP_LDS_ATTR(k_tf_col_fwd, LDS_BYTES);
+    ColArgs a{(const char*)wpack, bias_all, stash, feat, xa, rgb, nullptr, nullptr, nullptr, nullptr, nullptr, n};
+    hipLaunchKernelGGL(k_tf_col_fwd, dim3((n + TF_PTS - 1) / TF_PTS), dim3(TF_THREADS), LDS_BYTES, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_tf_col_bwd(const void* wpack, float* stash, const float* w4, const float* rgb, const float* drgb, int n,
+                             float* dfeat, float* dxa, float* dz4, void* stream) {
+    if (n <= 0) return 0;
+    MP_LDS_ATTR(k_tf_col_bwd, LDS_BYTES);
+    ColArgs a{(const char*)wpack, nullptr, stash, nullptr, nullptr, (float*)rgb, drgb, w4, dfeat, dxa, dz4, n};
+    hipLaunchKernelGGL(k_tf_col_bwd, dim3((n + TF_PTS - 1) / TF_PTS), dim3(TF_THREADS), LDS_BYTES, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }

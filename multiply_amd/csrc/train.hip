@@ -129,7 +129,7 @@ __global__ void k_shade_in_fwd(const float* __restrict__ Z8, int P, int n_pts, c
         o[3 + j] = n1[j] / b;
         nrm_out[3 * (size_t)i + j] = n1[j] / b;
     }
-    sdf_out[i] = Z8[(size_t)i * ld];
+    if (Z8) sdf_out[i] = Z8[(size_t)i * ld];   // Z8 == NULL (with grad given): the caller already holds the sdf column
 }
 
 // adjoints: dXA [n][6] (from the colour net), dsdf [n] (from compositing), dnrm_extra [n][3] (direct normal losses, may
@@ -173,7 +173,7 @@ __global__ void k_shade_in_bwd(const float* __restrict__ Z8, int P, int n_pts, c
         if (dgrad) dgrad[3 * (size_t)i + k] = dg;
         else dZ8[(size_t)((k + 1) * P + i) * ld] = dg;
     }
-    dZ8[(size_t)i * ld] = dsdf[i];
+    if (dZ8) dZ8[(size_t)i * ld] = dsdf[i];   // dZ8 == NULL (with dgrad given): the caller passes d sdf on as a vector
     if (djinv)   // v_j = sum_k g_k Jinv[k][j]
         for (int k = 0; k < 3; ++k)
             for (int j = 0; j < 3; ++j) djinv[9 * (size_t)i + 3 * k + j] = g[k] * dv[j];
@@ -242,6 +242,58 @@ __global__ __launch_bounds__(64) void k_wn_bwd(const float* __restrict__ v, cons
     for (int c = lane; c < in_dim; c += 64)
         dv[(size_t)r * in_dim + c] = (gg / nrm) * (dW[(size_t)r * in_dim + c] - dot / ss * v[(size_t)r * in_dim + c]);
     if (lane == 0) dg[r] = dot / nrm;
+}
+
+// The same two kernels for MANY layers in one launch (a training iteration resolves ~40 weight-normed layers: 2 launches instead
+// of ~80): block = one row of the concatenated row range, its layer found by binary search over the descriptors' first rows.
+__device__ __forceinline__ const MpWnDesc& wn_find(const MpWnDesc* __restrict__ d, int n, int row, int& r) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (d[mid].row0 <= row) lo = mid; else hi = mid - 1;
+    }
+    r = row - d[lo].row0;
+    return d[lo];
+}
+__global__ __launch_bounds__(64) void k_wn_fwd_multi(const MpWnDesc* __restrict__ descs, int n) {
+    int r;
+    const MpWnDesc& D = wn_find(descs, n, blockIdx.x, r);
+    const int lane = threadIdx.x, in_dim = D.in_dim, out_dim = D.out_dim;
+    const float* v = D.v + (size_t)r * in_dim;
+    float ss = 0.f;
+    if (D.g)
+        for (int c = lane; c < in_dim; c += 64) ss += v[c] * v[c];
+    ss = mp::wsum(ss);
+    const float s = D.g ? D.g[r] / sqrtf(ss) : 1.0f;
+    for (int c = lane; c < in_dim; c += 64) {
+        const float w = v[c] * s;
+        D.W[(size_t)r * in_dim + c] = w;
+        if (D.WT) D.WT[(size_t)c * out_dim + r] = w;
+    }
+}
+__global__ __launch_bounds__(64) void k_wn_bwd_multi(const MpWnDesc* __restrict__ descs, int n, const float* __restrict__ acc_base,
+                                                      float* __restrict__ grad_base) {
+    int r;
+    const MpWnDesc& D = wn_find(descs, n, blockIdx.x, r);
+    const int lane = threadIdx.x, in_dim = D.in_dim;
+    const float* v = D.v + (size_t)r * in_dim;
+    const float* dW = acc_base + D.dW_off + (size_t)r * in_dim;
+    float* dv = grad_base + D.dv_off + (size_t)r * in_dim;
+    if (!D.g) {
+        for (int c = lane; c < in_dim; c += 64) dv[c] = dW[c];
+        return;
+    }
+    float ss = 0.f, dot = 0.f;
+    for (int c = lane; c < in_dim; c += 64) {
+        const float x = v[c];
+        ss += x * x;
+        dot += dW[c] * x;
+    }
+    ss = mp::wsum(ss);
+    dot = mp::wsum(dot);
+    const float nrm = sqrtf(ss), gg = D.g[r];
+    for (int c = lane; c < in_dim; c += 64) dv[c] = (gg / nrm) * (dW[c] - dot / ss * v[c]);
+    if (lane == 0) grad_base[D.dg_off + r] = dot / nrm;
 }
 
 // hoisted conditioning: b2[r] = b[r] + sum_c W[r][c0+c] vec[c]   /  dW[r][c0+c] += db2[r] vec[c]
@@ -999,6 +1051,16 @@ int mp_tr_wn_fwd(const float* v, const float* g, int out_dim, int in_dim, float*
 int mp_tr_wn_bwd(const float* v, const float* g, int out_dim, int in_dim, const float* dW, float* dv, float* dg,
                  void* stream) {
     hipLaunchKernelGGL(k_wn_bwd, dim3(out_dim), dim3(64), 0, ST, v, g, out_dim, in_dim, dW, dv, dg);
+    return (int)hipGetLastError();
+}
+int mp_tr_wn_fwd_multi(const MpWnDesc* descs, int n_desc, int total_rows, void* stream) {
+    if (n_desc <= 0 || total_rows <= 0) return 0;
+    hipLaunchKernelGGL(k_wn_fwd_multi, dim3(total_rows), dim3(64), 0, ST, descs, n_desc);
+    return (int)hipGetLastError();
+}
+int mp_tr_wn_bwd_multi(const MpWnDesc* descs, int n_desc, int total_rows, const float* acc_base, float* grad_base, void* stream) {
+    if (n_desc <= 0 || total_rows <= 0) return 0;
+    hipLaunchKernelGGL(k_wn_bwd_multi, dim3(total_rows), dim3(64), 0, ST, descs, n_desc, acc_base, grad_base);
     return (int)hipGetLastError();
 }
 int mp_tr_hoist_fwd(const float* W, int out_dim, int in_dim, const float* b, int c0, int n, const float* vec, float* b2,

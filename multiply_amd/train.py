@@ -101,7 +101,7 @@ class LinW:
 class ImplicitTrain:
     """ImplicitNet (networks.py:126-208) evaluated layer by layer for P points, optionally in forward mode."""
 
-    def __init__(self, net, x, cond_vec, fwd):
+    def __init__(self, net, x, cond_vec, fwd, lins=None):
         L = hip.lib()
         self.net, self.fwd, self.x = net, fwd, x
         dev = x.device
@@ -109,7 +109,7 @@ class ImplicitTrain:
         self.rows = rows = 4 * P if fwd else P
         self.E = E = net.embed_dim
         self.cond = cond_vec
-        self.lins = [LinW(l) for l in net.layers()]
+        self.lins = lins if lins is not None else [LinW(l) for l in net.layers()]
         nl = len(self.lins)
         self.IN = torch.empty(rows, E, dtype=F32, device=dev)
         _chk(L.mp_tr_pe(_p(x), net.d_in, P, net.multires, int(fwd), C.c_float(1.0), _p(self.IN), E, 0, hip.stream()),
@@ -201,7 +201,7 @@ class ImplicitTrainRev:
     rows, where the forward-mode class above spends 3 GEMMs over 4P rows.  Same results, same parameter gradients.
     self.out [P][257] = last layer, self.grad [P][3] = d sdf / d x."""
 
-    def __init__(self, net, x, cond_vec):
+    def __init__(self, net, x, cond_vec, lins=None):
         L = hip.lib()
         st = hip.stream()
         self.net, self.x, self.cond = net, x, cond_vec
@@ -209,7 +209,7 @@ class ImplicitTrainRev:
         self.P = P = x.shape[0]
         self.E = E = net.embed_dim
         assert net.d_in == 3 and len(net.skip_in) == 1
-        self.lins = lins = [LinW(l) for l in net.layers()]
+        self.lins = lins = lins if lins is not None else [LinW(l) for l in net.layers()]
         self.nl = nl = len(lins)
         r2 = 1.0 / math.sqrt(2.0)
         f32 = dict(dtype=F32, device=dev)
@@ -345,36 +345,160 @@ class ImplicitTrainRev:
         return [g for lw in self.lins for g in lw.param_grads()]
 
 
-class LinP(LinW):
-    """LinW with PERSISTENT device buffers (effective weights, gradient accumulators): the fused kernels' pointer tables are built
-    once per network instead of once per iteration.  refresh() re-resolves the weight norm and zeroes the accumulators."""
+class MpWnDesc(C.Structure):
+    _fields_ = [("v", C.c_void_p), ("g", C.c_void_p), ("W", C.c_void_p), ("WT", C.c_void_p), ("dW_off", C.c_longlong),
+                ("dv_off", C.c_longlong), ("dg_off", C.c_longlong), ("out_dim", C.c_int), ("in_dim", C.c_int), ("row0", C.c_int),
+                ("pad_", C.c_int)]
 
-    def __init__(self, lin):
+
+class LinP(LinW):
+    """LinW with PERSISTENT effective weights (W, optionally the transpose WT) and, under a TrainState, gradient accumulators /
+    parameter gradients that are views of the iteration's two flat buffers (one fill, one batched weight-norm launch per group
+    instead of two launches per layer).  Standalone (no TrainState): refresh() resolves the weight norm and zeroes its own
+    accumulators, param_grads() runs the per-layer adjoint like LinW."""
+
+    def __init__(self, lin, pad_rows=0, need_wt=False, standalone=True):
+        """pad_rows: gradient accumulators of max(out_dim, pad_rows) rows (a 217-row layer contracted as 256 rows takes the
+        aligned path of mp_gemm_tn; the extra rows receive exact zeros and are never read)"""
         self.lin = lin
         self.wn = hasattr(lin, "weight_g")
         v = lin.weight_v if self.wn else lin.weight
         self.out_dim, self.in_dim = v.shape
         dev = v.device
         self.W = torch.empty(self.out_dim, self.in_dim, dtype=F32, device=dev)
-        self.WT = None
-        self.dW = torch.zeros(self.out_dim, self.in_dim, dtype=F32, device=dev)
-        self.db = torch.zeros(self.out_dim, dtype=F32, device=dev)
-        self.refresh()
+        self.WT = torch.empty(self.in_dim, self.out_dim, dtype=F32, device=dev) if need_wt else None
+        self.rows = max(self.out_dim, pad_rows)
+        self.standalone = standalone
+        self._g = None
+        self.read_params()
+        if standalone:
+            self.dW_full = torch.zeros(self.rows, self.in_dim, dtype=F32, device=dev)
+            self.db_full = torch.zeros(self.rows, dtype=F32, device=dev)
+            self.dW, self.db = self.dW_full[:self.out_dim], self.db_full[:self.out_dim]
+            self.refresh()
 
-    def refresh(self):
+    def read_params(self):
         lin = self.lin
         self.v = (lin.weight_v if self.wn else lin.weight).detach().contiguous()
         self.g = lin.weight_g.detach().reshape(-1).contiguous() if self.wn else None
         self.b = lin.bias.detach().contiguous()
-        _chk(hip.lib().mp_tr_wn_fwd(_p(self.v), _p(self.g), self.out_dim, self.in_dim, _p(self.W), None, hip.stream()),
+
+    def refresh(self):
+        self.read_params()
+        _chk(hip.lib().mp_tr_wn_fwd(_p(self.v), _p(self.g), self.out_dim, self.in_dim, _p(self.W), _p(self.WT), hip.stream()),
              "mp_tr_wn_fwd")
-        self.dW.zero_()
-        self.db.zero_()
+        self.dW_full.zero_()
+        self.db_full.zero_()
+
+    def bind(self, acc, o_dW, o_db, gbuf, o_dv, o_dg):
+        """this iteration's accumulators / gradients: views of the flat buffers (TrainState.begin)"""
+        n = self.rows * self.in_dim
+        self.dW_full = acc[o_dW:o_dW + n].view(self.rows, self.in_dim)
+        self.db_full = acc[o_db:o_db + self.rows]
+        self.dW, self.db = self.dW_full[:self.out_dim], self.db_full[:self.out_dim]
+        self._g = (gbuf, o_dv, o_dg)
 
     def param_grads(self):
-        gs = super().param_grads()
-        gs[-1] = self.db.clone()          # the accumulator itself lives on: never hand it to autograd
-        return gs
+        if self.standalone:
+            gs = super().param_grads()
+            gs[-1] = self.db.clone()          # the accumulator itself lives on: never hand it to autograd
+            return gs
+        # TrainState.finish_group ran the batched adjoint.  FRESH view objects on purpose: autograd's AccumulateGrad takes a
+        # gradient over without a copy only if nothing else references the tensor object (a view kept here would make it
+        # clone all ~110 gradients of an iteration)
+        gbuf, o_dv, o_dg = self._g
+        db = self.db_full[:self.out_dim]
+        if not self.wn:
+            return [self.dW_full[:self.out_dim], db]
+        dv = gbuf[o_dv:o_dv + self.out_dim * self.in_dim].view(self.out_dim, self.in_dim)
+        return [gbuf[o_dg:o_dg + self.out_dim].view(self.out_dim, 1), dv, db]
+
+
+class TrainState:
+    """Per-model state of the training path, shared by every network of an iteration: persistent effective weights, ONE batched
+    weight-norm launch per group (a person's two networks; the background's two) in the forward and one in the backward, and two
+    flat per-iteration buffers -- gradient accumulators (one fill) and parameter gradients -- of which every layer's tensors are
+    views.  Replaces ~80 weight-norm launches, ~80 fills and ~40 allocations per iteration."""
+
+    def __init__(self, model):
+        m = self.model = model
+        self.groups = []                      # (key, [nets])
+        for p in range(len(m.foreground_implicit_network_list)):
+            self.groups.append((p, [m.foreground_implicit_network_list[p], m.foreground_rendering_network_list[p]]))
+        self.groups.append(("bg", [m.bg_implicit_network, m.bg_rendering_network]))
+        self.lins = {}
+        self.acc_size = self.grad_size = 0
+        self.layout = {}                      # id(LinP) -> offsets
+        self.tables = {}
+        for key, nets in self.groups:
+            for net in nets:
+                fused = isinstance(net, _implicit_net_type()) and fused_sdf_supported(net)
+                ls = []
+                for i, lin in enumerate(net.layers()):
+                    lp = LinP(lin, pad_rows=256 if (fused and i == 3) else 0, need_wt=True, standalone=False)
+                    o_dW = self.acc_size; self.acc_size += (lp.rows * lp.in_dim + 3) // 4 * 4
+                    o_db = self.acc_size; self.acc_size += (lp.rows + 3) // 4 * 4
+                    o_dv = self.grad_size; self.grad_size += (lp.out_dim * lp.in_dim + 3) // 4 * 4
+                    o_dg = self.grad_size; self.grad_size += (lp.out_dim + 3) // 4 * 4 if lp.wn else 0
+                    self.layout[id(lp)] = (o_dW, o_db, o_dv, o_dg)
+                    ls.append(lp)
+                self.lins[id(net)] = ls
+        self.dev = next(iter(self.lins.values()))[0].W.device
+        self._key = None
+
+    def _build_tables(self):
+        for key, nets in self.groups:
+            lps = [lp for net in nets for lp in self.lins[id(net)]]
+            arr = (MpWnDesc * len(lps))()
+            row = 0
+            for i, lp in enumerate(lps):
+                o_dW, o_db, o_dv, o_dg = self.layout[id(lp)]
+                arr[i] = MpWnDesc(lp.v.data_ptr(), lp.g.data_ptr() if lp.wn else None, lp.W.data_ptr(),
+                                  lp.WT.data_ptr() if lp.WT is not None else None, o_dW, o_dv, o_dg, lp.out_dim, lp.in_dim, row, 0)
+                row += lp.out_dim
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            self.tables[key] = (host.to(self.dev), len(lps), row, lps)
+
+    def begin(self, keys=None):
+        """start of an iteration: effective weights of the groups in `keys` (default: all), fresh accumulators"""
+        L, st = hip.lib(), hip.stream()
+        ptrs = []
+        for ls in self.lins.values():
+            for lp in ls:
+                lp.read_params()
+                ptrs.append(lp.v.data_ptr())
+                ptrs.append(lp.g.data_ptr() if lp.wn else 0)
+        key = tuple(ptrs)
+        if key != self._key:
+            self._key = key
+            self._build_tables()
+        for k, _ in self.groups:
+            if keys is None or k in keys:
+                tab, n, rows, _ = self.tables[k]
+                _chk(L.mp_tr_wn_fwd_multi(_p(tab), n, rows, st), "mp_tr_wn_fwd_multi")
+        self.acc = torch.zeros(self.acc_size, dtype=F32, device=self.dev)
+        self.gbuf = torch.empty(self.grad_size, dtype=F32, device=self.dev)
+        for ls in self.lins.values():
+            for lp in ls:
+                lp.bind(self.acc, *self.layout[id(lp)][:2], self.gbuf, *self.layout[id(lp)][2:])
+        return self
+
+    def finish_group(self, key):
+        """the weight-norm adjoint of one group's layers: accumulators -> parameter gradients (views of the flat buffer)"""
+        tab, n, rows, lps = self.tables[key]
+        _chk(hip.lib().mp_tr_wn_bwd_multi(_p(tab), n, rows, _p(self.acc), _p(self.gbuf), hip.stream()), "mp_tr_wn_bwd_multi")
+
+
+def _implicit_net_type():
+    from .networks import ImplicitNet
+    return ImplicitNet
+
+
+def train_state(model):
+    st = model.__dict__.get("_mp_train_state")
+    if st is None:
+        st = model.__dict__["_mp_train_state"] = TrainState(model)
+    return st
 
 
 def fused_sdf_supported(net):
@@ -387,9 +511,12 @@ class FusedSDFState:
     """Per-network device state of the layer-fused training kernels (csrc/tfuse.hip): persistent effective weights, the split-bf16
     chunk stream, the bias table and the pointer tables mp_tf_sdf_pack reads."""
 
-    def __init__(self, net):
+    def __init__(self, net, lins=None):
+        """lins: the network's LinP list of a TrainState (weights resolved and accumulators bound by TrainState.begin); None:
+        standalone layers owned by this object (unit tests, tools)"""
         self.net = net
-        self.lins = [LinP(l) for l in net.layers()]
+        self.shared = lins is not None
+        self.lins = lins if self.shared else [LinP(l, pad_rows=256 if i == 3 else 0) for i, l in enumerate(net.layers())]
         dev = self.lins[0].W.device
         arena, pack = C.c_longlong(0), C.c_longlong(0)
         _chk(hip.lib().mp_tf_sdf_sizes(1, C.byref(arena), C.byref(pack)), "mp_tf_sdf_sizes")
@@ -403,8 +530,9 @@ class FusedSDFState:
     def refresh(self, cond_vec):
         L, st = hip.lib(), hip.stream()
         net, lins = self.net, self.lins
-        for lw in lins:
-            lw.refresh()
+        if not self.shared:
+            for lw in lins:
+                lw.refresh()
         lw0 = lins[0]
         _chk(L.mp_tr_hoist_fwd(_p(lw0.W), 256, lw0.in_dim, _p(lw0.b), net.embed_dim, net.cond_dim, _p(cond_vec), _p(self.b0), st),
              "mp_tr_hoist_fwd")
@@ -416,10 +544,11 @@ class FusedSDFState:
         return self
 
 
-def fused_sdf_state(net):
-    st = net.__dict__.get("_mp_tfuse")
-    if st is None:
-        st = net.__dict__["_mp_tfuse"] = FusedSDFState(net)
+def fused_sdf_state(net, lins=None):
+    key = "_mp_tfuse_shared" if lins is not None else "_mp_tfuse"
+    st = net.__dict__.get(key)
+    if st is None or (lins is not None and st.lins is not lins):
+        st = net.__dict__[key] = FusedSDFState(net, lins)
     return st
 
 
@@ -430,14 +559,14 @@ class ImplicitTrainFused(ImplicitTrainRev):
     Same interface: self.out [P][257], self.grad [P][3], backward(dZ_last, dgrad) -> d cond.  The adjoint of the input points
     (pose optimisation) is not produced here: TrainGraph takes ImplicitTrainRev when it is needed."""
 
-    def __init__(self, net, x, cond_vec):
+    def __init__(self, net, x, cond_vec, lins=None):
         L, st = hip.lib(), hip.stream()
         assert fused_sdf_supported(net)
         self.net, self.x, self.cond = net, x, cond_vec
         self.P = P = x.shape[0]
         self.E = E = net.embed_dim
         dev = x.device
-        self.fs = fs = fused_sdf_state(net).refresh(cond_vec)
+        self.fs = fs = fused_sdf_state(net, lins).refresh(cond_vec)
         self.lins, self.nl = fs.lins, len(fs.lins)
         self.arena = torch.empty(fs.arena_per_point * P, dtype=F32, device=dev)
         PL = 256 * P
@@ -447,37 +576,43 @@ class ImplicitTrainFused(ImplicitTrainRev):
         self.o_G = 47 * PL + 2 * E * P
         r2 = 1.0 / math.sqrt(2.0)
         _chk(L.mp_tr_pe(_p(x), 3, P, net.multires, 0, C.c_float(1.0), off(self.arena, self.o_BB0), E, 0, st), "mp_tr_pe")
-        self.out = torch.empty(P, 257, dtype=F32, device=dev)
+        self.feat = torch.empty(P, 256, dtype=F32, device=dev)      # columns 1.. of the reference's output
+        self.sdf = torch.empty(P, dtype=F32, device=dev)            # column 0
         self.w8 = fs.lins[8].W                          # row 0 = the sdf row of the last layer
-        _chk(L.mp_tf_sdf_fwd(_p(fs.wpack), _p(fs.bias_all), _p(self.w8), _p(self.arena), P, _p(self.out), st), "mp_tf_sdf_fwd")
+        _chk(L.mp_tf_sdf_fwd(_p(fs.wpack), _p(fs.bias_all), _p(self.w8), _p(self.arena), P, _p(self.feat), _p(self.sdf), st),
+             "mp_tf_sdf_fwd")
         # the skip connection re-injects the Fourier features into layer 4's input (times 1/sqrt 2): columns 217.. of X_4
         _chk(L.mp_tr_copy_cols(off(self.arena, self.o_BB0), E, 0, off(self.arena, self.o_BB(4)), 256, 256 - E, P, E, C.c_float(r2), 0,
                                st), "mp_tr_copy_cols")
         self.grad = torch.empty(P, 3, dtype=F32, device=dev)
         _chk(L.mp_tr_pe_grad_fwd(_p(x), P, net.multires, off(self.arena, self.o_G), E, _p(self.grad), st), "mp_tr_pe_grad_fwd")
 
-    def backward(self, dZ_last, dgrad, want_dx=False):
+    @property
+    def out(self):
+        """the reference's [P][257] layout (column 0 = sdf), assembled on demand (tests; the trainer reads feat / sdf)"""
+        return torch.cat([self.sdf[:, None], self.feat], 1)
+
+    def backward(self, dfeat, dsdf, dgrad, want_dx=False):
+        """dfeat [P][256], dsdf [P], dgrad [P][3] -> dW / db of every layer; returns d cond"""
         assert not want_dx, "the fused SDF kernels do not produce the adjoint of the input points"
         L, st = hip.lib(), hip.stream()
         net, P, E, lins, fs, A = self.net, self.P, self.E, self.lins, self.fs, self.arena
-        dev = dZ_last.device
+        dev = dfeat.device
         r2 = 1.0 / math.sqrt(2.0)
         PL = 256 * P
         dG = off(A, self.o_BB0 + E * P)
         _chk(L.mp_tr_pe_grad_bwd(_p(self.x), P, net.multires, _p(dgrad), off(A, self.o_G), E, dG, E, None, st), "mp_tr_pe_grad_bwd")
-        dw8 = torch.zeros(256, dtype=F32, device=dev)
-        _chk(L.mp_tf_sdf_bwd(_p(fs.wpack), _p(self.w8), _p(A), P, _p(dZ_last), _p(dw8), st), "mp_tf_sdf_bwd")
+        lw8 = lins[8]                                   # the sdf row's gradient goes straight into row 0 of dW_8 / db_8
+        _chk(L.mp_tf_sdf_bwd(_p(fs.wpack), _p(self.w8), _p(A), P, _p(dfeat), _p(dsdf), _p(lw8.dW), _p(lw8.db), st), "mp_tf_sdf_bwd")
         _chk(L.mp_tr_copy_cols(dG, E, 0, off(A, self.o_BB(4) + PL), 256, 256 - E, P, E, C.c_float(r2), 0, st), "mp_tr_copy_cols")
         # weight gradients: both sweeps' contributions of a layer in ONE contraction over 2 P rows (bias gradient: the first P)
         lw0 = lins[0]
         gemm_tn(off(A, self.o_AB(0)), 256, off(A, self.o_BB0), E, _p(lw0.dW), lw0.in_dim, 256, E, 2 * P, _p(lw0.db), P)
         for l in range(1, 8):
-            lw = lins[l]
-            gemm_tn(off(A, self.o_AB(l)), 256, off(A, self.o_BB(l)), 256, _p(lw.dW), lw.in_dim, lw.out_dim, lw.in_dim, 2 * P,
-                    _p(lw.db), P)
-        lw8 = lins[8]
-        gemm_tn(_p(dZ_last), 257, off(A, self.o_BB(8)), 256, _p(lw8.dW), 256, 257, 256, P, _p(lw8.db), P)
-        lw8.dW[0] += dw8
+            lw = lins[l]                                # (layer 3: 217 rows contracted as 256, see LinP)
+            gemm_tn(off(A, self.o_AB(l)), 256, off(A, self.o_BB(l)), 256, _p(lw.dW_full), lw.in_dim, lw.dW_full.shape[0], lw.in_dim,
+                    2 * P, _p(lw.db_full), P)
+        gemm_tn(_p(dfeat), 256, off(A, self.o_BB(8)), 256, off(lw8.dW, 256), 256, 256, 256, P, off(lw8.db, 1), P)   # feature rows
         _chk(L.mp_tr_hoist_bwd(_p(lw0.db), 256, lw0.in_dim, E, net.cond_dim, _p(self.cond), _p(lw0.dW), st), "mp_tr_hoist_bwd")
         dcond = torch.zeros(net.cond_dim, dtype=F32, device=dev)
         gemm_tn(_p(lw0.db), 1, off(lw0.W, E), lw0.in_dim, _p(dcond), net.cond_dim, 1, net.cond_dim, 256)
@@ -489,11 +624,11 @@ class RenderTrain:
     """RenderingNet (networks.py:263-312): mode 'pose_no_view' (inputs XA = [x_c, n] (6), feat) or 'nerf_frame_encoding'
     (XA = PE_4(view) (27), feat).  feat is read in place from the SDF net's last layer (ld 257, column 1..)."""
 
-    def __init__(self, net, XA, feat_ptr, feat_ld, n, cond_vec):
+    def __init__(self, net, XA, feat_ptr, feat_ld, n, cond_vec, lins=None):
         L = hip.lib()
         self.net, self.n = net, n
         dev = XA.device
-        self.lins = [LinW(l) for l in net.layers()]
+        self.lins = lins if lins is not None else [LinW(l) for l in net.layers()]
         self.pose_mode = net.mode == "pose_no_view"
         self.na = XA.shape[1]                                # 6 or 27
         self.c_h0, self.n_h = (6, 8) if self.pose_mode else (27, 32)   # hoisted columns
@@ -530,8 +665,9 @@ class RenderTrain:
         self.rgb = torch.empty(n, 3, dtype=F32, device=dev)
         _chk(L.mp_tr_sigmoid_fwd(_p(self.H[-1]), n * 3, _p(self.rgb), hip.stream()), "mp_tr_sigmoid_fwd")
 
-    def backward(self, drgb, dXA, dfeat_ptr, dfeat_ld):
-        """drgb [n][3] -> dW/db, dXA [n][na] (written), d feat (+= into dfeat_ptr); returns d hoisted-vector"""
+    def backward(self, drgb, dXA, dfeat_ptr, dfeat_ld, feat_accumulate=True):
+        """drgb [n][3] -> dW/db, dXA [n][na] (written), d feat (+= into dfeat_ptr, or written with feat_accumulate=False);
+        returns d hoisted-vector"""
         L = hip.lib()
         n, dev = self.n, drgb.device
         nl = len(self.lins)
@@ -556,7 +692,7 @@ class RenderTrain:
         gemm_tn(_p(lw0.db), 1, off(lw0.W, self.c_h0), lw0.in_dim, _p(dh), self.n_h, 1, self.n_h, o0)
         # data gradients
         gemm_nt(_p(dZ), o0, _p(lw0.WT), o0, _p(dXA), self.na, n, self.na, o0)
-        gemm_nt(_p(dZ), o0, off(lw0.WT, self.c_feat * o0), o0, dfeat_ptr, dfeat_ld, n, 256, o0, None, 0, accumulate=True)
+        gemm_nt(_p(dZ), o0, off(lw0.WT, self.c_feat * o0), o0, dfeat_ptr, dfeat_ld, n, 256, o0, None, 0, accumulate=feat_accumulate)
         self.extra_grads = []
         if self.pose_mode:
             dlp_w = torch.zeros(8, 69, dtype=F32, device=dev)
@@ -567,6 +703,109 @@ class RenderTrain:
     def params(self):
         ps = [self.net.lin_pose.weight, self.net.lin_pose.bias] if self.pose_mode else []
         return ps + [p for lw in self.lins for p in lw.params()]
+
+    def param_grads(self):
+        return list(self.extra_grads) + [g for lw in self.lins for g in lw.param_grads()]
+
+
+def fused_col_supported(net):
+    """the RenderingNet shape the fused colour kernels of csrc/tfuse.hip are specialised for (the shipped foreground net)"""
+    return net.mode == "pose_no_view" and list(net.dims) == [270, 256, 256, 256, 256, 3]
+
+
+class FusedColState:
+    """chunk stream, bias table and pointer tables of the fused colour kernels for one RenderingNet (its LinP layers shared with
+    the TrainState, or its own)"""
+
+    def __init__(self, net, lins=None):
+        self.net = net
+        self.shared = lins is not None
+        self.lins = lins if self.shared else [LinP(l) for l in net.layers()]
+        dev = self.lins[0].W.device
+        stash, pack = C.c_longlong(0), C.c_longlong(0)
+        _chk(hip.lib().mp_tf_col_sizes(1, C.byref(stash), C.byref(pack)), "mp_tf_col_sizes")
+        self.stash_per_point = int(stash.value)
+        self.wpack = torch.empty(int(pack.value), dtype=torch.uint8, device=dev)
+        self.bias_all = torch.empty(5 * 288, dtype=F32, device=dev)
+        self.b0 = torch.empty(256, dtype=F32, device=dev)
+        self.pose8 = torch.empty(8, dtype=F32, device=dev)
+        self.wtab = _table([lw.W for lw in self.lins], dev)
+        self._btab_key, self.btab = None, None
+
+    def refresh(self, cond_vec):
+        L, st = hip.lib(), hip.stream()
+        net, lins = self.net, self.lins
+        if not self.shared:
+            for lw in lins:
+                lw.refresh()
+        lp = net.lin_pose
+        self.lp_w, self.lp_b = lp.weight.detach().contiguous(), lp.bias.detach().contiguous()
+        _chk(L.mp_tr_hoist_fwd(_p(self.lp_w), 8, 69, _p(self.lp_b), 0, 69, _p(cond_vec), _p(self.pose8), st), "mp_tr_hoist_fwd")
+        lw0 = lins[0]
+        _chk(L.mp_tr_hoist_fwd(_p(lw0.W), 256, lw0.in_dim, _p(lw0.b), 6, 8, _p(self.pose8), _p(self.b0), st), "mp_tr_hoist_fwd")
+        bs = [self.b0] + [lw.b for lw in lins[1:]]
+        key = tuple(b.data_ptr() for b in bs)
+        if key != self._btab_key:
+            self._btab_key, self.btab = key, _table(bs, self.b0.device)
+        _chk(L.mp_tf_col_pack(_p(self.wtab), _p(self.btab), _p(self.wpack), _p(self.bias_all), st), "mp_tf_col_pack")
+        return self
+
+
+def fused_col_state(net, lins=None):
+    key = "_mp_tfuse_shared" if lins is not None else "_mp_tfuse"
+    st = net.__dict__.get(key)
+    if st is None or (lins is not None and st.lins is not lins):
+        st = net.__dict__[key] = FusedColState(net, lins)
+    return st
+
+
+class RenderTrainFused:
+    """RenderTrain's arithmetic for the foreground colour net on the layer-fused kernels (csrc/tfuse.hip: mp_tf_col_fwd /
+    mp_tf_col_bwd): the five layers in one launch each way, the weight gradients as one contraction per layer.  feat [>= n][256]
+    (row stride 256: the fused SDF net's feature rows), XA [n][6]."""
+
+    def __init__(self, net, XA, feat, n, cond_vec, lins=None):
+        L, st = hip.lib(), hip.stream()
+        assert fused_col_supported(net) and feat.shape[1] == 256 and feat.is_contiguous()
+        self.net, self.n, self.XA, self.feat, self.cond = net, n, XA, feat, cond_vec
+        dev = XA.device
+        self.cs = cs = fused_col_state(net, lins).refresh(cond_vec)
+        self.lins = cs.lins
+        self.stash = torch.empty(cs.stash_per_point * n, dtype=F32, device=dev)
+        self.rgb = torch.empty(n, 3, dtype=F32, device=dev)
+        _chk(L.mp_tf_col_fwd(_p(cs.wpack), _p(cs.bias_all), _p(self.stash), _p(feat), _p(XA), n, _p(self.rgb), st), "mp_tf_col_fwd")
+
+    def backward(self, drgb, dXA, dfeat):
+        """drgb [n][3] -> dW / db, dXA [n][6] and rows [0, n) of dfeat [.][256] (both written); returns d pose-embedding"""
+        L, st = hip.lib(), hip.stream()
+        n, lins, cs, S = self.n, self.lins, self.cs, self.stash
+        dev = drgb.device
+        NL = 256 * n
+        dz4 = torch.empty(n, 3, dtype=F32, device=dev)
+        _chk(L.mp_tf_col_bwd(_p(cs.wpack), _p(S), _p(lins[4].W), _p(self.rgb), _p(drgb), n, _p(dfeat), _p(dXA), _p(dz4), st),
+             "mp_tf_col_bwd")
+        H = lambda l: off(S, l * NL)
+        dZ = lambda l: off(S, (4 + l) * NL)
+        lw0 = lins[0]
+        gemm_tn(dZ(0), 256, _p(self.XA), 6, _p(lw0.dW), lw0.in_dim, 256, 6, n, _p(lw0.db), n)
+        gemm_tn(dZ(0), 256, _p(self.feat), 256, off(lw0.dW, 14), lw0.in_dim, 256, 256, n)
+        for l in range(1, 4):
+            lw = lins[l]
+            gemm_tn(dZ(l), 256, H(l - 1), 256, _p(lw.dW), 256, 256, 256, n, _p(lw.db), n)
+        lw4 = lins[4]
+        gemm_tn(_p(dz4), 3, H(3), 256, _p(lw4.dW), 256, 3, 256, n, _p(lw4.db), n)
+        # the hoisted pose embedding: dW_0[:, 6:14] += db_0 (x) pose8 ; d pose8 = W_0[:, 6:14]^T db_0 ; then lin_pose's own gradients
+        _chk(L.mp_tr_hoist_bwd(_p(lw0.db), 256, lw0.in_dim, 6, 8, _p(cs.pose8), _p(lw0.dW), st), "mp_tr_hoist_bwd")
+        dh = torch.zeros(8, dtype=F32, device=dev)
+        gemm_tn(_p(lw0.db), 1, off(lw0.W, 6), lw0.in_dim, _p(dh), 8, 1, 8, 256)
+        dlp_w = torch.zeros(8, 69, dtype=F32, device=dev)
+        _chk(L.mp_tr_hoist_bwd(_p(dh), 8, 69, 0, 69, _p(self.cond), _p(dlp_w), st), "mp_tr_hoist_bwd")
+        self.extra_grads = [dlp_w, dh]
+        self.lp_w = cs.lp_w
+        return dh
+
+    def params(self):
+        return [self.net.lin_pose.weight, self.net.lin_pose.bias] + [p for lw in self.lins for p in lw.params()]
 
     def param_grads(self):
         return list(self.extra_grads) + [g for lw in self.lins for g in lw.param_grads()]
@@ -608,12 +847,13 @@ def make_draws(model, cx, gen=None):
 class TrainGraph:
     """Everything one training forward keeps for its backward."""
 
-    def __init__(self, model, cx, input, cond_zero, draws, surface_flags=False, pose_grad=False, shard=None):
+    def __init__(self, model, cx, input, cond_zero, draws, surface_flags=False, pose_grad=False, shard=None, ts=None):
         """shard = (world, rank): person-sharded training: cx holds only this rank's persons
         {p : p % world == rank}; their per-sample rows are all-gathered once in the forward, every rank composites all rays
         (512 of them: cheaper than a second exchange in the backward), the background branch is ray-sliced."""
         self.model, self.cx, self.input, self.cond_zero, self.draws = model, cx, input, cond_zero, draws
         self.surface_flags, self.pose_grad, self.shard = surface_flags, pose_grad, shard
+        self.ts = ts if ts is not None else train_state(model).begin()     # shared layers: weights resolved, accumulators zeroed
 
     # ---- forward ------------------------------------------------------------------------------------------------
     def run(self):
@@ -670,17 +910,25 @@ class TrainGraph:
             if mode == "fused" and (self.pose_grad or TRAIN_PRECISION != "bf16x3" or not fused_sdf_supported(imp)):
                 mode = "reverse"      # the fused kernels: split-bf16 arithmetic, the shipped network shape, no d x_c
             rev = mode != "forward"
+            li, lr = self.ts.lins[id(imp)], self.ts.lins[id(ren)]
             if mode == "fused":
-                it = ImplicitTrainFused(imp, X, pp["cond"])
+                it = ImplicitTrainFused(imp, X, pp["cond"], lins=li)
             else:
-                it = ImplicitTrainRev(imp, X, pp["cond"]) if rev else ImplicitTrain(imp, X, pp["cond"], fwd=True)
+                it = ImplicitTrainRev(imp, X, pp["cond"], lins=li) if rev else ImplicitTrain(imp, X, pp["cond"], fwd=True, lins=li)
             gptr = _p(it.grad) if rev else None
-            XA = torch.empty(npts, 6, **f32); nrm = torch.empty(npts, 3, **f32); sdf = torch.empty(npts, **f32)
-            _chk(L.mp_tr_shade_in_fwd(_p(it.out), Pt, npts, _p(X), _p(jinv), _p(XA), _p(nrm), _p(sdf), gptr, st),
+            fusedp = mode == "fused"     # the fused kernels hand the last layer over as feat [Pt][256] + sdf [Pt], not [Pt][257]
+            XA = torch.empty(npts, 6, **f32); nrm = torch.empty(npts, 3, **f32)
+            sdf = it.sdf[:npts] if fusedp else torch.empty(npts, **f32)
+            z8 = None if fusedp else _p(it.out)
+            _chk(L.mp_tr_shade_in_fwd(z8, Pt, npts, _p(X), _p(jinv), _p(XA), _p(nrm), None if fusedp else _p(sdf), gptr, st),
                  "mp_tr_shade_in_fwd")
             gth = torch.empty(E, 3, **f32)
-            _chk(L.mp_tr_eik_fwd(_p(it.out), Pt, npts, E, _p(gth), gptr, st), "mp_tr_eik_fwd")
-            rt = RenderTrain(ren, XA, off(it.out, 1), 257, npts, pp["cond"])
+            _chk(L.mp_tr_eik_fwd(z8, Pt, npts, E, _p(gth), gptr, st), "mp_tr_eik_fwd")
+            if fusedp and fused_col_supported(ren):
+                rt = RenderTrainFused(ren, XA, it.feat, npts, pp["cond"], lins=lr)
+            else:
+                rt = RenderTrain(ren, XA, _p(it.feat), 256, npts, pp["cond"], lins=lr) if fusedp else \
+                    RenderTrain(ren, XA, off(it.out, 1), 257, npts, pp["cond"], lins=lr)
             self.fg[p] = dict(it=it, rt=rt, X=X, jinv=jinv, XA=XA, sdf=sdf, nrm=nrm, gth=gth, zfinal=zfinal, iters=iters,
                               wcount=wcount, npts=npts, Pt=Pt, Rp=Rp, flags=flags, nn_posed=nn_posed,
                               nn_cano=nn_cano)
@@ -761,11 +1009,12 @@ class TrainGraph:
                 cam = pose.reshape(4, 4)[:3, 3].contiguous()
                 _chk(L.mp_tr_bg_points(_p(bdirs), _p(cam), _p(zbg), Rb, NB, C.c_float(m.sdf_bounding_sphere), _p(pts), st),
                      "mp_tr_bg_points")
-                bit = ImplicitTrain(m.bg_implicit_network, pts, code, fwd=False)
+                bit = ImplicitTrain(m.bg_implicit_network, pts, code, fwd=False, lins=self.ts.lins[id(m.bg_implicit_network)])
                 drep = bdirs[:, None, :].expand(Rb, NB, 3).reshape(-1, 3).contiguous()
                 XAb = torch.empty(Rb * NB, 27, **f32)
                 _chk(L.mp_tr_pe(_p(drep), 3, Rb * NB, 4, 0, C.c_float(1.0), _p(XAb), 27, 0, st), "mp_tr_pe")
-                brt = RenderTrain(m.bg_rendering_network, XAb, off(bit.out, 1), 257, Rb * NB, code)
+                brt = RenderTrain(m.bg_rendering_network, XAb, off(bit.out, 1), 257, Rb * NB, code,
+                                  lins=self.ts.lins[id(m.bg_rendering_network)])
                 sdfb = torch.empty(Rb * NB, **f32)
                 _chk(L.mp_tr_copy_cols(_p(bit.out), 257, 0, _p(sdfb), 1, 0, Rb * NB, 1, C.c_float(1.0), 0, st),
                      "mp_tr_copy_cols")
@@ -812,7 +1061,9 @@ class TrainGraph:
         zero = lambda t, shape: torch.zeros(shape, **f32) if t is None else t.contiguous().float()
         d_rgb_values = zero(d_rgb_values, (R, 3)); d_acc_map = zero(d_acc_map, (R,)); d_acc_person = zero(d_acc_person, (R, P))
         # remote persons (person-sharded mode) get scratch rows: their owners compute the same compositing adjoint
-        dsdf_l = [torch.zeros(self.fg[p]["npts"] if p in self.fg else R * S, **f32) for p in all_persons]
+        # (a fused person's d sdf vector also covers its eikonal points, which no compositing term reaches: zeros)
+        dsdf_l = [torch.zeros((self.fg[p]["Pt"] if isinstance(self.fg[p]["it"], ImplicitTrainFused) else self.fg[p]["npts"])
+                              if p in self.fg else R * S, **f32) for p in all_persons]
         drgb_l = [torch.zeros(self.fg[p]["npts"] if p in self.fg else R * S, 3, **f32) for p in all_persons]
         d_bg_rgb = torch.zeros(R, 3, **f32)
         d_beta = torch.zeros(1, **f32)
@@ -840,17 +1091,31 @@ class TrainGraph:
             f = self.fg[p]
             it, rt, npts, Pt = f["it"], f["rt"], f["npts"], f["Pt"]
             rev = isinstance(it, ImplicitTrainRev)
-            dZ8 = torch.zeros(Pt if rev else 4 * Pt, 257, **f32)
+            fusedp = isinstance(it, ImplicitTrainFused)
             dgrad = torch.zeros(Pt, 3, **f32) if rev else None
             dXA = torch.empty(npts, 6, **f32)
-            rt.backward(drgb_l[n], dXA, off(dZ8, 1), 257)
+            if fusedp:                 # d features as their own aligned matrix, written (not accumulated) by the colour net
+                dZ8 = None
+                dfeat = torch.empty(Pt, 256, **f32)
+                dfeat[npts:].zero_()   # the eikonal points have no colour path
+                if isinstance(rt, RenderTrainFused):
+                    rt.backward(drgb_l[n], dXA, dfeat)
+                else:
+                    rt.backward(drgb_l[n], dXA, _p(dfeat), 256, feat_accumulate=False)
+            else:
+                dZ8 = torch.zeros(Pt if rev else 4 * Pt, 257, **f32)
+                rt.backward(drgb_l[n], dXA, off(dZ8, 1), 257)
             djinv = torch.empty(npts, 9, **f32) if self.pose_grad else None
-            _chk(L.mp_tr_shade_in_bwd(_p(it.out), Pt, npts, _p(f["jinv"]), _p(dXA), _p(dsdf_l[n]), None, _p(dZ8),
+            _chk(L.mp_tr_shade_in_bwd(None if fusedp else _p(it.out), Pt, npts, _p(f["jinv"]), _p(dXA), _p(dsdf_l[n]), None, _p(dZ8),
                                       _p(djinv), _p(it.grad) if rev else None, _p(dgrad), st), "mp_tr_shade_in_bwd")
             if d_grad_theta is not None:
                 dg = d_grad_theta.reshape(-1, 3)[n * N_EIKONAL:(n + 1) * N_EIKONAL].contiguous().float()
                 _chk(L.mp_tr_eik_bwd(Pt, npts, N_EIKONAL, _p(dg), _p(dZ8), _p(dgrad), st), "mp_tr_eik_bwd")
-            dcond = it.backward(dZ8, dgrad, want_dx=self.pose_grad) if rev else it.backward(dZ8, want_dx=self.pose_grad)
+            if fusedp:
+                dcond = it.backward(dfeat, dsdf_l[n], dgrad)
+            else:
+                dcond = it.backward(dZ8, dgrad, want_dx=self.pose_grad) if rev else it.backward(dZ8, want_dx=self.pose_grad)
+            self.ts.finish_group(p)                                   # one batched weight-norm adjoint for the person's two nets
             collect(it); collect(rt)
             retire(it, rt)
             if self.pose_grad:
@@ -884,6 +1149,7 @@ class TrainGraph:
             dcode = brt.backward(drgbb, dXAb, off(dZ8b, 1), 257)
             _chk(L.mp_tr_copy_cols(_p(dsdfb), 1, 0, _p(dZ8b), 257, 0, rows, 1, C.c_float(1.0), 0, st), "mp_tr_copy_cols")
             dcode = dcode + bit.backward(dZ8b)
+            self.ts.finish_group("bg")
             collect(bit); collect(brt)
             w = m.frame_latent_encoder.weight
             gw = torch.zeros_like(w)

@@ -135,7 +135,7 @@ def test_fused_sdf_kernels_against_autograd(P):
     names = [n for n, p in m.named_parameters() if n.startswith("foreground_implicit_network_list.0.")]
     plist = [p for n, p in m.named_parameters() if n.startswith("foreground_implicit_network_list.0.")]
     want = torch.autograd.grad(loss, plist, allow_unused=True)
-    dc_f = fus.backward(a_out.clone(), a_g.clone())
+    dc_f = fus.backward(a_out[:, 1:].contiguous(), a_out[:, 0].contiguous(), a_g.clone())
     dc_r = ref.backward(a_out.clone(), a_g.clone())
     assert rel("d cond, fused vs layer-wise", dc_f, dc_r) < 2e-4
     got = dict(zip([id(p) for p in fus.params()], fus.param_grads()))
@@ -147,7 +147,7 @@ def test_fused_sdf_kernels_against_autograd(P):
     # a second forward on the same network object re-uses the persistent state (weights re-packed, accumulators zeroed)
     fus2 = T.ImplicitTrainFused(net, x, cond)
     assert torch.equal(fus2.out, fus.out) and torch.equal(fus2.grad, fus.grad)
-    fus2.backward(a_out.clone(), a_g.clone())
+    fus2.backward(a_out[:, 1:].contiguous(), a_out[:, 0].contiguous(), a_g.clone())
     for g1, g2 in zip(fus2.param_grads(), got.values()):
         assert rel("second iteration, same gradients", g1, g2) < 1e-5
 
@@ -186,6 +186,46 @@ def test_rendering_net_backward():
         bad = int((row_err > 1e-5).sum())
         print(f"[grad parity] {nme}: rows off by > 1e-5 of max: {bad} of {n}; worst {float(row_err.max()):.3e}")
         assert bad <= 2, nme
+
+
+@pytest.mark.parametrize("n", [900, 129])
+def test_fused_colour_kernels_against_autograd(n):
+    """The layer-fused colour-net kernels (csrc/tfuse.hip: mp_tf_col_fwd / mp_tf_col_bwd, split-bf16 products inside) against
+    torch autograd on the oracle's formula: rgb, every parameter gradient, d XA and d feat (ReLU-mask flips: see above)."""
+    from multiply_amd import train as T
+    m, _ = seeded_networks(1, 0)
+    m = m.cuda()
+    ren = m.foreground_rendering_network_list[0]
+    assert T.fused_col_supported(ren)
+    torch.manual_seed(2)
+    XA = torch.randn(n, 6, device="cuda")
+    feat = (torch.randn(n + 7, 256, device="cuda") * 0.3).contiguous()      # more rows than points, like the SDF net's batch
+    cond = torch.randn(69, device="cuda") * 0.1
+    rt = T.RenderTrainFused(ren, XA, feat, n, cond)
+    sd = {k: v for k, v in m.named_parameters()}
+    XAg, featg = XA.clone().requires_grad_(True), feat[:n].clone().requires_grad_(True)
+    want_rgb = O.rendering_forward_pose_no_view(sd, "foreground_rendering_network_list.0.", XAg[:, :3], XAg[:, 3:], cond, featg)
+    assert rel("fused rgb", rt.rgb, want_rgb.detach()) < 3e-5
+    a = torch.randn(n, 3, device="cuda")
+    plist = [p for nme, p in m.named_parameters() if nme.startswith("foreground_rendering_network_list.0.")]
+    names = [nme for nme, p in m.named_parameters() if nme.startswith("foreground_rendering_network_list.0.")]
+    want = torch.autograd.grad((want_rgb * a).sum(), plist + [XAg, featg])
+    dXA = torch.empty(n, 6, device="cuda")
+    dfeat = torch.full((n + 7, 256), 7.0, device="cuda")
+    rt.backward(a, dXA, dfeat)
+    assert bool((dfeat[n:] == 7.0).all()), "rows past the n points are not touched"
+    got = dict(zip([id(p) for p in rt.params()], rt.param_grads()))
+    assert len(got) == len(plist)
+    # per-sample data gradients first: a ReLU mask that flips (a pre-activation within the products' 2^-16 of zero -- these
+    # inputs are dense around zero) touches exactly the sample it belongs to, so all but a few ROWS must agree tightly ...
+    for nme, g, w in (("d XA", dXA, want[-2]), ("d feat", dfeat[:n], want[-1])):
+        row_err = (g - w).abs().amax(1) / w.abs().max()
+        bad = int((row_err > 5e-5).sum())
+        print(f"[grad parity] fused {nme}: rows off by > 5e-5 of max: {bad} of {n}; worst {float(row_err.max()):.3e}")
+        assert bad <= 4, nme
+    # ... and one flipped sample moves an element of a 900-sample parameter gradient by up to ~2e-2 of the tensor's maximum
+    for nme, p, ww in zip(names, plist, want[:len(plist)]):
+        assert rel(nme, got[id(p)].reshape(ww.shape), ww) < 4e-2, nme
 
 
 def test_background_branch_backward():

@@ -22,6 +22,7 @@ x = (torch.rand(P, 3, device="cuda") - 0.5) * 1.6
 cond = torch.randn(69, device="cuda") * 0.1
 dZ = torch.randn(P, 257, device="cuda") * 1e-3
 dg = torch.randn(P, 3, device="cuda") * 1e-3
+dfeat, dsdf = dZ[:, 1:].contiguous(), dZ[:, 0].contiguous()
 
 
 def timed(fn, n):
@@ -43,8 +44,12 @@ for name, cls in (("fused", T.ImplicitTrainFused), ("layer-wise", T.ImplicitTrai
         holder["it"] = cls(net, x, cond)
 
     def bwd():
-        holder["it"].backward(dZ, dg)
-        holder["it"].param_grads()
+        it = holder["it"]
+        if isinstance(it, T.ImplicitTrainFused):
+            it.backward(dfeat, dsdf, dg)
+        else:
+            it.backward(dZ, dg)
+        it.param_grads()
 
     t_f = timed(fwd, reps)
     t_fb = timed(lambda: (fwd(), bwd()), reps)
@@ -53,10 +58,12 @@ for name, cls in (("fused", T.ImplicitTrainFused), ("layer-wise", T.ImplicitTrai
 # the two fused kernels alone
 it = T.ImplicitTrainFused(net, x, cond)
 fs, L, st = it.fs, hip.lib(), hip.stream()
-dw8 = torch.zeros(256, device="cuda")
-t1 = timed(lambda: L.mp_tf_sdf_fwd(T._p(fs.wpack), T._p(fs.bias_all), T._p(it.w8), T._p(it.arena), P, T._p(it.out), st), reps)
-it.backward(dZ, dg)
-t2 = timed(lambda: L.mp_tf_sdf_bwd(T._p(fs.wpack), T._p(it.w8), T._p(it.arena), P, T._p(dZ), T._p(dw8), st), reps)
+dw8 = torch.zeros(257, device="cuda")
+t1 = timed(lambda: L.mp_tf_sdf_fwd(T._p(fs.wpack), T._p(fs.bias_all), T._p(it.w8), T._p(it.arena), P, T._p(it.feat), T._p(it.sdf), st),
+           reps)
+it.backward(dfeat, dsdf, dg)
+t2 = timed(lambda: L.mp_tf_sdf_bwd(T._p(fs.wpack), T._p(it.w8), T._p(it.arena), P, T._p(dfeat), T._p(dsdf), T._p(dw8), T._p(dw8), st),
+           reps)
 flop = P * 2 * 542208 * 2            # value sweep + gradient sweep, algorithmic
 print(f"k_tf_sdf_fwd {t1:.3f} ms ({flop / t1 / 1e9:.1f} TFLOP/s algorithmic), k_tf_sdf_bwd {t2:.3f} ms "
       f"({flop / t2 / 1e9:.1f} TFLOP/s)")
