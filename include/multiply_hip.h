@@ -258,6 +258,18 @@ int mp_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int l
  * operands into k-contiguous MFMA fragments happens on the way into LDS.  colsum stays an exact fp32 sum. */
 int mp_gemm_tn_bf16x3(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, float* colsum,
                int colsum_rows, void* stream);
+/* Up to MP_TN_MAX_GROUPS such contractions in ONE launch (the weight gradients of all layers of a network): groups is a HOST
+ * array; every group needs 16-byte aligned A, B, lda / ldb multiples of 4 and M, N multiples of 128.  Far fewer row slices per
+ * output than one launch per contraction needs to fill the chip, hence far fewer fp32 atomics. */
+#define MP_TN_MAX_GROUPS 24
+typedef struct {
+    const float* A;
+    const float* B;
+    float* C;
+    float* colsum;       /* may be NULL */
+    int lda, ldb, ldc, M, N, K, colsum_rows, pad_;
+} MpTnGroup;
+int mp_gemm_tn_bf16x3_grouped(const MpTnGroup* groups, int n_groups, void* stream);
 /* Fourier features (embedders.py) of x [P][d_in] (d_in 3|4, L octaves) times `scale` into out[.][ld] at col0; fwd != 0 also
  * writes the three (d_in = 3) tangent row blocks */
 int mp_tr_pe(const float* x, int d_in, int P, int L, int fwd, float scale, float* out, int ld, int col0, void* stream);
@@ -350,15 +362,17 @@ int mp_tr_copy_cols(const float* src, int lds, int c0s, float* dst, int ldd, int
  *                    B[0] = layer 0's bias with the conditioning hoisted in) -> wpack (pack_bytes of mp_tf_sdf_sizes: split
  *                    bf16 fragment tiles of W_l, W_l^T in consumption order) and bias_all [9][288] (pack-row order).
  *                    W and B are device arrays of 9 device pointers.
- *   arena          : floats as reported by mp_tf_sdf_sizes(P, &arena_floats, &pack_bytes), PL = 256 P:
- *                      AB(l) l=0..7 [2P][256] at l*2PL          rows [0,P) dZ_l (bwd), rows [P,2P) V_l (fwd)
- *                      BB(l) l=1..8 [2P][256] at 16PL+(l-1)*2PL rows [0,P) X_l (fwd: layer l's input), rows [P,2P) dT_l (bwd)
- *                      U(l)  l=0..6 [P][256]  at 32PL+l*PL ;  dS(l) l=0..7 [P][256] at 39PL+l*PL
- *                      BB0 [2P][39] at 47PL: rows [0,P) Fourier features (caller, before fwd), rows [P,2P) dG (caller, before bwd)
- *                      G [P][39] at 47PL+78P: d sdf / d Fourier features (fwd)
+ *   arena          : floats as reported by mp_tf_sdf_sizes(P, &arena_floats, &pack_bytes).  Every [P][256] tensor has P + 1 rows
+ *                    (row P: where the lanes of the last tile's missing points store); R1 = (P + 1) 256:
+ *                      dZ(l) l=0..7 at l R1 (bwd)          V(l)  l=0..7 at (8+l) R1 (fwd)
+ *                      X(l)  l=1..8 at (15+l) R1 (fwd: layer l's input)   dT(l) l=1..7 at (23+l) R1 (bwd)
+ *                      U(l)  l=0..6 at (31+l) R1 ;  dS(l) l=0..7 at (38+l) R1
+ *                      IN [P][39] at 46 R1 (Fourier features: caller, before fwd), dG [P][39] at 46 R1 + 39 P (caller, before bwd),
+ *                      G [P][39] at 46 R1 + 78 P: d sdf / d Fourier features (fwd); then 256 floats the kernels scribble on
  *                    columns >= 217 of X_4 and dT_4 (the re-injected Fourier features of the skip connection, times 1/sqrt 2)
- *                    are NOT written by the kernels: the caller copies them from BB0 (mp_tr_copy_cols).
- *   mp_tf_sdf_fwd  : feat [P][256] and sdf [P] = the last layer's outputs (the reference's column 0 = sdf, columns 1.. = features),
+ *                    are NOT written by the kernels: the caller copies them from IN / dG (mp_tr_copy_cols).
+ *                    Weight gradients (mp_gemm_tn_bf16x3[_grouped]): dW_l += dZ_l^T X_l + V_l^T dT_l.
+ *   mp_tf_sdf_fwd  : feat [P+1][256] and sdf [P+1] (one pad row each) = the last layer's outputs (the reference's column 0 = sdf, columns 1.. = features),
  *                    G, and the stashes
  *   mp_tf_sdf_bwd  : dfeat [P][256], dsdf [P] (adjoints of feat / sdf), dG in BB0 -> dZ_l, dT_l stashes;
  *                    dw8 [256] += gradient of the last layer's sdf ROW (the gradient sweep's V_7 = sigma'_7 (.) w8 and the value
@@ -373,7 +387,8 @@ int mp_tf_sdf_bwd(const void* wpack, const float* w8, float* arena, int P, const
 /* The foreground RenderingNet ('pose_no_view', networks.py:263-312: 270 -> 4 x 256 ReLU -> 3, sigmoid) on the same skeleton:
  *   mp_tf_col_pack : W[5] (effective weights, layer 0 = [256][270]: columns 0..5 x_c / normal, 6..13 pose embedding, 14.. features),
  *                    B[5] (B[0] with the pose embedding hoisted in) -> wpack, bias_all [5][288]
- *   stash          : 8 n 256 floats: H(l) l=0..3 [n][256] at l*256n (ReLU outputs), dZ(l) l=0..3 at (4+l)*256n (their adjoints)
+ *   stash          : mp_tf_col_sizes floats; N1 = (n + 1) 256 (pad rows as above): H(l) l=0..3 at l N1 (ReLU outputs), dZ(l) l=0..3 at
+ *                    (4+l) N1 (their adjoints)
  *   mp_tf_col_fwd  : feat [n][256] (row stride 256), xa [n][6] -> rgb [n][3], H stashes
  *   mp_tf_col_bwd  : drgb, rgb [n][3], w4 = W_4 [3][256] -> dfeat [n][256], dxa [n][6], dz4 [n][3] (adjoint of the last layer's
  *                    pre-activations), dZ stashes.  Weight gradients: dW_l = dZ_l^T H_{l-1} etc. by mp_gemm_tn_bf16x3. */

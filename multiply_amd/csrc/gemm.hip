@@ -539,15 +539,13 @@ __global__ __launch_bounds__(NT_THREADS) void k_gemm_tn(const float* __restrict_
 // blocks (2 kg, 2 kg + 1) of its column: two b64 reads, consecutive lanes on consecutive 8-byte slots (conflict-free).
 // (operand rows fetched PT = 2 stages ahead through a register ring, k loop unrolled by 2 -- what fits under 128 VGPRs; see k_gemm_nt_b3)
 template <bool FAST>
-__global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_tn_b3(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                                    float* __restrict__ C, int ldc, int M, int N, int K, int rows_per_block,
-                                                    float* __restrict__ colsum, int colsum_rows) {
+__device__ __forceinline__ void tn_b3_tile(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                           float* __restrict__ C, int ldc, int M, int N, int m0, int n0, int r_begin, int r_end,
+                                           float* __restrict__ colsum, int colsum_rows, bool sum_tile) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int HALF = (BK / 4) * BM * 4;            // bf16 elements of one [row block][column][4] tile (BM == BN)
     __bf16* Ts = (__bf16*)smem;                          // [stage][A | B][hi | lo][HALF]
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int r_begin = blockIdx.z * rows_per_block, r_end = min(K, r_begin + rows_per_block);
     const int wm = (wave >> 2) * 64, wn = (wave & 3) * 32;   // 2 x 4 waves, each 64 (m) x 32 (n)
     const int li = lane & 15, kg = lane >> 4;
     f32x4 acc[4][2];
@@ -561,7 +559,7 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_tn_b3(const float* __res
     const float* src = is_b ? B : A;
     const int ld = is_b ? ldb : lda, c0 = (is_b ? n0 : m0) + 4 * mg, cmax = is_b ? N : M;
     const bool al = (ld & 3) == 0 && ((size_t)src & 15) == 0;
-    const bool do_sum = colsum != nullptr && blockIdx.y == 0 && !is_b;
+    const bool do_sum = colsum != nullptr && sum_tile && !is_b;
     constexpr int PT = 2;
     f32x4 rr_[PT][4], csum = {0.f, 0.f, 0.f, 0.f};
     auto gload = [&](f32x4 (&rr)[4], int r0) {
@@ -648,7 +646,7 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_tn_b3(const float* __res
 #endif
             }
         }
-    if (colsum != nullptr && blockIdx.y == 0) {   // A-staging threads with the same mg hold partial sums of the same 4 columns
+    if (colsum != nullptr && sum_tile) {   // A-staging threads with the same mg hold partial sums of the same 4 columns
         __syncthreads();
         float* red = smem;
         for (int i = t; i < BM; i += NT_THREADS) red[i] = 0.f;
@@ -659,6 +657,38 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_tn_b3(const float* __res
         for (int i = t; i < BM; i += NT_THREADS)
             if (m0 + i < M && red[i] != 0.f) atomicAdd(colsum + m0 + i, red[i]);
     }
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_tn_b3(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                    float* __restrict__ C, int ldc, int M, int N, int K, int rows_per_block,
+                                                    float* __restrict__ colsum, int colsum_rows) {
+    const int r_begin = blockIdx.z * rows_per_block;
+    tn_b3_tile<FAST>(A, lda, B, ldb, C, ldc, M, N, blockIdx.x * BM, blockIdx.y * BN, r_begin, min(K, r_begin + rows_per_block), colsum,
+                     colsum_rows, blockIdx.y == 0);
+}
+
+// GROUPED form: up to MP_TN_MAX_GROUPS independent contractions (the weight gradients of all layers of a network) in ONE grid.
+// Launched one contraction at a time, each 256 x 256 output is split into ~128 row slices to fill the chip, and every slice adds
+// its 128 x 128 partial with fp32 atomics: 8.4 M atomics per layer -- about a third of the kernel's time.  With G layers in one
+// grid the same number of workgroups needs 1/G of the slices per output (and the slices are long enough to amortise a
+// workgroup's prologue / epilogue).  Aligned operands only (FAST path: 16 B aligned, M, N multiples of 128).
+struct TnGroups {
+    MpTnGroup g[MP_TN_MAX_GROUPS];
+    int slice0[MP_TN_MAX_GROUPS + 1];    // first blockIdx.z of every group
+    int n, rows_per_block;
+};
+__global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_tn_b3g(TnGroups T) {
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < MP_TN_MAX_GROUPS; ++i)
+        if (i < T.n && (int)blockIdx.z >= T.slice0[i]) gi = i;
+    const MpTnGroup& G = T.g[gi];
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    if (m0 >= G.M || n0 >= G.N) return;
+    const int r_begin = ((int)blockIdx.z - T.slice0[gi]) * T.rows_per_block;
+    tn_b3_tile<true>(G.A, G.lda, G.B, G.ldb, G.C, G.ldc, G.M, G.N, m0, n0, r_begin, min(G.K, r_begin + T.rows_per_block), G.colsum,
+                     G.colsum_rows, blockIdx.y == 0);
 }
 
 }  // namespace
@@ -767,5 +797,41 @@ extern "C" int mp_gemm_tn_bf16x3(const float* A, int lda, const float* B, int ld
     else
         hipLaunchKernelGGL(k_gemm_tn_b3<false>, dim3((M + BM - 1) / BM, (N + BN - 1) / BN, slices), dim3(NT_THREADS), LDS_B3,
                            (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, rows, colsum, colsum_rows);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_gemm_tn_bf16x3_grouped(const MpTnGroup* groups, int n_groups, void* stream) {
+    if (n_groups <= 0) return 0;
+    if (n_groups > MP_TN_MAX_GROUPS) return -1;
+    TnGroups T;
+    T.n = n_groups;
+    long long work = 0;
+    int mt = 0, nt = 0;
+    for (int i = 0; i < n_groups; ++i) {
+        const MpTnGroup& g = groups[i];
+        if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.M % BM || g.N % BN || (g.lda & 3) || (g.ldb & 3) || ((size_t)g.A & 15) ||
+            ((size_t)g.B & 15))
+            return -2;
+        T.g[i] = g;
+        work += (long long)(g.M / BM) * (g.N / BN) * g.K;
+        mt = g.M / BM > mt ? g.M / BM : mt;
+        nt = g.N / BN > nt ? g.N / BN : nt;
+    }
+#ifndef MP_TNG_WGS
+#define MP_TNG_WGS 1024   // workgroups of a grouped launch: 2 resident per CU, two rounds
+#endif
+    long long rows = (work + MP_TNG_WGS - 1) / MP_TNG_WGS;
+    rows = (rows + BK - 1) / BK * BK;
+    if (rows < 8 * BK) rows = 8 * BK;
+    T.rows_per_block = (int)rows;
+    int z = 0;
+    for (int i = 0; i < n_groups; ++i) {
+        T.slice0[i] = z;
+        z += (int)((groups[i].K + rows - 1) / rows);
+    }
+    T.slice0[n_groups] = z;
+    constexpr int LDS_B3 = 2 * 2 * 2 * (BK / 4) * BM * 4 * 2;
+    MP_LDS_ATTR(k_gemm_tn_b3g, LDS_B3);
+    hipLaunchKernelGGL(k_gemm_tn_b3g, dim3(mt, nt, z), dim3(NT_THREADS), LDS_B3, (hipStream_t)stream, T);
     return (int)hipGetLastError();
 }

@@ -135,13 +135,14 @@ __global__ __launch_bounds__(512) void k_tf_pack(const float* const* __restrict_
     }
 }
 
-// ---- stash arena (floats), P points: PL = P * 256 -------------------------------------------------------------------------------
-//   AB(l) l = 0..7 : [2P][256]  rows [0,P) = dZ_l (backward), rows [P,2P) = V_l (forward)          at  l * 2 PL
-//   BB(l) l = 1..8 : [2P][256]  rows [0,P) = X_l (forward),   rows [P,2P) = dT_l (backward)        at  16 PL + (l-1) * 2 PL
-//   U(l)  l = 0..6 : [P][256]   the gradient sweep's rows before the sigmoid factor                at  32 PL + l PL
-//   dS(l) l = 0..7 : [P][256]   sigma'' (.) U (.) dV between the backward's two sweeps               at  39 PL + l PL
-//   BB0            : [2P][39]   rows [0,P) = the Fourier features, rows [P,2P) = dG                at  47 PL
-//   G              : [P][39]                                                                       at  47 PL + 78 P
+// ---- stash arena (floats), P points.  Every [P][256] tensor has P + 1 rows: row P is where the lanes of the last tile's missing
+// points store (unconditional stores, no select: a divergent branch around them makes hipcc's wait-count bookkeeping fall back
+// to vmcnt(0) at every chunk).  R1 = (P + 1) * 256:
+//   dZ(l) l = 0..7 at l R1 (backward)          V(l)  l = 0..7 at (8 + l) R1 (forward)
+//   X(l)  l = 1..8 at (15 + l) R1 (forward)    dT(l) l = 1..7 at (23 + l) R1 (backward)
+//   U(l)  l = 0..6 at (31 + l) R1: the gradient sweep's rows before the sigmoid factor
+//   dS(l) l = 0..7 at (38 + l) R1: sigma'' (.) U (.) dV between the backward's two sweeps
+//   IN [P][39] at 46 R1 (Fourier features), dG [P][39] at 46 R1 + 39 P, G [P][39] at 46 R1 + 78 P
 struct TfArgs {
     const char* wpack;
     const float* bias;     // [9][288]
@@ -155,12 +156,15 @@ struct TfArgs {
     float* db8;            // bwd: [1] +=  gradient of its bias
     int P;
 };
-__host__ __device__ inline size_t off_AB(size_t PL, int l) { return (size_t)l * 2 * PL; }
-__host__ __device__ inline size_t off_BB(size_t PL, int l) { return 16 * PL + (size_t)(l - 1) * 2 * PL; }
-__host__ __device__ inline size_t off_U(size_t PL, int l) { return 32 * PL + (size_t)l * PL; }
-__host__ __device__ inline size_t off_dS(size_t PL, int l) { return 39 * PL + (size_t)l * PL; }
-__host__ __device__ inline size_t off_BB0(size_t PL) { return 47 * PL; }
-__host__ __device__ inline size_t off_G(size_t PL, size_t P) { return 47 * PL + 78 * P; }
+__host__ __device__ inline size_t off_dZ(size_t R1, int l) { return (size_t)l * R1; }
+__host__ __device__ inline size_t off_V(size_t R1, int l) { return (size_t)(8 + l) * R1; }
+__host__ __device__ inline size_t off_X(size_t R1, int l) { return (size_t)(15 + l) * R1; }
+__host__ __device__ inline size_t off_dT(size_t R1, int l) { return (size_t)(23 + l) * R1; }
+__host__ __device__ inline size_t off_U(size_t R1, int l) { return (size_t)(31 + l) * R1; }
+__host__ __device__ inline size_t off_dS(size_t R1, int l) { return (size_t)(38 + l) * R1; }
+__host__ __device__ inline size_t off_IN(size_t R1) { return 46 * R1; }
+__host__ __device__ inline size_t off_dG(size_t R1, size_t P) { return 46 * R1 + 39 * P; }
+__host__ __device__ inline size_t off_G(size_t R1, size_t P) { return 46 * R1 + 78 * P; }
 
 struct BReg { bf16x8 h[8], l[8]; };
 __device__ __forceinline__ bf16x8 zero_frag() { return __builtin_bit_cast(bf16x8, (f32x4){0.f, 0.f, 0.f, 0.f}); }
@@ -185,8 +189,11 @@ struct Ctx {
     int split_at, src_shift;            // stream position k -> chunk k (k < split_at) or k + src_shift
     int noreg_hi, in0_lo, in0_hi, in1_lo, in1_hi;   // chunks below noreg_hi have no register-fed part; two chunk ranges have an input-fed part
     bool valid;
-    size_t row;        // 256 * (clamped) point index
+    unsigned row;      // 256 * point index, clamped to the last point: LOADS of this lane's stash rows
+    unsigned srow;     // 256 * min(point index, P): STORES (row P = the tensors' pad row)
+    unsigned pad;      // P
     size_t prow;       // (clamped) point index
+    float* trash;      // 256 floats for the few stores into caller-owned arrays without a pad row
 };
 
 // pieces [wl, wl + nw, ...) of chunk k into ring slot `slot`
@@ -198,6 +205,9 @@ __device__ __forceinline__ void tf_issue(const Ctx& cx, int k, int slot, int wl)
     const char* s = mp::uniform_ptr(cx.wpack) + (size_t)src * CH_BYTES + wu * TILE_B;
     const unsigned d = __builtin_amdgcn_readfirstlane(mp::lds_offset(cx.ring)) + __builtin_amdgcn_readfirstlane(slot) * CH_BYTES +
                        wu * TILE_B;
+#if TF_EXP & 8
+    return;
+#endif
     if (has_reg) {
 #pragma unroll
         for (int i = 0; i < 32 / NW; ++i) mp::lds_dma_16(s + i * NW * TILE_B, cx.lane * 16, d + i * NW * TILE_B);
@@ -208,27 +218,49 @@ __device__ __forceinline__ void tf_issue(const Ctx& cx, int k, int slot, int wl)
     }
 }
 
+// ablation switches (timing experiments only: results are wrong), -DTF_EXP=<bits>: 1 no stash stores, 2 no MFMAs, 4 no A-fragment
+// LDS reads, 8 no weight DMA, 16 no stash loads (the activation code sees zeros)
+#ifndef TF_EXP
+#define TF_EXP 0
+#endif
+#if TF_EXP & 2
+#define TF_MFMA(a, b, c) (c)
+#else
 #define TF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#endif
+#ifndef TF_QD
+#define TF_QD 3      // depth of the A-fragment register queue (K steps)
+#endif
 
+__device__ __forceinline__ bf16x8 lds_frag(const char* p) {
+#if TF_EXP & 4
+    return __builtin_bit_cast(bf16x8, (f32x4){1e-3f, 2e-3f, 1e-3f, 2e-3f});
+#else
+    return *(const bf16x8*)p;
+#endif
+}
 // the products of one chunk: acc[mb] (16 rows x 16 points) += W tile . activations, K = 256 from registers (+ 64 from the input)
 template <bool HAS_IN>
 __device__ __forceinline__ void tf_mma(const Ctx& cx, bool use_reg, bool use_in, const BReg& B, f32x4 (&acc)[2]) {
     const char* slot = cx.ring + cx.ring_pos * CH_BYTES + cx.lane * 16;
     if (use_reg) {
-        // A fragments one K step ahead in a two-deep register queue: q[.][2 mb + half].  Pinned with sched_barrier: left alone,
-        // hipcc sinks every ds_read to just before its MFMA and drains lgkmcnt(0) sixteen times per chunk.
-        bf16x8 q[2][4];
+        // A fragments TF_QD - 1 K steps ahead in a register queue: q[.][2 mb + half].  Pinned with sched_barrier: left alone,
+        // hipcc sinks every ds_read to just before its MFMA and drains lgkmcnt(0) sixteen times per chunk.  One K step ahead is
+        // ~100 cycles of MFMA cover -- less than the LDS latency with eight waves reading 4 KB per K step each.
+        bf16x8 q[TF_QD][4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) q[0][t] = *(const bf16x8*)(slot + (((t >> 1) * 8 + 0) * 2 + (t & 1)) * TILE_B);
+        for (int k0 = 0; k0 < TF_QD - 1; ++k0)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) q[k0][t] = lds_frag(slot + (((t >> 1) * 8 + k0) * 2 + (t & 1)) * TILE_B);
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            if (ks + 1 < 8) {
+            if (ks + TF_QD - 1 < 8) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
-                    q[(ks + 1) & 1][t] = *(const bf16x8*)(slot + (((t >> 1) * 8 + ks + 1) * 2 + (t & 1)) * TILE_B);
+                    q[(ks + TF_QD - 1) % TF_QD][t] = lds_frag(slot + (((t >> 1) * 8 + ks + TF_QD - 1) * 2 + (t & 1)) * TILE_B);
             }
             __builtin_amdgcn_sched_barrier(0);
-            const bf16x8 (&a)[4] = q[ks & 1];       // a[0] = hi of row block 0, a[1] = lo, a[2] = hi of row block 1, a[3] = lo
+            const bf16x8 (&a)[4] = q[ks % TF_QD];   // a[0] = hi of row block 0, a[1] = lo, a[2] = hi of row block 1, a[3] = lo
             // the small terms first; the two row blocks alternate so that no MFMA waits for the one before it
             acc[0] = TF_MFMA(a[1], B.h[ks], acc[0]);
             acc[1] = TF_MFMA(a[3], B.h[ks], acc[1]);
@@ -262,43 +294,79 @@ __device__ __forceinline__ void tf_mma(const Ctx& cx, bool use_reg, bool use_in,
     }
 }
 
-// One layer = up to MAXC chunks of 32 output rows.  Per chunk: prefetch of what the activation code reads, the products, the
-// chunk barrier, the activation code (Epi::run), which also writes K step c of the NEXT layer's operand.  Waves 0..3 ("early",
-// one per SIMD) pass the barrier behind their activation code, waves 4..7 ("late") between products and activation code: the
-// two waves of a SIMD run in anti-phase, one wave's VALU / memory work beside the other's MFMAs (mlp_core.hpp run_layer_pp).
+// One layer = up to MAXC chunks of 32 output rows.  Per chunk: the products, the chunk barrier, the activation code (Epi::run),
+// which also writes K step c of the NEXT layer's operand.  Waves 0..3 ("early", one per SIMD) pass the barrier behind their
+// activation code, waves 4..7 ("late") between products and activation code: the two waves of a SIMD run in anti-phase, one
+// wave's VALU / memory work beside the other's MFMAs (mlp_core.hpp run_layer_pp).
 // Ring protocol: behind barrier(ci) every wave is done with chunk ci's products, so the late waves refill its slot with chunk
-// ci + 3 and wait for those pieces before barrier(ci + 1); chunk ci + 3 is first read behind barrier(ci + 2).
+// ci + 3 and make sure those pieces have landed before barrier(ci + 1); chunk ci + 3 is first read behind barrier(ci + 2).
+// Memory latency: what the activation code of chunk c + 1 reads (biases, stash rows) is requested at the head of the activation
+// code of chunk c, BEFORE chunk c's stash stores -- vector memory operations complete in issue order, so a load issued behind a
+// store cannot return before the store is acknowledged (measured on the first version: ~2.5 us per chunk = one HBM round trip,
+// against 0.8 us of MFMA work).  For the same reason nothing here waits with vmcnt(0): Epi::touch() makes the compiler wait for
+// the prefetched registers at a point where only stores are younger (and before the asm-issued DMA, which it does not know of),
+// and the explicit wait is counted: vmcnt(npref) = "everything older than the last npref operations", i.e. older than the
+// prefetch loads, which are younger than the DMA pieces of the previous barrier.
+template <int N>
+__device__ __forceinline__ void wait_vm() { __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14)); }
+__device__ __forceinline__ void wait_vm_rt(int n) {
+    if (n >= 4) wait_vm<4>();
+    else if (n >= 2) wait_vm<2>();
+    else wait_vm<0>();
+}
+__device__ __forceinline__ void touch4(const f32x4& v) { asm volatile("" ::"v"(v)); }
+
 template <class Epi, int MAXC, bool HAS_IN>
 __device__ __forceinline__ void tf_layer(Ctx& cx, Epi& ep, int n_chunk, bool use_reg, bool use_in, BReg& Bcur, BReg& Bnext) {
+    int npref = ep.prefetch(cx, 0);
+    ep.rotate();
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
         if (c < n_chunk) {
-            ep.prefetch(cx, c);
             f32x4 acc[2];
             ep.init(cx, c, acc);
             tf_mma<HAS_IN>(cx, use_reg, use_in, Bcur, acc);
+            ep.touch();
             if (cx.late) {
-                mp::dma_wait_all();
+                wait_vm_rt(npref);
                 __syncthreads();
                 if (cx.ci + RING < cx.n_total) tf_issue<4>(cx, cx.ci + RING, cx.ring_pos, cx.wave - 4);
             }
+            npref = c + 1 < n_chunk ? ep.prefetch(cx, c + 1) : 0;
             ep.run(cx, c, acc, Bnext);
+            ep.rotate();
             if (!cx.late) __syncthreads();
             ++cx.ci;
             cx.ring_pos = cx.ring_pos + 1 == RING ? 0 : cx.ring_pos + 1;
         }
     }
+    if constexpr (Epi::NEXT_FROM_MEM) {
+        ep.load_next(cx, Bcur);
+    } else {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { Bcur.h[k] = Bnext.h[k]; Bcur.l[k] = Bnext.l[k]; }
+        for (int k = 0; k < 8; ++k) { Bcur.h[k] = Bnext.h[k]; Bcur.l[k] = Bnext.l[k]; }
+    }
 }
 
+#if TF_EXP & 16
+__device__ __forceinline__ f32x4 ld4g(const float* p) { return (f32x4){0.01f, 0.02f, 0.03f, 0.04f}; }
+#else
 __device__ __forceinline__ f32x4 ld4g(const float* p) { return *(const f32x4*)p; }
+#endif
+__device__ __forceinline__ void st4g(float* p, f32x4 v) {
+#if TF_EXP & 1
+    if (v[0] == 123.456f)
+#endif
+        *(f32x4*)p = v;
+}
 // 1 - sigma'(Z) = exp(-100 softplus(Z)) from the stored activation x = scale * softplus(Z), kx = 100 log2(e) / scale
 // (clamped at x = 0: columns 217.. of X_4 hold the re-injected Fourier features, which may be negative -- those columns only ever
 // meet zero weights, but 2^(+144) = inf times a zero weight would be a NaN inside the MFMA)
 __device__ __forceinline__ float one_minus_sig(float x, float kx) { return __builtin_amdgcn_exp2f(__builtin_fminf(-(x * kx), 0.0f)); }
 
-__device__ __forceinline__ void ctx_setup(Ctx& cx, char* smem, const char* wpack, int P, int n_total, int split_at, int src_shift) {
+__device__ __forceinline__ void ctx_setup(Ctx& cx, char* smem, const char* wpack, int P, int n_total, int split_at, int src_shift,
+                                          float* trash) {
+    cx.trash = trash;
     cx.wpack = wpack;
     cx.ring = smem;
     cx.wave = threadIdx.x >> 6;
@@ -317,7 +385,9 @@ __device__ __forceinline__ void ctx_setup(Ctx& cx, char* smem, const char* wpack
     const int pt = blockIdx.x * TF_PTS + cx.wave * 16 + cx.j;
     cx.valid = pt < P;
     cx.prow = (size_t)(pt < P ? pt : P - 1);
-    cx.row = cx.prow * HID;
+    cx.row = (unsigned)cx.prow * HID;
+    cx.srow = (unsigned)(pt < P ? pt : P) * HID;
+    cx.pad = (unsigned)P;
 }
 
 // the wave's input-fed B fragments (64 K slots in natural order, 39 used) of src [P][39] into its LDS block
@@ -348,27 +418,33 @@ __device__ __forceinline__ void tf_prologue(Ctx& cx) {
 // ================================================================================================================ forward
 // value sweep: softplus layers (and the linear last layer)
 struct EpiA {
+    static constexpr bool NEXT_FROM_MEM = false;
     const float* bias;     // this layer's biases, pack-row order
     float* xout;           // X_{l+1} rows (row-major [P][256])
     float osc;             // scale / K2 of the stored activation (layer 3: 1/sqrt(2): the skip connection's factor)
     bool linear;           // layer 8: rows 0..255 -> feat [P][256], row 256 -> sdf [P]
     float* feat;
     float* sdf;
-    __device__ __forceinline__ void prefetch(const Ctx&, int) {}
-    __device__ __forceinline__ void init(const Ctx& cx, int c, f32x4 (&acc)[2]) {
-        acc[0] = ld4g(bias + 32 * c + 4 * cx.g);
-        acc[1] = ld4g(bias + 32 * c + 16 + 4 * cx.g);
+    f32x4 pb[2], nb[2];
+    __device__ __forceinline__ int prefetch(const Ctx& cx, int c) {
+        nb[0] = ld4g(bias + 32 * c + 4 * cx.g);
+        nb[1] = ld4g(bias + 32 * c + 16 + 4 * cx.g);
+        return 2;
+    }
+    __device__ __forceinline__ void rotate() { pb[0] = nb[0]; pb[1] = nb[1]; }
+    __device__ __forceinline__ void touch() { touch4(pb[0]); touch4(pb[1]); }
+    __device__ __forceinline__ void init(const Ctx&, int, f32x4 (&acc)[2]) {
+        acc[0] = pb[0];
+        acc[1] = pb[1];
     }
     __device__ __forceinline__ void run(const Ctx& cx, int c, const f32x4 (&acc)[2], BReg& Bn) {
         if (linear) {
-            if (cx.valid) {
-                if (c < 8) {
-                    float* p = feat + cx.row + 32 * c + 4 * cx.g;
-                    *(f32x4*)p = acc[0];
-                    *(f32x4*)(p + 16) = acc[1];
-                } else if (cx.g == 0) {
-                    sdf[cx.prow] = acc[0][0];
-                }
+            if (c < 8) {
+                float* p = feat + cx.srow + 32 * c + 4 * cx.g;
+                st4g(p, acc[0]);
+                st4g((p + 16), acc[1]);
+            } else {
+                sdf[cx.g == 0 ? cx.srow >> 8 : cx.pad] = acc[0][0];   // row 256 lives in the g = 0 lanes; the others hit the pad entry
             }
             return;
         }
@@ -379,10 +455,10 @@ struct EpiA {
             const float u = __builtin_amdgcn_exp2f(-__builtin_fabsf(t));
             x[e] = (__builtin_fmaxf(t, 0.0f) + __builtin_amdgcn_logf(1.0f + u)) * osc;
         }
-        if (cx.valid) {
-            float* p = xout + cx.row + 32 * c + 4 * cx.g;
-            *(f32x4*)p = (f32x4){x[0], x[1], x[2], x[3]};
-            *(f32x4*)(p + 16) = (f32x4){x[4], x[5], x[6], x[7]};
+        {
+            float* p = xout + cx.srow + 32 * c + 4 * cx.g;
+            st4g(p, (f32x4){x[0], x[1], x[2], x[3]});
+            st4g((p + 16), (f32x4){x[4], x[5], x[6], x[7]});
         }
         if (c < 8) split8(x, Bn.h[c], Bn.l[c]);
     }
@@ -390,19 +466,24 @@ struct EpiA {
 
 // gradient sweep: V_{l-1} = sigma'_{l-1} (.) T_l
 struct EpiB {
+    static constexpr bool NEXT_FROM_MEM = false;
     const float* xin;      // X_l rows: sigma'_{l-1} is derived from them
     float kx;
     float* uout;           // U_{l-1}
     float* vout;           // V_{l-1}
     bool final;            // the 39-row product with W_0^T: accumulators start from the Fourier rows of T_4, result -> G
     float* gout;           // [P][39]
-    f32x4 px[2];
-    __device__ __forceinline__ void prefetch(const Ctx& cx, int c) {
+    f32x4 px[2], nx[2];
+    __device__ __forceinline__ int prefetch(const Ctx& cx, int c) {
         if (!final && c < 8) {
-            px[0] = ld4g(xin + cx.row + 32 * c + 4 * cx.g);
-            px[1] = ld4g(xin + cx.row + 32 * c + 16 + 4 * cx.g);
+            nx[0] = ld4g(xin + cx.row + 32 * c + 4 * cx.g);
+            nx[1] = ld4g(xin + cx.row + 32 * c + 16 + 4 * cx.g);
+            return 2;
         }
+        return 0;
     }
+    __device__ __forceinline__ void rotate() { px[0] = nx[0]; px[1] = nx[1]; }
+    __device__ __forceinline__ void touch() { touch4(px[0]); touch4(px[1]); }
     __device__ __forceinline__ void init(const Ctx& cx, int c, f32x4 (&acc)[2]) {
         acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
         acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -435,13 +516,13 @@ struct EpiB {
             u[e] = acc[e >> 2][e & 3];
             v[e] = (1.0f - one_minus_sig(px[e >> 2][e & 3], kx)) * u[e];
         }
-        if (cx.valid) {
-            float* pu = uout + cx.row + 32 * c + 4 * cx.g;
-            float* pv = vout + cx.row + 32 * c + 4 * cx.g;
-            *(f32x4*)pu = (f32x4){u[0], u[1], u[2], u[3]};
-            *(f32x4*)(pu + 16) = (f32x4){u[4], u[5], u[6], u[7]};
-            *(f32x4*)pv = (f32x4){v[0], v[1], v[2], v[3]};
-            *(f32x4*)(pv + 16) = (f32x4){v[4], v[5], v[6], v[7]};
+        {
+            float* pu = uout + cx.srow + 32 * c + 4 * cx.g;
+            float* pv = vout + cx.srow + 32 * c + 4 * cx.g;
+            st4g(pu, (f32x4){u[0], u[1], u[2], u[3]});
+            st4g((pu + 16), (f32x4){u[4], u[5], u[6], u[7]});
+            st4g(pv, (f32x4){v[0], v[1], v[2], v[3]});
+            st4g((pv + 16), (f32x4){v[4], v[5], v[6], v[7]});
         }
         split8(v, Bn.h[c], Bn.l[c]);
     }
@@ -450,9 +531,9 @@ struct EpiB {
 __global__ __launch_bounds__(TF_THREADS) void k_tf_sdf_fwd(TfArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Ctx cx;
-    ctx_setup(cx, smem, a.wpack, a.P, FWD_CHUNKS, FWD_CHUNKS, 0);
-    const size_t PL = (size_t)a.P * HID;
-    build_bin(cx, a.arena + off_BB0(PL));
+    ctx_setup(cx, smem, a.wpack, a.P, FWD_CHUNKS, FWD_CHUNKS, 0, a.arena + 46 * (size_t)(a.P + 1) * HID + 117 * (size_t)a.P);
+    const size_t R1 = (size_t)(a.P + 1) * HID;
+    build_bin(cx, a.arena + off_IN(R1));
     tf_prologue(cx);
     BReg Bcur, Bnext;
 #pragma unroll
@@ -461,7 +542,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tf_sdf_fwd(TfArgs a) {
     for (int l = 0; l <= 8; ++l) {
         EpiA ep;
         ep.bias = a.bias + l * BIAS_LD;
-        ep.xout = a.arena + off_BB(PL, l < 8 ? l + 1 : 8);
+        ep.xout = a.arena + off_X(R1, l < 8 ? l + 1 : 8);
         ep.osc = (l == 3 ? R2 : 1.0f) / K2;
         ep.linear = l == 8;
         ep.feat = a.feat;
@@ -470,7 +551,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tf_sdf_fwd(TfArgs a) {
     }
     // ---- top of the gradient sweep: V_7 = sigma'_7 (.) w8, from X_8 (still the operand registers of layer 8)
     {
-        float* vout = a.arena + off_AB(PL, 7) + PL;
+        float* vout = a.arena + off_V(R1, 7);
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             const f32x4 w0 = ld4g(a.w8 + 32 * ks + 4 * cx.g), w1 = ld4g(a.w8 + 32 * ks + 16 + 4 * cx.g);
@@ -480,10 +561,10 @@ __global__ __launch_bounds__(TF_THREADS) void k_tf_sdf_fwd(TfArgs a) {
                 const float x = (float)Bcur.h[ks][e] + (float)Bcur.l[ks][e];
                 v[e] = (1.0f - one_minus_sig(x, K2)) * (e < 4 ? w0[e & 3] : w1[e & 3]);
             }
-            if (cx.valid) {
-                float* pv = vout + cx.row + 32 * ks + 4 * cx.g;
-                *(f32x4*)pv = (f32x4){v[0], v[1], v[2], v[3]};
-                *(f32x4*)(pv + 16) = (f32x4){v[4], v[5], v[6], v[7]};
+            {
+                float* pv = vout + cx.srow + 32 * ks + 4 * cx.g;
+                st4g(pv, (f32x4){v[0], v[1], v[2], v[3]});
+                st4g((pv + 16), (f32x4){v[4], v[5], v[6], v[7]});
             }
             split8(v, Bcur.h[ks], Bcur.l[ks]);
         }
@@ -492,11 +573,11 @@ __global__ __launch_bounds__(TF_THREADS) void k_tf_sdf_fwd(TfArgs a) {
     for (int l = 7; l >= 0; --l) {
         EpiB ep;
         ep.final = l == 0;
-        ep.xin = a.arena + off_BB(PL, l > 0 ? l : 1);
+        ep.xin = a.arena + off_X(R1, l > 0 ? l : 1);
         ep.kx = l == 4 ? K2 / R2 : K2;
-        ep.uout = a.arena + off_U(PL, l > 0 ? l - 1 : 0);
-        ep.vout = a.arena + off_AB(PL, l > 0 ? l - 1 : 0) + PL;
-        ep.gout = a.arena + off_G(PL, a.P);
+        ep.uout = a.arena + off_U(R1, l > 0 ? l - 1 : 0);
+        ep.vout = a.arena + off_V(R1, l > 0 ? l - 1 : 0);
+        ep.gout = a.arena + off_G(R1, a.P);
         tf_layer<EpiB, 10, false>(cx, ep, l == 4 ? 10 : (l == 0 ? 2 : 8), true, false, Bcur, Bnext);
     }
 }
@@ -521,6 +602,20 @@ __device__ __forceinline__ void col_reduce(const Ctx& cx, int c, float (&r)[8]) 
 
 // ascending sweep: dV_l arrives in the accumulators;  dU = s (.) dV,  dS = s'' (.) U (.) dV,  dT_{l+1} = scale * dU
 struct EpiC {
+    // The next layer's operand (dT_{l+1}) is NOT kept in registers while this layer runs: it is re-read from the rows this wave
+    // has just stored for the weight-gradient contraction (its own stores: in order, L2-resident).  This sweep prefetches four
+    // stash vectors per chunk, double-buffered; with the 64 operand registers on top the kernel spilled, and a scratch reload in
+    // the chunk loop drains the memory pipeline (vmcnt counts scratch traffic) -- exactly what the prefetch order is there to avoid.
+    static constexpr bool NEXT_FROM_MEM = true;
+    __device__ __forceinline__ void load_next(const Ctx& cx, BReg& B) {
+        if (top) return;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const f32x4 v0 = ld4g(dtout + cx.row + 32 * ks + 4 * cx.g), v1 = ld4g(dtout + cx.row + 32 * ks + 16 + 4 * cx.g);
+            const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            split8(v, B.h[ks], B.l[ks]);
+        }
+    }
     const float* xin;      // X_{l+1} rows
     float kx;
     const float* uin;      // U_l rows; top layer (7): the row vector w8
@@ -528,19 +623,22 @@ struct EpiC {
     float* dsout;          // dS_l rows
     float osc;
     bool top;
-    f32x4 px[2], pu[2];
-    __device__ __forceinline__ void prefetch(const Ctx& cx, int c) {
+    f32x4 px[2], pu[2], nx[2], nu[2];
+    __device__ __forceinline__ int prefetch(const Ctx& cx, int c) {
         const int col = 32 * c + 4 * cx.g;
-        px[0] = ld4g(xin + cx.row + col);
-        px[1] = ld4g(xin + cx.row + col + 16);
+        nx[0] = ld4g(xin + cx.row + col);
+        nx[1] = ld4g(xin + cx.row + col + 16);
         if (top) {
-            pu[0] = ld4g(uin + col);
-            pu[1] = ld4g(uin + col + 16);
+            nu[0] = ld4g(uin + col);
+            nu[1] = ld4g(uin + col + 16);
         } else {
-            pu[0] = ld4g(uin + cx.row + col);
-            pu[1] = ld4g(uin + cx.row + col + 16);
+            nu[0] = ld4g(uin + cx.row + col);
+            nu[1] = ld4g(uin + cx.row + col + 16);
         }
+        return 4;
     }
+    __device__ __forceinline__ void rotate() { px[0] = nx[0]; px[1] = nx[1]; pu[0] = nu[0]; pu[1] = nu[1]; }
+    __device__ __forceinline__ void touch() { touch4(px[0]); touch4(px[1]); touch4(pu[0]); touch4(pu[1]); }
     __device__ __forceinline__ void init(const Ctx&, int, f32x4 (&acc)[2]) {
         acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
         acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -555,10 +653,10 @@ struct EpiC {
             ds[e] = 100.0f * s1 * q * pu[e >> 2][e & 3] * dv;
             dt[e] = du[e] * osc;
         }
-        if (cx.valid) {
-            float* ps = dsout + cx.row + 32 * c + 4 * cx.g;
-            *(f32x4*)ps = (f32x4){ds[0], ds[1], ds[2], ds[3]};
-            *(f32x4*)(ps + 16) = (f32x4){ds[4], ds[5], ds[6], ds[7]};
+        {
+            float* ps = dsout + cx.srow + 32 * c + 4 * cx.g;
+            st4g(ps, (f32x4){ds[0], ds[1], ds[2], ds[3]});
+            st4g((ps + 16), (f32x4){ds[4], ds[5], ds[6], ds[7]});
         }
         if (top) {
             if (!cx.valid) {
@@ -568,17 +666,25 @@ struct EpiC {
             col_reduce(cx, c, du);
             return;
         }
-        if (cx.valid) {
-            float* pt = dtout + cx.row + 32 * c + 4 * cx.g;
-            *(f32x4*)pt = (f32x4){dt[0], dt[1], dt[2], dt[3]};
-            *(f32x4*)(pt + 16) = (f32x4){dt[4], dt[5], dt[6], dt[7]};
+        {
+            float* pt = dtout + cx.srow + 32 * c + 4 * cx.g;
+            st4g(pt, (f32x4){dt[0], dt[1], dt[2], dt[3]});
+            st4g((pt + 16), (f32x4){dt[4], dt[5], dt[6], dt[7]});
         }
-        split8(dt, Bn.h[c], Bn.l[c]);
     }
 };
 
 // descending sweep: dX_l arrives in the accumulators;  dZ_{l-1} = s_{l-1} (.) dX_l + dS_{l-1}
 struct EpiD {
+    static constexpr bool NEXT_FROM_MEM = true;      // see EpiC: the next operand dZ_{l-1} is re-read from the rows just stored
+    __device__ __forceinline__ void load_next(const Ctx& cx, BReg& B) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const f32x4 v0 = ld4g(dzout + cx.row + 32 * ks + 4 * cx.g), v1 = ld4g(dzout + cx.row + 32 * ks + 16 + 4 * cx.g);
+            const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            split8(v, B.h[ks], B.l[ks]);
+        }
+    }
     const float* xin;      // X_l rows
     float kx;
     const float* dsin;     // dS_{l-1} rows
@@ -586,14 +692,17 @@ struct EpiD {
     bool first;            // layer 8: accumulators start from w8 (x) d sdf (a rank-1 term); also sums d sdf . X_8
     const float* w8;
     float dsdf;
-    f32x4 px[2], pd[2];
-    __device__ __forceinline__ void prefetch(const Ctx& cx, int c) {
+    f32x4 px[2], pd[2], nx[2], nd[2];
+    __device__ __forceinline__ int prefetch(const Ctx& cx, int c) {
         const int col = 32 * c + 4 * cx.g;
-        px[0] = ld4g(xin + cx.row + col);
-        px[1] = ld4g(xin + cx.row + col + 16);
-        pd[0] = ld4g(dsin + cx.row + col);
-        pd[1] = ld4g(dsin + cx.row + col + 16);
+        nx[0] = ld4g(xin + cx.row + col);
+        nx[1] = ld4g(xin + cx.row + col + 16);
+        nd[0] = ld4g(dsin + cx.row + col);
+        nd[1] = ld4g(dsin + cx.row + col + 16);
+        return 4;
     }
+    __device__ __forceinline__ void rotate() { px[0] = nx[0]; px[1] = nx[1]; pd[0] = nd[0]; pd[1] = nd[1]; }
+    __device__ __forceinline__ void touch() { touch4(px[0]); touch4(px[1]); touch4(pd[0]); touch4(pd[1]); }
     __device__ __forceinline__ void init(const Ctx& cx, int c, f32x4 (&acc)[2]) {
         acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
         acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -607,12 +716,11 @@ struct EpiD {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
             dz[e] = (1.0f - one_minus_sig(px[e >> 2][e & 3], kx)) * acc[e >> 2][e & 3] + pd[e >> 2][e & 3];
-        if (cx.valid) {
-            float* pz = dzout + cx.row + 32 * c + 4 * cx.g;
-            *(f32x4*)pz = (f32x4){dz[0], dz[1], dz[2], dz[3]};
-            *(f32x4*)(pz + 16) = (f32x4){dz[4], dz[5], dz[6], dz[7]};
+        {
+            float* pz = dzout + cx.srow + 32 * c + 4 * cx.g;
+            st4g(pz, (f32x4){dz[0], dz[1], dz[2], dz[3]});
+            st4g((pz + 16), (f32x4){dz[4], dz[5], dz[6], dz[7]});
         }
-        split8(dz, Bn.h[c], Bn.l[c]);
         if (first) {            // the value sweep's part of the sdf row's gradient: sum over points of d sdf . X_8
             float r[8];
 #pragma unroll
@@ -625,9 +733,9 @@ struct EpiD {
 __global__ __launch_bounds__(TF_THREADS) void k_tf_sdf_bwd(TfArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Ctx cx;
-    ctx_setup(cx, smem, a.wpack, a.P, BWD_CHUNKS, 64, BWD_SHIFT);
-    const size_t PL = (size_t)a.P * HID;
-    build_bin(cx, a.arena + off_BB0(PL) + (size_t)a.P * E_PE);     // dG
+    ctx_setup(cx, smem, a.wpack, a.P, BWD_CHUNKS, 64, BWD_SHIFT, a.arena + 46 * (size_t)(a.P + 1) * HID + 117 * (size_t)a.P);
+    const size_t R1 = (size_t)(a.P + 1) * HID;
+    build_bin(cx, a.arena + off_dG(R1, a.P));
     if (threadIdx.x < 257) cx.redf[threadIdx.x] = 0.0f;
     tf_prologue(cx);
     BReg Bcur, Bnext;
@@ -636,12 +744,12 @@ __global__ __launch_bounds__(TF_THREADS) void k_tf_sdf_bwd(TfArgs a) {
     // ---- ascending: the adjoint of the gradient sweep
     for (int l = 0; l <= 7; ++l) {
         EpiC ep;
-        ep.xin = a.arena + off_BB(PL, l + 1);
+        ep.xin = a.arena + off_X(R1, l + 1);
         ep.kx = l == 3 ? K2 / R2 : K2;
         ep.top = l == 7;
-        ep.uin = l == 7 ? a.w8 : a.arena + off_U(PL, l);
-        ep.dtout = a.arena + off_BB(PL, l < 7 ? l + 1 : 8) + PL;
-        ep.dsout = a.arena + off_dS(PL, l);
+        ep.uin = l == 7 ? a.w8 : a.arena + off_U(R1, l);
+        ep.dtout = a.arena + off_dT(R1, l < 7 ? l + 1 : 7);
+        ep.dsout = a.arena + off_dS(R1, l);
         ep.osc = l == 3 ? R2 : 1.0f;
         tf_layer<EpiC, 8, true>(cx, ep, 8, l > 0, l == 0 || l == 4, Bcur, Bnext);
     }
@@ -663,10 +771,10 @@ __global__ __launch_bounds__(TF_THREADS) void k_tf_sdf_bwd(TfArgs a) {
     }
     for (int l = 8; l >= 1; --l) {
         EpiD ep;
-        ep.xin = a.arena + off_BB(PL, l);
+        ep.xin = a.arena + off_X(R1, l);
         ep.kx = l == 4 ? K2 / R2 : K2;
-        ep.dsin = a.arena + off_dS(PL, l - 1);
-        ep.dzout = a.arena + off_AB(PL, l - 1);
+        ep.dsin = a.arena + off_dS(R1, l - 1);
+        ep.dzout = a.arena + off_dZ(R1, l - 1);
         ep.first = l == 8;
         ep.w8 = a.w8;
         ep.dsdf = dsdf;
@@ -704,7 +812,7 @@ __global__ __launch_bounds__(512) void k_tf_pack_col(const float* const* __restr
         for (int r = threadIdx.x; r < BIAS_LD; r += 512) bias_all[l * BIAS_LD + r] = r < (l < 4 ? HID : 3) ? B[l][r] : 0.f;
 }
 
-// stash (floats), n points: H(l) l = 0..3 [n][256] at l * 256 n (layer l's ReLU output); dZ(l) l = 0..3 at (4 + l) * 256 n
+// stash (floats), n points, N1 = (n + 1) * 256 (pad rows as above): H(l) l = 0..3 at l N1 (layer l's ReLU output); dZ(l) at (4 + l) N1
 struct ColArgs {
     const char* wpack;
     const float* bias;     // [5][288]
@@ -721,14 +829,22 @@ struct ColArgs {
 };
 
 struct EpiR {
+    static constexpr bool NEXT_FROM_MEM = false;
     const float* bias;
     float* hout;
     bool last;
     float* rgb;
-    __device__ __forceinline__ void prefetch(const Ctx&, int) {}
-    __device__ __forceinline__ void init(const Ctx& cx, int c, f32x4 (&acc)[2]) {
-        acc[0] = ld4g(bias + 32 * c + 4 * cx.g);
-        acc[1] = ld4g(bias + 32 * c + 16 + 4 * cx.g);
+    f32x4 pb[2], nb[2];
+    __device__ __forceinline__ int prefetch(const Ctx& cx, int c) {
+        nb[0] = ld4g(bias + 32 * c + 4 * cx.g);
+        nb[1] = ld4g(bias + 32 * c + 16 + 4 * cx.g);
+        return 2;
+    }
+    __device__ __forceinline__ void rotate() { pb[0] = nb[0]; pb[1] = nb[1]; }
+    __device__ __forceinline__ void touch() { touch4(pb[0]); touch4(pb[1]); }
+    __device__ __forceinline__ void init(const Ctx&, int, f32x4 (&acc)[2]) {
+        acc[0] = pb[0];
+        acc[1] = pb[1];
     }
     __device__ __forceinline__ void run(const Ctx& cx, int c, const f32x4 (&acc)[2], BReg& Bn) {
         if (last) {
@@ -741,10 +857,10 @@ struct EpiR {
         float h[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) h[e] = __builtin_fmaxf(acc[e >> 2][e & 3], 0.0f);
-        if (cx.valid) {
-            float* p = hout + cx.row + 32 * c + 4 * cx.g;
-            *(f32x4*)p = (f32x4){h[0], h[1], h[2], h[3]};
-            *(f32x4*)(p + 16) = (f32x4){h[4], h[5], h[6], h[7]};
+        {
+            float* p = hout + cx.srow + 32 * c + 4 * cx.g;
+            st4g(p, (f32x4){h[0], h[1], h[2], h[3]});
+            st4g((p + 16), (f32x4){h[4], h[5], h[6], h[7]});
         }
         if (c < 8) split8(h, Bn.h[c], Bn.l[c]);
     }
@@ -753,9 +869,9 @@ struct EpiR {
 __global__ __launch_bounds__(TF_THREADS) void k_tf_col_fwd(ColArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Ctx cx;
-    ctx_setup(cx, smem, a.wpack, a.n, COL_FWD, COL_FWD, 0);
+    ctx_setup(cx, smem, a.wpack, a.n, COL_FWD, COL_FWD, 0, a.stash + (size_t)(a.n + 1) * 8 * HID);
     cx.noreg_hi = 0; cx.in0_lo = 0; cx.in0_hi = 8; cx.in1_lo = cx.in1_hi = 0;
-    const size_t NL = (size_t)a.n * HID;
+    const size_t NL = (size_t)(a.n + 1) * HID;
     build_bin(cx, a.xa, COL_IN);
     tf_prologue(cx);
     BReg Bcur, Bnext;
@@ -778,44 +894,47 @@ __global__ __launch_bounds__(TF_THREADS) void k_tf_col_fwd(ColArgs a) {
 
 // backward: dH_{l-1} arrives in the accumulators; dZ_{l-1} = [H_{l-1} > 0] dH_{l-1};  last product: d feat (256 rows) and d XA (6)
 struct EpiRb {
+    static constexpr bool NEXT_FROM_MEM = false;
     const float* hin;
     float* dzout;
     bool final;
     float* dfeat;
     float* dxa;
-    f32x4 ph[2];
-    __device__ __forceinline__ void prefetch(const Ctx& cx, int c) {
+    f32x4 ph[2], nh[2];
+    __device__ __forceinline__ int prefetch(const Ctx& cx, int c) {
         if (!final) {
-            ph[0] = ld4g(hin + cx.row + 32 * c + 4 * cx.g);
-            ph[1] = ld4g(hin + cx.row + 32 * c + 16 + 4 * cx.g);
+            nh[0] = ld4g(hin + cx.row + 32 * c + 4 * cx.g);
+            nh[1] = ld4g(hin + cx.row + 32 * c + 16 + 4 * cx.g);
+            return 2;
         }
+        return 0;
     }
+    __device__ __forceinline__ void rotate() { ph[0] = nh[0]; ph[1] = nh[1]; }
+    __device__ __forceinline__ void touch() { touch4(ph[0]); touch4(ph[1]); }
     __device__ __forceinline__ void init(const Ctx&, int, f32x4 (&acc)[2]) {
         acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
         acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     __device__ __forceinline__ void run(const Ctx& cx, int c, const f32x4 (&acc)[2], BReg& Bn) {
         if (final) {
-            if (cx.valid) {
-                if (c < 8) {
-                    float* p = dfeat + cx.row + 32 * c + 4 * cx.g;
-                    *(f32x4*)p = acc[0];
-                    *(f32x4*)(p + 16) = acc[1];
-                } else {
+            if (c < 8) {
+                float* p = (cx.valid ? dfeat + cx.row : cx.trash) + 32 * c + 4 * cx.g;   // caller-owned rows: no pad row
+                st4g(p, acc[0]);
+                st4g((p + 16), acc[1]);
+            } else if (cx.valid) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (4 * cx.g + i < COL_IN) dxa[cx.prow * COL_IN + 4 * cx.g + i] = acc[0][i];
-                }
+                for (int i = 0; i < 4; ++i)
+                    if (4 * cx.g + i < COL_IN) dxa[cx.prow * COL_IN + 4 * cx.g + i] = acc[0][i];
             }
             return;
         }
         float dz[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) dz[e] = ph[e >> 2][e & 3] > 0.0f ? acc[e >> 2][e & 3] : 0.0f;
-        if (cx.valid) {
-            float* p = dzout + cx.row + 32 * c + 4 * cx.g;
-            *(f32x4*)p = (f32x4){dz[0], dz[1], dz[2], dz[3]};
-            *(f32x4*)(p + 16) = (f32x4){dz[4], dz[5], dz[6], dz[7]};
+        {
+            float* p = dzout + cx.srow + 32 * c + 4 * cx.g;
+            st4g(p, (f32x4){dz[0], dz[1], dz[2], dz[3]});
+            st4g((p + 16), (f32x4){dz[4], dz[5], dz[6], dz[7]});
         }
         if (c < 8) split8(dz, Bn.h[c], Bn.l[c]);
     }
@@ -824,9 +943,9 @@ struct EpiRb {
 __global__ __launch_bounds__(TF_THREADS) void k_tf_col_bwd(ColArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Ctx cx;
-    ctx_setup(cx, smem, a.wpack, a.n, COL_TOTAL - COL_FWD, 0, COL_FWD);
+    ctx_setup(cx, smem, a.wpack, a.n, COL_TOTAL - COL_FWD, 0, COL_FWD, a.stash + (size_t)(a.n + 1) * 8 * HID);
     cx.noreg_hi = 0; cx.in0_lo = cx.in0_hi = cx.in1_lo = cx.in1_hi = 0;
-    const size_t NL = (size_t)a.n * HID;
+    const size_t NL = (size_t)(a.n + 1) * HID;
     tf_prologue(cx);
     BReg Bcur, Bnext;
     // the sigmoid and the 3-row last layer by hand: dz4 = d rgb . rgb (1 - rgb);  dH_3 = W_4^T dz4;  dZ_3 = [H_3 > 0] dH_3
@@ -842,7 +961,6 @@ __global__ __launch_bounds__(TF_THREADS) void k_tf_col_bwd(ColArgs a) {
     }
     {
         const float* h3 = a.stash + 3 * NL + cx.row;
-        float* dz3 = a.stash + 7 * NL + cx.row;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             const int col = 32 * ks + 4 * cx.g;
@@ -856,9 +974,10 @@ __global__ __launch_bounds__(TF_THREADS) void k_tf_col_bwd(ColArgs a) {
             float v[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = h0[e] > 0.0f ? d0[e] : 0.0f; v[4 + e] = h1[e] > 0.0f ? d1[e] : 0.0f; }
-            if (cx.valid) {
-                *(f32x4*)(dz3 + col) = (f32x4){v[0], v[1], v[2], v[3]};
-                *(f32x4*)(dz3 + col + 16) = (f32x4){v[4], v[5], v[6], v[7]};
+            {
+                float* pd = a.stash + 7 * NL + cx.srow + col;
+                st4g(pd, (f32x4){v[0], v[1], v[2], v[3]});
+                st4g((pd + 16), (f32x4){v[4], v[5], v[6], v[7]});
             }
             split8(v, Bcur.h[ks], Bcur.l[ks]);
             Bnext.h[ks] = Bnext.l[ks] = zero_frag();
@@ -878,7 +997,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tf_col_bwd(ColArgs a) {
 }  // namespace
 
 extern "C" int mp_tf_sdf_sizes(int P, long long* arena_floats, long long* pack_bytes) {
-    if (arena_floats) *arena_floats = (long long)P * (47LL * HID + 3 * E_PE);
+    if (arena_floats) *arena_floats = 46LL * (P + 1) * HID + 117LL * P + 256;
     if (pack_bytes) *pack_bytes = (long long)CH_TOTAL * CH_BYTES;
     return 0;
 }
@@ -907,7 +1026,7 @@ extern "C" int mp_tf_sdf_bwd(const void* wpack, const float* w8, float* arena, i
 }
 
 extern "C" int mp_tf_col_sizes(int n, long long* stash_floats, long long* pack_bytes) {
-    if (stash_floats) *stash_floats = (long long)n * 8 * HID;
+    if (stash_floats) *stash_floats = 8LL * (n + 1) * HID + 256;
     if (pack_bytes) *pack_bytes = (long long)COL_TOTAL * CH_BYTES;
     return 0;
 }

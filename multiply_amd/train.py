@@ -62,6 +62,26 @@ def gemm_tn(A, lda, B, ldb, Cm, ldc, M, N, K, colsum=None, colsum_rows=0):
     _chk(fn(A, lda, B, ldb, Cm, ldc, M, N, K, colsum, colsum_rows, hip.stream()), "mp_gemm_tn")
 
 
+class MpTnGroup(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("colsum", C.c_void_p), ("lda", C.c_int),
+                ("ldb", C.c_int), ("ldc", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("colsum_rows", C.c_int),
+                ("pad_", C.c_int)]
+
+
+def tn_group(A, lda, B, ldb, Cm, ldc, M, N, K, colsum=None, colsum_rows=0):
+    """one contraction of a grouped launch (mp_gemm_tn_bf16x3_grouped); pointers as returned by _p() / off()"""
+    return MpTnGroup(A.value, B.value, Cm.value, colsum.value if colsum is not None else None, lda, ldb, ldc, M, N, K,
+                     colsum_rows, 0)
+
+
+def gemm_tn_grouped(groups):
+    """all weight-gradient contractions of `groups` in ONE launch (aligned 128-multiples only); chunks of 24"""
+    for i in range(0, len(groups), 24):
+        chunk = groups[i:i + 24]
+        arr = (MpTnGroup * len(chunk))(*chunk)
+        _chk(hip.lib().mp_gemm_tn_bf16x3_grouped(arr, len(chunk), hip.stream()), "mp_gemm_tn_bf16x3_grouped")
+
+
 def off(t, n_floats):
     """device pointer `n_floats` floats into tensor t"""
     return C.c_void_p(t.data_ptr() + 4 * n_floats)
@@ -568,51 +588,69 @@ class ImplicitTrainFused(ImplicitTrainRev):
         dev = x.device
         self.fs = fs = fused_sdf_state(net, lins).refresh(cond_vec)
         self.lins, self.nl = fs.lins, len(fs.lins)
-        self.arena = torch.empty(fs.arena_per_point * P, dtype=F32, device=dev)
-        PL = 256 * P
-        self.o_AB = lambda l: l * 2 * PL
-        self.o_BB = lambda l: 16 * PL + (l - 1) * 2 * PL
-        self.o_BB0 = 47 * PL
-        self.o_G = 47 * PL + 2 * E * P
+        arena = C.c_longlong(0)
+        _chk(L.mp_tf_sdf_sizes(P, C.byref(arena), None), "mp_tf_sdf_sizes")
+        self.arena = torch.empty(int(arena.value), dtype=F32, device=dev)
+        R1 = 256 * (P + 1)                               # every [P][256] stash tensor carries one pad row (csrc/tfuse.hip)
+        self.o_dZ = lambda l: l * R1
+        self.o_V = lambda l: (8 + l) * R1
+        self.o_X = lambda l: (15 + l) * R1
+        self.o_dT = lambda l: (23 + l) * R1
+        self.o_IN, self.o_dG, self.o_G = 46 * R1, 46 * R1 + E * P, 46 * R1 + 2 * E * P
         r2 = 1.0 / math.sqrt(2.0)
-        _chk(L.mp_tr_pe(_p(x), 3, P, net.multires, 0, C.c_float(1.0), off(self.arena, self.o_BB0), E, 0, st), "mp_tr_pe")
-        self.feat = torch.empty(P, 256, dtype=F32, device=dev)      # columns 1.. of the reference's output
-        self.sdf = torch.empty(P, dtype=F32, device=dev)            # column 0
+        _chk(L.mp_tr_pe(_p(x), 3, P, net.multires, 0, C.c_float(1.0), off(self.arena, self.o_IN), E, 0, st), "mp_tr_pe")
+        self.feat = torch.empty(P + 1, 256, dtype=F32, device=dev)  # columns 1.. of the reference's output (+ the pad row)
+        self.sdf = torch.empty(P + 1, dtype=F32, device=dev)        # column 0
         self.w8 = fs.lins[8].W                          # row 0 = the sdf row of the last layer
         _chk(L.mp_tf_sdf_fwd(_p(fs.wpack), _p(fs.bias_all), _p(self.w8), _p(self.arena), P, _p(self.feat), _p(self.sdf), st),
              "mp_tf_sdf_fwd")
         # the skip connection re-injects the Fourier features into layer 4's input (times 1/sqrt 2): columns 217.. of X_4
-        _chk(L.mp_tr_copy_cols(off(self.arena, self.o_BB0), E, 0, off(self.arena, self.o_BB(4)), 256, 256 - E, P, E, C.c_float(r2), 0,
+        _chk(L.mp_tr_copy_cols(off(self.arena, self.o_IN), E, 0, off(self.arena, self.o_X(4)), 256, 256 - E, P, E, C.c_float(r2), 0,
                                st), "mp_tr_copy_cols")
         self.grad = torch.empty(P, 3, dtype=F32, device=dev)
         _chk(L.mp_tr_pe_grad_fwd(_p(x), P, net.multires, off(self.arena, self.o_G), E, _p(self.grad), st), "mp_tr_pe_grad_fwd")
 
+    @staticmethod
+    def _launch(groups):
+        if TRAIN_PRECISION == "bf16x3":
+            gemm_tn_grouped(groups)
+        else:                                   # exact-fp32 cross-check: one launch per contraction
+            for g in groups:
+                gemm_tn(C.c_void_p(g.A), g.lda, C.c_void_p(g.B), g.ldb, C.c_void_p(g.C), g.ldc, g.M, g.N, g.K,
+                        C.c_void_p(g.colsum) if g.colsum else None, g.colsum_rows)
+
     @property
     def out(self):
         """the reference's [P][257] layout (column 0 = sdf), assembled on demand (tests; the trainer reads feat / sdf)"""
-        return torch.cat([self.sdf[:, None], self.feat], 1)
+        return torch.cat([self.sdf[:self.P, None], self.feat[:self.P]], 1)
 
-    def backward(self, dfeat, dsdf, dgrad, want_dx=False):
-        """dfeat [P][256], dsdf [P], dgrad [P][3] -> dW / db of every layer; returns d cond"""
+    def backward(self, dfeat, dsdf, dgrad, want_dx=False, tn_groups=None):
+        """dfeat [P][256], dsdf [P], dgrad [P][3] -> dW / db of every layer; returns d cond.  tn_groups (a list): the aligned
+        weight-gradient contractions are appended to it instead of launched (the caller launches them grouped)"""
         assert not want_dx, "the fused SDF kernels do not produce the adjoint of the input points"
         L, st = hip.lib(), hip.stream()
         net, P, E, lins, fs, A = self.net, self.P, self.E, self.lins, self.fs, self.arena
         dev = dfeat.device
         r2 = 1.0 / math.sqrt(2.0)
-        PL = 256 * P
-        dG = off(A, self.o_BB0 + E * P)
+        dG = off(A, self.o_dG)
         _chk(L.mp_tr_pe_grad_bwd(_p(self.x), P, net.multires, _p(dgrad), off(A, self.o_G), E, dG, E, None, st), "mp_tr_pe_grad_bwd")
         lw8 = lins[8]                                   # the sdf row's gradient goes straight into row 0 of dW_8 / db_8
         _chk(L.mp_tf_sdf_bwd(_p(fs.wpack), _p(self.w8), _p(A), P, _p(dfeat), _p(dsdf), _p(lw8.dW), _p(lw8.db), st), "mp_tf_sdf_bwd")
-        _chk(L.mp_tr_copy_cols(dG, E, 0, off(A, self.o_BB(4) + PL), 256, 256 - E, P, E, C.c_float(r2), 0, st), "mp_tr_copy_cols")
-        # weight gradients: both sweeps' contributions of a layer in ONE contraction over 2 P rows (bias gradient: the first P)
+        _chk(L.mp_tr_copy_cols(dG, E, 0, off(A, self.o_dT(4)), 256, 256 - E, P, E, C.c_float(r2), 0, st), "mp_tr_copy_cols")
+        # weight gradients  dW_l += dZ_l^T X_l (value sweep; bias gradient = its column sums) + V_l^T dT_l (gradient sweep)
         lw0 = lins[0]
-        gemm_tn(off(A, self.o_AB(0)), 256, off(A, self.o_BB0), E, _p(lw0.dW), lw0.in_dim, 256, E, 2 * P, _p(lw0.db), P)
+        gemm_tn(off(A, self.o_dZ(0)), 256, off(A, self.o_IN), E, _p(lw0.dW), lw0.in_dim, 256, E, P, _p(lw0.db), P)
+        gemm_tn(off(A, self.o_V(0)), 256, dG, E, _p(lw0.dW), lw0.in_dim, 256, E, P)
+        groups = tn_groups if tn_groups is not None else []
         for l in range(1, 8):
             lw = lins[l]                                # (layer 3: 217 rows contracted as 256, see LinP)
-            gemm_tn(off(A, self.o_AB(l)), 256, off(A, self.o_BB(l)), 256, _p(lw.dW_full), lw.in_dim, lw.dW_full.shape[0], lw.in_dim,
-                    2 * P, _p(lw.db_full), P)
-        gemm_tn(_p(dfeat), 256, off(A, self.o_BB(8)), 256, off(lw8.dW, 256), 256, 256, 256, P, off(lw8.db, 1), P)   # feature rows
+            rows = lw.dW_full.shape[0]
+            groups.append(tn_group(off(A, self.o_dZ(l)), 256, off(A, self.o_X(l)), 256, _p(lw.dW_full), lw.in_dim, rows, lw.in_dim, P,
+                                   _p(lw.db_full), P))
+            groups.append(tn_group(off(A, self.o_V(l)), 256, off(A, self.o_dT(l)), 256, _p(lw.dW_full), lw.in_dim, rows, lw.in_dim, P))
+        groups.append(tn_group(_p(dfeat), 256, off(A, self.o_X(8)), 256, off(lw8.dW, 256), 256, 256, 256, P, off(lw8.db, 1), P))
+        if tn_groups is None:
+            self._launch(groups)
         _chk(L.mp_tr_hoist_bwd(_p(lw0.db), 256, lw0.in_dim, E, net.cond_dim, _p(self.cond), _p(lw0.dW), st), "mp_tr_hoist_bwd")
         dcond = torch.zeros(net.cond_dim, dtype=F32, device=dev)
         gemm_tn(_p(lw0.db), 1, off(lw0.W, E), lw0.in_dim, _p(dcond), net.cond_dim, 1, net.cond_dim, 256)
@@ -771,16 +809,19 @@ class RenderTrainFused:
         dev = XA.device
         self.cs = cs = fused_col_state(net, lins).refresh(cond_vec)
         self.lins = cs.lins
-        self.stash = torch.empty(cs.stash_per_point * n, dtype=F32, device=dev)
+        stash = C.c_longlong(0)
+        _chk(L.mp_tf_col_sizes(n, C.byref(stash), None), "mp_tf_col_sizes")
+        self.stash = torch.empty(int(stash.value), dtype=F32, device=dev)
         self.rgb = torch.empty(n, 3, dtype=F32, device=dev)
         _chk(L.mp_tf_col_fwd(_p(cs.wpack), _p(cs.bias_all), _p(self.stash), _p(feat), _p(XA), n, _p(self.rgb), st), "mp_tf_col_fwd")
 
-    def backward(self, drgb, dXA, dfeat):
-        """drgb [n][3] -> dW / db, dXA [n][6] and rows [0, n) of dfeat [.][256] (both written); returns d pose-embedding"""
+    def backward(self, drgb, dXA, dfeat, tn_groups=None):
+        """drgb [n][3] -> dW / db, dXA [n][6] and rows [0, n) of dfeat [.][256] (both written); returns d pose-embedding.
+        tn_groups: see ImplicitTrainFused.backward"""
         L, st = hip.lib(), hip.stream()
         n, lins, cs, S = self.n, self.lins, self.cs, self.stash
         dev = drgb.device
-        NL = 256 * n
+        NL = 256 * (n + 1)                               # one pad row per stash tensor
         dz4 = torch.empty(n, 3, dtype=F32, device=dev)
         _chk(L.mp_tf_col_bwd(_p(cs.wpack), _p(S), _p(lins[4].W), _p(self.rgb), _p(drgb), n, _p(dfeat), _p(dXA), _p(dz4), st),
              "mp_tf_col_bwd")
@@ -788,10 +829,13 @@ class RenderTrainFused:
         dZ = lambda l: off(S, (4 + l) * NL)
         lw0 = lins[0]
         gemm_tn(dZ(0), 256, _p(self.XA), 6, _p(lw0.dW), lw0.in_dim, 256, 6, n, _p(lw0.db), n)
-        gemm_tn(dZ(0), 256, _p(self.feat), 256, off(lw0.dW, 14), lw0.in_dim, 256, 256, n)
+        groups = tn_groups if tn_groups is not None else []
+        groups.append(tn_group(dZ(0), 256, _p(self.feat), 256, off(lw0.dW, 14), lw0.in_dim, 256, 256, n))
         for l in range(1, 4):
             lw = lins[l]
-            gemm_tn(dZ(l), 256, H(l - 1), 256, _p(lw.dW), 256, 256, 256, n, _p(lw.db), n)
+            groups.append(tn_group(dZ(l), 256, H(l - 1), 256, _p(lw.dW), 256, 256, 256, n, _p(lw.db), n))
+        if tn_groups is None:
+            ImplicitTrainFused._launch(groups)
         lw4 = lins[4]
         gemm_tn(_p(dz4), 3, H(3), 256, _p(lw4.dW), 256, 3, 256, n, _p(lw4.db), n)
         # the hoisted pose embedding: dW_0[:, 6:14] += db_0 (x) pose8 ; d pose8 = W_0[:, 6:14]^T db_0 ; then lin_pose's own gradients
@@ -1098,8 +1142,9 @@ class TrainGraph:
                 dZ8 = None
                 dfeat = torch.empty(Pt, 256, **f32)
                 dfeat[npts:].zero_()   # the eikonal points have no colour path
+                tn_groups = []             # the person's aligned weight-gradient contractions: ONE grouped launch below
                 if isinstance(rt, RenderTrainFused):
-                    rt.backward(drgb_l[n], dXA, dfeat)
+                    rt.backward(drgb_l[n], dXA, dfeat, tn_groups=tn_groups)
                 else:
                     rt.backward(drgb_l[n], dXA, _p(dfeat), 256, feat_accumulate=False)
             else:
@@ -1112,7 +1157,8 @@ class TrainGraph:
                 dg = d_grad_theta.reshape(-1, 3)[n * N_EIKONAL:(n + 1) * N_EIKONAL].contiguous().float()
                 _chk(L.mp_tr_eik_bwd(Pt, npts, N_EIKONAL, _p(dg), _p(dZ8), _p(dgrad), st), "mp_tr_eik_bwd")
             if fusedp:
-                dcond = it.backward(dfeat, dsdf_l[n], dgrad)
+                dcond = it.backward(dfeat, dsdf_l[n], dgrad, tn_groups=tn_groups)
+                ImplicitTrainFused._launch(tn_groups)
             else:
                 dcond = it.backward(dZ8, dgrad, want_dx=self.pose_grad) if rev else it.backward(dZ8, want_dx=self.pose_grad)
             self.ts.finish_group(p)                                   # one batched weight-norm adjoint for the person's two nets
