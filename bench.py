@@ -88,9 +88,10 @@ def host_cpu():
     return torch.get_num_threads(), (len(cores) or None), model
 
 
-def cpu_baseline(model, inp, tables, sc, n_samples, n_rays=2048):
+def cpu_baseline(model, inp, tables, sc, n_samples, n_rays=8192):
     """Times the CPU oracle on a bounded sample of the same frame: `n_rays` rays = a centred block of image rows that crosses
-    both bodies, every pixel of those rows (>= 2 k rays, extrapolated and labelled).  Also returns the
+    both bodies, every pixel of those rows (>= 16 k rays or 3 frames asked, 8 192 taken by default = ~8 min of
+    oracle so that the whole bench.py run stays inside the driver's timeout; extrapolated and labelled).  Also returns the
     GPU-vs-oracle pixel error on that sample."""
     from oracle import multiply_oracle as O
     H = W = int(round(np.sqrt(inp["uv"].shape[1])))
@@ -111,9 +112,19 @@ def cpu_baseline(model, inp, tables, sc, n_samples, n_rays=2048):
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     cfg = O.SamplerCfg(N_samples=n_samples, N_samples_eval=max(128, n_samples))
     oracle = O.MultiplyOracle(sd, tables, sc["smpl_params"][0, :, 76:], cfg)
+    # the oracle in chunks of one convergence group (512 rays = the reference's pixel_per_batch chunk: the sampler's convergence
+    # vote spans a call, multiply.py / ray_sampler.py:137), exactly the device's groups; bounded memory at any sample size
+    G = int(model.convergence_group or len(sel))
+    parts = []
     t0 = time.time()
-    want = oracle.forward_eval(sub, hit)
+    for c0 in range(0, len(sel), G):
+        chunk = dict(sub)
+        chunk["uv"] = sub["uv"][:, c0:c0 + G]
+        hg = [h[(h >= c0) & (h < c0 + G)] - c0 for h in hit]
+        hg = [h if len(h) else torch.zeros(1, dtype=torch.long) for h in hg]        # multiply.py:262-263 per chunk
+        parts.append(oracle.forward_eval(chunk, hg)["rgb_values"])
     dt = time.time() - t0
+    want = {"rgb_values": torch.cat(parts, 0)}
     err = (got["rgb_values"].cpu() - want["rgb_values"]).abs()
     err = err[~err.isnan()]
     threads, phys, name = host_cpu()
@@ -244,7 +255,7 @@ def train_cpu_baseline(model, gin, inp, tables, sc, n_samples, rays=512, iters=3
     tl = torch.mean(torch.square((inp["smpl_pose"] + 0.01) - inp["smpl_pose"])).reshape(())      # multiply.py:242-243
     names = [k for k, v in sd.items() if v.requires_grad]
     times, parity = [], {}
-    for i in range(iters):
+    for i in range(iters + 1):                       # the first (cold: allocator, thread pool) is compared but not timed
         t0 = time.time()
         want = oracle.forward_train(oin, hit, z_given, draws)
         want.update(fg_rgb_values_each_person_list=[], index_in_surface=None, epoch=301, temporal_loss=tl,
@@ -276,13 +287,23 @@ def train_cpu_baseline(model, gin, inp, tables, sc, n_samples, rays=512, iters=3
                       "parity_grad_tensors": n_cmp, "parity_grad_tensors_below_1e-7": n_tiny,
                       "parity_state_entries_without_gradient": n_nograd, "parity_forward_max_abs": fwd}
         del gw
-    dt = float(np.mean(times))
+    dt = float(np.mean(times[1:]))
     threads, phys, name = host_cpu()
     return {"value": 1e3 * dt, "unit": "ms/train-iter", "cores": threads, "physical_cores": phys, "cpu_model": name,
-            "kind": "port", "rays": rays, "iters": iters, **parity,
-            "sample": f"mean of {iters} iterations on {rays} rays (hit rays {[int(len(h)) for h in hit]}): forward from the "
-                      f"sampler's depths + loss + autograd on the fp32 torch oracle, {threads} threads; per iteration "
-                      f"{[round(t, 1) for t in times]} s"}
+            "kind": "port", "rays": rays, "iters": iters, "discarded_warmup_iters": 1, **parity,
+            "sample": f"mean of {iters} iterations (after one discarded cold iteration, {round(times[0], 1)} s) on {rays} rays "
+                      f"(hit rays {[int(len(h)) for h in hit]}): forward from the sampler's depths + loss + autograd on the fp32 "
+                      f"torch oracle, {threads} threads; per iteration {[round(t, 1) for t in times[1:]]} s"}
+
+
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) over the sources of the eval-path kernels: what a committed PMC measurement is tied to"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("mlp.hip", "mlp_core.hpp", "geom.hip", "sampler.hip", "composite.hip", "common.hpp"):
+        with open(os.path.join(REPO, "multiply_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def relaunch_under_torchrun(n):
@@ -324,8 +345,8 @@ def main():
     ap.add_argument("--train-steps", type=int, default=10, help="timed training iterations for ms/train-iter (0 = skip)")
     ap.add_argument("--train-warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the CPU oracle's render sample")
-    ap.add_argument("--cpu-train-iters", type=int, default=3)
+    ap.add_argument("--cpu-rays", type=int, default=8192, help="rays of the CPU oracle's render sample (~1 min per 1000 on the box's host)")
+    ap.add_argument("--cpu-train-iters", type=int, default=5, help="timed oracle training iterations (one more, cold, is run first and discarded)")
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the frame-per-rank weak-scaling leg")
     ap.add_argument("--breakdown", action="store_true", help="print per-phase GPU times to stderr")
     args = ap.parse_args()
@@ -381,10 +402,16 @@ def main():
 
         KEEP = ("rgb_values", "normal_values", "fg_rgb_values")
 
+        gather_evs = []                      # (start, end) events around every image all_gather of the timed region
+
         def assemble(out):                   # ONE all_gather of the outputs the caller keeps (multiply_model.py:1045-1069)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             full = gather_rays_interleaved(torch.cat([out[k] for k in KEEP], dim=1), R, world, GROUP, GPR)
             for k, part in zip(KEEP, full.split([out[k].shape[1] for k in KEEP], dim=1)):
                 image[k] = part
+            e1.record()
+            gather_evs.append((e0, e1))
     else:
         gin, assemble = to_dev(inp), None
 
@@ -395,8 +422,20 @@ def main():
             assemble(o)
     torch.cuda.synchronize()
     model.phase_events = {}
+    if dist:
+        gather_evs.clear()
     elapsed, shaded, sdf_evals = timed_frames(model, gin, args.steps, barrier, assemble)
     model.profile = False
+    per_rank = None
+    if dist:
+        # what a scaling run is diagnosed with: every rank's own wall time per frame, its share of the rays and the time it
+        # spent inside the image all_gather (which includes waiting for the slowest rank)
+        mine = torch.tensor([1e3 * elapsed / args.steps, float(gin["uv"].shape[1]),
+                             sum(a.elapsed_time(b) for a, b in gather_evs) / max(len(gather_evs), 1)], device="cuda", dtype=torch.float64)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        td.all_gather(allr, mine)
+        per_rank = {"ms_per_step": [float(t[0]) for t in allr], "rays": [int(t[1]) for t in allr],
+                    "all_gather_ms_per_step": [float(t[2]) for t in allr]}
     elapsed = max_over_ranks(elapsed)
     render_stats = model.last_stats
     phases = model.phase_times_ms()
@@ -473,11 +512,25 @@ def main():
     traffic = None
     kernels = {"mlp_shade": ["k_mlp_fwdsave", "k_mlp_grad"] if model.shade_mode == "reverse" else ["k_mlp_shade"],
                "mlp_color": ["k_mlp_color"], "background": ["k_background"], "sampler_mlp_sdf": ["k_mlp_sdf"]}[dom]
-    pmc_file = next((os.path.join(REPO, "profiles", f) for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+    pmc_file = next((os.path.join(REPO, "profiles", f) for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json")
                      if os.path.exists(os.path.join(REPO, "profiles", f))), None)
+    traffic_note = None
     if pmc_file and args.res == 512 and args.samples == 128 and world == 1:
         with open(pmc_file) as f:
             pmc = json.load(f)                      # per-dispatch averages of ONE frame (bench.py --steps 1 --warmup 0)
+        # a committed measurement is attached only when it is a measurement of THIS tree on THIS workload (tools/write_profiles.py
+        # records both): the hash of the kernels' sources and the algorithmic work per launch of the profiled run
+        meta = pmc.pop("_meta", None)
+        want_hash = kernel_source_hash()
+        if meta is None:
+            traffic_note, pmc = f"{os.path.basename(pmc_file)} carries no _meta record (tree / workload of the profiled run unknown): not attached", {}
+        elif meta.get("kernel_source_sha16") != want_hash:
+            traffic_note, pmc = (f"{os.path.basename(pmc_file)} was measured on kernel sources {meta.get('kernel_source_sha16')}, this tree "
+                                 f"is {want_hash}: not attached"), {}
+        elif abs(meta.get("algorithmic_flop_per_launch", 0.0) / (flops[dom] / launches_per_frame) - 1.0) > 0.01 or \
+                meta.get("dominant") != dom:
+            traffic_note, pmc = (f"{os.path.basename(pmc_file)}: the profiled run's work per launch ({meta.get('dominant')}, "
+                                 f"{meta.get('algorithmic_flop_per_launch', 0.0):.4g} FLOP) differs from this run's: not attached"), {}
         rd = wr = 0.0
         for name, e in pmc.items():
             if any(k in name for k in kernels):
@@ -508,12 +561,14 @@ def main():
                        "parallelism": (f"ray-sharded dp{world}: one frame per step, convergence groups dealt on a diagonal lattice, "
                                        f"all_gather of the image on every rank") if dist else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": dom + " = " + " + ".join(kernels), "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                          "avg_launch_ms": 1e3 * per_launch_s, "launches_per_step": launches_per_frame,
                          "algorithmic_flop_per_launch": flops[dom] / launches_per_frame,
                          "note": "rank 0's share of the frame" if dist else None},
             "phases_ms_per_step": {k: v[1] / args.steps for k, v in phases.items()},
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if weak is not None:
             out["weak"] = weak
         if train is not None:

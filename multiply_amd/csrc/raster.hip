@@ -425,7 +425,9 @@ extern "C" int mp_raster_soft(const float* verts, int n_verts, const int* faces,
         hipLaunchKernelGGL(k_soft_bin<true>, dim3((n_faces + 255) / 256), dim3(256), 0, st, verts, faces, n_faces, cam, H, W, sp.sc,
                            sqrtf(blur_radius), tx, tile_n, offsets, list);
     const int lds = faces_per_pixel * 64 * 12 + 64 * (int)(sizeof(SoftTri) + sizeof(int));
-    MP_LDS_ATTR(k_soft_blend, lds);
+    // the attribute is set ONCE per device (MP_LDS_ATTR): to the largest size any call may ask for (K = SOFT_MAX_K), not to this
+    // call's -- a first call with K = 10 (11 KB) would otherwise leave a later K = 100 call (80 KB) above the 64 KB default
+    MP_LDS_ATTR(k_soft_blend, SOFT_MAX_K * 64 * 12 + 64 * (int)(sizeof(SoftTri) + sizeof(int)));
     hipLaunchKernelGGL(k_soft_blend, dim3(T), dim3(64), lds, st, verts, faces, colors, cam, H, W, sp, tx, offsets, list, image, sel);
     return (int)hipGetLastError();
 }

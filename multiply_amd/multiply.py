@@ -198,13 +198,16 @@ class Multiply(nn.Module):
             if not self.training:
                 b = self.density.beta
                 cache = self.__dict__.get("_eval_beta")
-                if cache is None or cache[0] != b._version or cache[1].device != b.device:
+                # keyed on the parameter OBJECT, its storage and its version: writes through .data and a replaced Parameter with the
+                # same version number must not leave a stale value behind (a load_state_dict bumps the version: copy_ in place)
+                key = (id(b), b.data_ptr(), b._version, str(b.device))
+                if cache is None or cache[0] != key:
                     val = (b.detach().abs() + self.density.beta_min).reshape(1).float().contiguous()   # caller's stream
                     ev = torch.cuda.Event()
                     ev.record(main)
                     side.wait_event(ev)          # once per parameter version: later side-stream work is ordered behind it
                     val.record_stream(side)
-                    cache = self.__dict__["_eval_beta"] = (b._version, val)
+                    cache = self.__dict__["_eval_beta"] = (key, val)
                 beta_in = cache[1]
             with torch.cuda.stream(side):
                 cx = self._setup(input, id, canonical_pose, _beta=beta_in if beta_in is not None else "defer")
@@ -329,6 +332,15 @@ class Multiply(nn.Module):
         return dict(dev=dev, R=R, uv=uv, K=K, pose=pose, dirs=dirs, far=far, per=per, persons=persons, n_hit=n_hit,
                     group=group, beta=beta, counts=counts)
 
+    def _vote_groups_equal(self, n_groups, grp):
+        """one-off check (cached) that every rank of the vote's process group holds `n_groups` convergence groups"""
+        import torch.distributed as dist
+        t = torch.tensor([n_groups, -n_groups], device=self.density.beta.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=grp)
+        ok = int(t[0]) == n_groups and int(-t[1]) == n_groups
+        self.sampler_vote_groups_checked = ok
+        return ok
+
     def _sample_person(self, cx, n, p, draws=None):
         """ErrorBoundSampler.get_z_vals for person p's rays (ray_sampler.py:66-220): returns zfinal [R_p][N+N_extra+2],
         the iteration counters and the per-iteration SDF worklist counts.  draws = None: eval-mode determinism;
@@ -392,6 +404,10 @@ class Multiply(nn.Module):
                 # N-rank step sample exactly like the single-process step (option (a)).
                 import torch.distributed as dist
                 grp = None if self.sampler_vote_group is True else self.sampler_vote_group
+                # every rank must contribute the same number of flags: one per call (training: group = all rays), or equally many
+                # convergence groups per rank -- uneven ray shards with convergence_group set would mismatch the collective
+                assert n_groups == 1 or getattr(self, "sampler_vote_groups_checked", False) or self._vote_groups_equal(n_groups, grp), \
+                    "sampler vote: the ranks hold different numbers of convergence groups"
                 dist.all_reduce(gflag[it * n_groups:(it + 1) * n_groups], op=dist.ReduceOp.MAX, group=grp)
             with self._ph("sampler_resample"):
                 hip.check(L.mp_sampler_resample(C.byref(cfg), C.byref(state), hip.ptr(beta), hip.ptr(far),

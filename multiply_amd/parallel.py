@@ -181,27 +181,29 @@ class BucketedGradientSync:
 # {p : p % world == g} for ALL rays of the call, then ONE exchange step turns "all rays of my persons" into "all persons
 # of my rays", and compositing + background are ray-partitioned.
 # ======================================================================================================================
-def _exchange_by_rays(dense, world, backend_alltoall):
+def _exchange_by_rays(dense, world, backend_alltoall, group=None):
     """dense [world * n_slice, ...] (rows = rays of the whole call, slice-major) -> [world, n_slice, ...]: block g holds
-    rank g's rows for MY ray slice.  all_to_all over RCCL; all_gather + select where the backend has no all_to_all."""
+    rank g's rows for MY ray slice.  all_to_all over RCCL; all_gather + select where the backend has no all_to_all.
+    group: the process group the exchange runs in (None: the world); world = its size."""
     n_slice = dense.shape[0] // world
     if backend_alltoall:
         out = torch.empty_like(dense)
-        dist.all_to_all_single(out, dense.contiguous())
+        dist.all_to_all_single(out, dense.contiguous(), group=group)
         return out.reshape(world, n_slice, *dense.shape[1:])
-    rank = dist.get_rank()
+    rank = dist.get_rank(group)
     bufs = [torch.empty_like(dense) for _ in range(world)]
-    dist.all_gather(bufs, dense.contiguous())
+    dist.all_gather(bufs, dense.contiguous(), group=group)
     return torch.stack([b.reshape(world, n_slice, *dense.shape[1:])[rank] for b in bufs], 0)
 
 
-def render_person_sharded(model, input, canonical_pose=False):
-    """Eval-mode Multiply.forward with the persons sharded over the ranks.  Every rank returns the output dict for ITS ray
-    slice [rank * ceil(R / world), ...) (use gather_rays to assemble the image).  Identical results to the single-process
-    call with convergence groups that do not straddle a slice (the sampler's vote is per person and per group)."""
+def render_person_sharded(model, input, canonical_pose=False, group=None):
+    """Eval-mode Multiply.forward with the persons sharded over the ranks (of `group`; None: all ranks).  Every rank returns the
+    output dict for ITS ray slice [rank * ceil(R / world), ...) (use gather_rays to assemble the image).  Identical results to
+    the single-process call with convergence groups that do not straddle a slice (the sampler's vote is per person and per
+    group)."""
     import ctypes as C
     from . import hip
-    world, rank = dist.get_world_size(), dist.get_rank()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
     L = hip.lib()
     st = hip.stream()
     P = input["smpl_trans"].shape[1]
@@ -230,7 +232,7 @@ def render_person_sharded(model, input, canonical_pose=False):
             dense[rows, NZ + S:NZ + 4 * S] = d["rgb"][:n * S].reshape(n, 3 * S)
             dense[rows, NZ + 4 * S:NZ + 7 * S] = d["nrm"][:n * S].reshape(n, 3 * S)
             dense[rows, -1] = 1.0
-        recv.append(_exchange_by_rays(dense, world, dist.get_backend() == "nccl"))      # [world, n_slice, width]
+        recv.append(_exchange_by_rays(dense, world, dist.get_backend(group) == "nccl", group))      # [world, n_slice, width]
     # my ray slice, all persons: person p = j * world + g
     s0 = rank * n_slice
     n_my = max(0, min(R, s0 + n_slice) - s0)
@@ -270,6 +272,61 @@ def render_person_sharded(model, input, canonical_pose=False):
     torch.cuda.synchronize()                                  # the pointer tables / blocks above must outlive the launch
     out.update(acc_map=acc_map, acc_person_list=acc_person)
     return out, (s0, s0 + n_my)
+
+
+# ======================================================================================================================
+# HYBRID rendering (last sentence of the person-sharded row; BASELINE.json configs[3] on an 8-GPU node:
+# "4 person-groups x 2 ray-shards"): world = ray_shards x person_slots.  The frame's convergence groups are dealt to the
+# ray shards on the diagonal lattice (shard_indices_interleaved), and every ray shard is rendered by a TEAM of person_slots
+# ranks with render_person_sharded inside the team's own process group: persons {p : p % person_slots == slot} evaluated
+# for the shard's rays, one all_to_all inside the team, compositing + background partitioned by the shard's ray slices.
+# No collective crosses teams until the caller assembles the image.  rank r -> (shard r // person_slots, slot r % person_slots).
+# ======================================================================================================================
+_TEAMS = {}
+
+
+def hybrid_teams(person_slots, ray_shards):
+    """The team (process group) of this rank for a world of ray_shards x person_slots ranks.  Collective: EVERY rank creates
+    every team's group, in the same order (torch.distributed.new_group's contract).  Cached per (world, split)."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    assert world == person_slots * ray_shards, f"world {world} != {ray_shards} ray shards x {person_slots} person slots"
+    key = (world, person_slots, ray_shards)
+    if key not in _TEAMS:
+        teams = [dist.new_group([s * person_slots + k for k in range(person_slots)]) for s in range(ray_shards)]
+        _TEAMS[key] = teams
+    return _TEAMS[key][rank // person_slots], rank // person_slots, rank % person_slots
+
+
+def render_hybrid(model, input, person_slots, ray_shards, group_size, groups_per_row=None, canonical_pose=False):
+    """Eval-mode Multiply.forward on ray_shards x person_slots ranks.  Returns (out, ray_ids): the output dict of THIS rank's
+    rays and their ids in the frame's ray order (ascending).  Bit-identical to the single-process call with
+    convergence_group = group_size: the shards are whole convergence groups and the person teams composite exactly the rows
+    the single process composites."""
+    team, shard, slot = hybrid_teams(person_slots, ray_shards)
+    sub, idx = shard_input_interleaved(input, shard, ray_shards, group_size, groups_per_row)
+    out, (s0, s1) = render_person_sharded(model, sub, canonical_pose, group=team)
+    return out, idx[s0:s1]
+
+
+def gather_hybrid(local, ray_ids, n_rays):
+    """all_gather of a hybrid render's per-ray outputs into (n_rays, ...) in ray order on every rank: ONE collective of the
+    padded (rows | ray id) blocks; ranks hold different counts."""
+    world = dist.get_world_size()
+    n = torch.tensor([local.shape[0]], device=local.device)
+    counts = [torch.empty_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    width = int(max(int(c) for c in counts))
+    flat = local.reshape(local.shape[0], -1).float()
+    pad = torch.zeros(width, flat.shape[1] + 1, dtype=torch.float32, device=local.device)
+    pad[:local.shape[0], :-1] = flat
+    pad[:local.shape[0], -1] = ray_ids.to(local.device).float()          # exact below 2^24 rays
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    full = torch.zeros((n_rays, flat.shape[1]), dtype=torch.float32, device=local.device)
+    for b, c in zip(bufs, counts):
+        c = int(c)
+        full[b[:c, -1].long()] = b[:c, :-1]
+    return full.reshape((n_rays,) + tuple(local.shape[1:])).to(local.dtype)
 
 
 # ======================================================================================================================

@@ -1120,6 +1120,9 @@ class TrainGraph:
         self.pose_grads = {}
         # data-parallel training: buckets of retired gradients are all-reduced while the sweep goes on (parallel.BucketedGradientSync)
         sync = getattr(m, "grad_bucket_sync", None)
+        # the buckets retire in the order of THIS rank's persons: person-sharded ranks own different persons, so their bucket
+        # sizes and counts differ and the collectives would mismatch -- that mode sums its shared gradients with PersonShardedGradSync
+        assert sync is None or self.shard is None, "grad_bucket_sync (ray-/frame-sharded data parallelism) cannot be combined with shard="
 
         def collect(obj):
             for prm, g in zip(obj.params(), obj.param_grads()):

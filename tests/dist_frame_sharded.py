@@ -19,7 +19,9 @@ from tests.test_render_gpu import build                   # noqa: E402
 
 
 def main():
-    dist.init_process_group("gloo")
+    backend = os.environ.get("MP_DIST_BACKEND", "gloo")     # "nccl" (= RCCL): one GPU per rank, real device collectives
+    dist.init_process_group(backend)
+    cdev = "cuda" if backend == "nccl" else "cpu"              # where the small control tensors of the collectives live
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(rank % torch.cuda.device_count())
     from multiply_amd.config import load_config
@@ -96,7 +98,7 @@ def main():
     torch.manual_seed(200 + rank)
     trainer.step(tin, targets[rank], rank)
     torch.cuda.synchronize()
-    flat = torch.cat([p_.detach().reshape(-1).double().cpu() for p_ in trainer.sync.params])
+    flat = torch.cat([p_.detach().reshape(-1).double().cpu() for p_ in trainer.sync.params]).to(cdev)
     both = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(both, flat)
     check(all(torch.equal(both[0], b) for b in both[1:]), "replicas differ after the optimiser step")
@@ -105,14 +107,14 @@ def main():
     model.eval()
     vs, fs = parallel.refresh_canonical_meshes_broadcast(model, res_up=1)
     sig = torch.tensor([float(sum(v.double().sum() for v in vs)), float(sum(f.double().sum() for f in fs)),
-                        float(sum(v.numel() for v in vs)), float(sum(f.numel() for f in fs))], dtype=torch.float64)
+                        float(sum(v.numel() for v in vs)), float(sum(f.numel() for f in fs))], dtype=torch.float64, device=cdev)
     sigs = [torch.zeros_like(sig) for _ in range(world)]
     dist.all_gather(sigs, sig)
     check(all(torch.equal(sigs[0], s_) for s_ in sigs[1:]), "canonical meshes differ between the ranks")
     check(all(v.shape[1] > 100 for v in vs) and model.mesh_face_vertices_list[0].shape[2:] == (3, 3), "canonical meshes look empty")
     print(f"[rank {rank}] canonical meshes from rank 0: {[int(v.shape[1]) for v in vs]} vertices, {[int(f.shape[0]) for f in fs]} faces",
           flush=True)
-    flag = torch.tensor([0 if ok else 1])
+    flag = torch.tensor([0 if ok else 1], device=cdev)
     dist.all_reduce(flag)
     dist.destroy_process_group()
     sys.exit(1 if int(flag) else 0)

@@ -12,7 +12,9 @@ from tests.test_render_gpu import build      # noqa: E402
 
 
 def main():
-    dist.init_process_group("gloo")
+    backend = os.environ.get("MP_DIST_BACKEND", "gloo")     # "nccl" (= RCCL): one GPU per rank, real device collectives
+    dist.init_process_group(backend)
+    cdev = "cuda" if backend == "nccl" else "cpu"              # where the small control tensors of the collectives live
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(rank % torch.cuda.device_count())
     model, oracle, inp = build(P=int(os.environ.get("MP_TEST_PERSONS", "2")), H=16, W=16)
@@ -31,7 +33,7 @@ def main():
         ok = ok and d < 1e-6
     full = parallel.gather_rays(part["rgb_values"], R, world, R // world)
     ok = ok and (torch.nan_to_num(full) - torch.nan_to_num(whole["rgb_values"])).abs().max().item() < 1e-6
-    flag = torch.tensor([1.0 if ok else 0.0])
+    flag = torch.tensor([1.0 if ok else 0.0], device=cdev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     dist.barrier()
     dist.destroy_process_group()

@@ -50,6 +50,8 @@ def test_gpus_flag_starts_the_ranks_and_reports_strong_scaling():
     assert d["config"]["rays_per_step"] == 64 * 64 and "ray-sharded dp2" in d["config"]["parallelism"]
     assert d["weak"]["scaling"] == "weak" and d["weak"]["value"] > 0
     assert d["train_iter"]["rays_per_iter_per_gpu"] == 256 and d["train_iter"]["rays_per_iter"] == 512
+    pr = d["per_rank"]       # the diagnosis of a scaling run: per-rank frame time, ray share, time inside the image all_gather
+    assert len(pr["ms_per_step"]) == 2 and sum(pr["rays"]) == 64 * 64 and all(t >= 0 for t in pr["all_gather_ms_per_step"])
 
 
 def test_two_ranks_over_rccl_when_the_box_has_two_gpus():

@@ -351,3 +351,63 @@ def test_person_sharded_exchange_all_to_all_branch(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res)
+
+
+def _hybrid_worker(rank, world, port, slots, q):
+    """hybrid mode (ray shards x person teams) on CPU: the teams' process groups, the exchange INSIDE a team (both branches) and
+    the image gather, with a stand-in 'renderer' whose value encodes (ray, person)"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shards = world // slots
+    team, shard, slot = parallel.hybrid_teams(slots, shards)
+    ok = dist.get_world_size(team) == slots and dist.get_rank(team) == slot and shard == rank // slots
+    n, group, P = 96, 8, 4                                   # 12 convergence groups dealt to the ray shards
+    inp = {"uv": torch.arange(n * 2, dtype=torch.float32).reshape(1, n, 2)}
+    sub, ids = parallel.shard_input_interleaved(inp, shard, shards, group)
+    # every rank "evaluates" its persons {p : p % slots == slot} for ALL rays of its shard ...
+    R = sub["uv"].shape[1]
+    n_slice = (R + slots - 1) // slots
+    mine = [p for p in range(P) if p % slots == slot]
+    per_person = []
+    for j in range((P + slots - 1) // slots):
+        dense = torch.zeros(n_slice * slots, 2)
+        if j < len(mine):
+            dense[:R, 0] = ids.float() * 10 + mine[j]        # value = (ray id, person)
+            dense[:R, 1] = 1.0
+        a = parallel._exchange_by_rays(dense, slots, True, team)
+        b = parallel._exchange_by_rays(dense, slots, False, team)
+        ok = ok and torch.equal(a, b)
+        per_person.append(a)
+    # ... and after the exchange holds ALL persons of its own ray slice of the shard
+    s0 = slot * n_slice
+    n_my = max(0, min(R, s0 + n_slice) - s0)
+    my_ids = ids[s0:s0 + n_my]
+    local = torch.zeros(n_my, P)
+    for p in range(P):
+        blk = per_person[p // slots][p % slots][:n_my]
+        ok = ok and bool((blk[:, 1] == 1.0).all()) and torch.equal(blk[:, 0], my_ids.float() * 10 + p)
+        local[:, p] = blk[:, 0]
+    full = parallel.gather_hybrid(local, my_ids, n)
+    want = torch.arange(n, dtype=torch.float32)[:, None] * 10 + torch.arange(P, dtype=torch.float32)[None, :]
+    ok = ok and torch.equal(full, want)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok))
+
+
+@pytest.mark.parametrize("world,slots", [(4, 2), (6, 3)])
+def test_hybrid_teams_exchange_inside_a_team_and_gather(world, slots):
+    """SURVEY.md section 8e ("4 person-groups x 2 ray-shards" on 8 GPUs), on gloo at 2 x 2 and 2 x 3: every rank's team is its ray
+    shard's person slots, the person exchange stays inside the team, and the gathered image is in the frame's ray order"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 37500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_hybrid_worker, args=(r, world, port, slots, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)

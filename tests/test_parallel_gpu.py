@@ -51,3 +51,27 @@ def test_frame_sharded_training_step_and_epoch_stage_broadcast():
     """a step over two frames (one per rank, body-model table rows included, one flat all-reduce) equals the
     mean of the single-frame gradients; the replicas stay identical after Adam; rank 0's canonical meshes reach rank 1"""
     _run_two_ranks("dist_frame_sharded.py", 31100)
+
+
+def test_hybrid_person_teams_times_ray_shards_on_four_ranks():
+    """SURVEY.md section 8e / BASELINE.json configs[3] on an 8-GPU node ("4 person-groups x 2 ray-shards"), at 2 x 2: the frame's
+    convergence groups dealt to two ray shards, each rendered by a team of two person slots inside its own process group (one
+    exchange inside the team); every rank's pixels and the gathered image bit-identical to the single-process render"""
+    _run_two_ranks("dist_hybrid.py", 31500, ranks=4, env={"MP_TEST_PERSONS": "4", "MP_TEST_SLOTS": "2"})
+
+
+def test_rccl_collectives_of_the_sharded_modes_when_the_box_has_enough_gpus():
+    """The person-sharded exchange (a real all_to_all_single), the hybrid teams (new_group + all_to_all inside a team) and the
+    frame-sharded trainer's flat all-reduce on backend "nccl" (= RCCL): one GPU per rank, so a one-GPU box cannot run them --
+    said loudly, not silently replaced by the gloo variants above."""
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        msg = f"RCCL PATH NOT EXECUTED: this box exposes {n} GPU(s); the sharded modes on backend 'nccl' need one GPU per rank"
+        print("\n[WARNING] " + msg, file=sys.stderr)
+        pytest.skip(msg)
+    env = {"MP_DIST_BACKEND": "nccl"}
+    _run_two_ranks("dist_person_sharded.py", 31900, ranks=2, env=env)
+    _run_two_ranks("dist_frame_sharded.py", 32300, ranks=2, env=env)
+    if n >= 4:
+        _run_two_ranks("dist_hybrid.py", 32700, ranks=4, env=dict(env, MP_TEST_PERSONS="4", MP_TEST_SLOTS="2"))

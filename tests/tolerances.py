@@ -4,26 +4,29 @@ The MLPs run with f16 MFMA operands and fp32 accumulation, everything else is fp
 bound is <= 5x the largest value MEASURED on MI355X over the test scenes (the measured figures are quoted beside it and in
 DESIGN.md §4), so that an order-of-magnitude regression of a kernel turns the suite red."""
 
-def Dist(mean, bulk, frac, hard):
+def Dist(mean, bulk, frac, hard, p999):
     """distribution bound of a transmittance-like quantity: element mean < `mean`; at most the fraction `frac` of the rays
-    may have an element off by more than `bulk`; no element off by more than `hard`"""
-    return dict(mean=mean, bulk=bulk, frac=frac, hard=hard)
+    may have an element off by more than `bulk`; the 99.9th percentile of the elements below `p999`; no element off by more
+    than `hard`"""
+    return dict(mean=mean, bulk=bulk, frac=frac, hard=hard, p999=p999)
 
 
 # Transmittance-like quantities (opacities, normals, the foreground colour over a white background): a ray that GRAZES a
 # surface has one sample whose alpha flips between ~0 and ~1 with the f16 rounding of its sdf, so single rays can be off by
 # several 1e-2 while everything else agrees to 1e-3.  A worst-case bound alone would have to be ~0.1 and assert nothing:
-# these are bounded by their DISTRIBUTION instead.  Measured on MI355X (headline 1 024-ray scene / the 16 384-ray slow test,
-# profiles/r03_parity_16k.txt): 0.3-0.4 % of the rays above 1e-2 (99th percentile 2.5e-3), worst single ray 4.7e-2.
-_GRAZE = dict(bulk=1e-2, frac=0.02, hard=0.15)
+# these are bounded by their DISTRIBUTION instead.  Measured on MI355X (headline 1 024-ray scene / the 16 384-ray headline run,
+# profiles/r03_parity_16k.txt): 0.22-0.4 % of the rays above 1e-2 (99th percentile 6.6e-4, 99.9th 1.2e-2 ... 3.2e-2), worst
+# single ray 9.0e-2.  Round 4 (review): the fraction at 2.5x the measured one (was 9x), the worst case at 1.33x, and a bound on
+# the 99.9th percentile per quantity (2-2.5x the 16k-ray figure; on a 1 024-ray scene it is the second-worst element).
+_GRAZE = dict(bulk=1e-2, frac=0.01, hard=0.12)
 EVAL = {                                   # eval-mode Multiply.forward outputs, per pixel
     # largest measured over the test scenes   (max, mean)
-    "rgb_values": (8e-3, 3e-5),             # 1.7e-3, 1.3e-5   (headline N = 128 scene)
-    "fg_rgb_values": Dist(1e-3, **_GRAZE),  # mean 2.4e-4; 3 of 1024 rays above 1e-2; fg + T_bg * 1: the transmittance error, undamped
-    "acc_map": Dist(1e-3, **_GRAZE),        # mean 4.8e-4; 4 of 1024 rays above 1e-2, worst 5.3e-2
-    "acc_person_list": Dist(1e-3, **_GRAZE),   # mean 2.7e-4; 4 of 1024
-    "bg_transmittance": Dist(1e-3, **_GRAZE),  # mean 1.2e-4
-    "normal_values": Dist(8e-4, **_GRAZE),  # mean 3.2e-4; 3 of 1024 rays above 1e-2, worst 3.9e-2
+    "rgb_values": (8e-3, 3e-5),             # 1.7e-3, 1.3e-5   (headline N = 128 scene; 16k rays: 3.0e-3, 4.9e-6)
+    "fg_rgb_values": Dist(1e-3, p999=0.04, **_GRAZE),  # mean 2.4e-4; 3 of 1024 rays above 1e-2; p99.9 1.6e-2; fg + T_bg: the transmittance error, undamped
+    "acc_map": Dist(1e-3, p999=0.08, **_GRAZE),        # mean 4.8e-4; 4 of 1024 rays above 1e-2, worst 5.3e-2; 16k: p99.9 3.2e-2, worst 9.0e-2
+    "acc_person_list": Dist(1e-3, p999=0.05, **_GRAZE),   # mean 2.7e-4; 4 of 1024; 16k: p99.9 1.6e-2
+    "bg_transmittance": Dist(1e-3, p999=0.08, **_GRAZE),  # mean 1.2e-4 (= 1 - acc of the last sample's exclusive transmittance)
+    "normal_values": Dist(8e-4, p999=0.04, **_GRAZE),  # mean 3.2e-4; 3 of 1024 rays above 1e-2, worst 3.9e-2; 16k: p99.9 1.2e-2
     "bg_rgb": (1.5e-4, 2.5e-5),             # 2.7e-5, 5.4e-6
 }
 Z_VALS = (5e-2, 3e-4)                       # sampler depths (inverse CDF of f16 sdf queries); measured 1.4e-2, 6.7e-5
@@ -66,11 +69,23 @@ class Stats(tuple):
         return st
 
 
+def torch_quantile(e, q):
+    """torch.quantile without its 16 M element limit (sorts; the k-th order statistic, linear interpolation)"""
+    import torch
+    v, _ = torch.sort(e)
+    pos = q * (v.numel() - 1)
+    lo = int(pos)
+    hi = min(lo + 1, v.numel() - 1)
+    return v[lo] + (v[hi] - v[lo]) * (pos - lo)
+
+
 def within(stats, tol):
     """tol = (max, mean) over elements, or a Dist {mean, bulk, frac, hard}: element mean below `mean`, at most the fraction
     `frac` of the RAYS with an element above `bulk`, and nothing above `hard`."""
     if isinstance(tol, dict):
         ray = stats.ray
         above = float((ray > tol["bulk"]).sum()) / max(ray.numel(), 1)
-        return stats[1] < tol["mean"] and above <= tol["frac"] and stats[0] < tol["hard"]
+        e = stats.err.reshape(-1).float()
+        p999 = float(torch_quantile(e, 0.999)) if e.numel() else 0.0
+        return stats[1] < tol["mean"] and above <= tol["frac"] and stats[0] < tol["hard"] and p999 <= tol["p999"]
     return stats[0] < tol[0] and stats[1] < tol[1]

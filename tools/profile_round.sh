@@ -16,6 +16,7 @@ rm -rf /tmp/prof_*
 rocprofv3 --kernel-trace -d /tmp/prof_kt -o run -- python "$REPO/bench.py" --no-cpu-baseline > "$OUT/bench_under_trace.json" 2> "$OUT/kt.log"
 python "$REPO/tools/rocpd_summary.py" "$(find /tmp/prof_kt -name '*.db' | head -1)" "$OUT/kernel_trace.txt" > /dev/null
 ONE="python $REPO/bench.py --steps 1 --warmup 0 --train-steps 0 --no-cpu-baseline"
+$ONE > "$OUT/bench_one_frame.json" 2> /dev/null
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -o run -- $ONE > /dev/null 2> "$OUT/pmc_fetch.log"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -o run -- $ONE > /dev/null 2> "$OUT/pmc_write.log"
 python "$REPO/tools/pmc_traffic.py" /tmp/prof_fetch /tmp/prof_write > "$OUT/pmc_traffic_raw.txt" 2>&1

@@ -26,6 +26,14 @@ with open(os.path.join(dst, tag + "_kernel_trace.txt"), "w") as f:
 # ---- traffic
 raw = open(os.path.join(src, "pmc_traffic_raw.txt")).read().strip().split("\n")
 pmc = json.loads(raw[-1])
+# what the measurement is a measurement OF (bench.py attaches the file only to a run of the same kernels on the same workload)
+sys.path.insert(0, root)
+import bench as _bench   # noqa: E402
+one = [l for l in open(os.path.join(src, "bench_one_frame.json")) if l.startswith("{")]
+one = json.loads(one[0]) if one else bench
+pmc["_meta"] = {"kernel_source_sha16": _bench.kernel_source_hash(), "dominant": one["roofline"]["kernel"].split(" = ")[0],
+                "algorithmic_flop_per_launch": one["roofline"]["algorithmic_flop_per_launch"],
+                "launches_per_step": one["roofline"]["launches_per_step"], "command": "bench.py --steps 1 --warmup 0 --train-steps 0 --no-cpu-baseline"}
 json.dump(pmc, open(os.path.join(dst, tag + "_pmc_traffic.json"), "w"))
 with open(os.path.join(dst, tag + "_pmc_traffic.txt"), "w") as f:
     f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, each with --kernel-trace only) of\n"
