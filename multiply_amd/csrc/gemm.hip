@@ -678,17 +678,26 @@ struct TnGroups {
     int slice0[MP_TN_MAX_GROUPS + 1];    // first blockIdx.z of every group
     int n, rows_per_block;
 };
-__global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_tn_b3g(TnGroups T) {
+// Workgroup -> (row slice, tile): the mt x nt tiles of ONE row slice read the same rows of A and B (each column block twice), so
+// they are placed on the SAME XCD next to each other in dispatch order -- workgroup L runs on XCD L % 8 (MI355X_MICROARCH.md),
+// hence tile = (L / 8) % tiles, slice = L % 8 + 8 (L / (8 tiles)) -- and the second reader finds the rows in that XCD's L2.
+// With the (tile fastest, slice slowest) order of a plain 3-D grid the four tiles of a slice sit on four different XCDs and every
+// operand byte crosses the fabric twice: the kernel then runs at the memory system's rate on 2x its algorithmic bytes.
+__global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_tn_b3g(TnGroups T, int mt, int nt, int n_slice) {
+    const int tiles = mt * nt, L = blockIdx.x;
+    const int tile = (L >> 3) % tiles, slice = (L & 7) + 8 * (L / (8 * tiles));
+    if (slice >= n_slice) return;
     int gi = 0;
 #pragma unroll
     for (int i = 1; i < MP_TN_MAX_GROUPS; ++i)
-        if (i < T.n && (int)blockIdx.z >= T.slice0[i]) gi = i;
+        if (i < T.n && slice >= T.slice0[i]) gi = i;
     const MpTnGroup& G = T.g[gi];
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int bx = tile % mt, by = tile / mt;
+    const int m0 = bx * BM, n0 = by * BN;
     if (m0 >= G.M || n0 >= G.N) return;
-    const int r_begin = ((int)blockIdx.z - T.slice0[gi]) * T.rows_per_block;
+    const int r_begin = (slice - T.slice0[gi]) * T.rows_per_block;
     tn_b3_tile<true>(G.A, G.lda, G.B, G.ldb, G.C, G.ldc, G.M, G.N, m0, n0, r_begin, min(G.K, r_begin + T.rows_per_block), G.colsum,
-                     G.colsum_rows, blockIdx.y == 0);
+                     G.colsum_rows, by == 0);
 }
 
 }  // namespace
@@ -832,6 +841,7 @@ extern "C" int mp_gemm_tn_bf16x3_grouped(const MpTnGroup* groups, int n_groups, 
     T.slice0[n_groups] = z;
     constexpr int LDS_B3 = 2 * 2 * 2 * (BK / 4) * BM * 4 * 2;
     MP_LDS_ATTR(k_gemm_tn_b3g, LDS_B3);
-    hipLaunchKernelGGL(k_gemm_tn_b3g, dim3(mt, nt, z), dim3(NT_THREADS), LDS_B3, (hipStream_t)stream, T);
+    const int zpad = (z + 7) / 8 * 8;
+    hipLaunchKernelGGL(k_gemm_tn_b3g, dim3(mt * nt * zpad), dim3(NT_THREADS), LDS_B3, (hipStream_t)stream, T, mt, nt, z);
     return (int)hipGetLastError();
 }

@@ -830,14 +830,22 @@ __device__ __forceinline__ void obb_frame(const double* n, const double* e, doub
     d[0] *= inv; d[1] *= inv; d[2] *= inv;
     w[0] = n[1] * d[2] - n[2] * d[1]; w[1] = n[2] * d[0] - n[0] * d[2]; w[2] = n[0] * d[1] - n[1] * d[0];
 }
+// counts (optional, device): {hull vertices, facet normals, edges, status} written by k_hull_wrap -- the launch then covers the
+// upper bound of facets and the blocks past the real count leave at once
 __global__ __launch_bounds__(OBB_T) void k_obb_hull_search(const double* __restrict__ hv, int H, const double* __restrict__ normals,
                                                            const double* __restrict__ evec, const double* __restrict__ ena,
-                                                           const double* __restrict__ enb, int E, double* __restrict__ work) {
+                                                           const double* __restrict__ enb, int E, double* __restrict__ work,
+                                                           const int* __restrict__ counts) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sh = (double*)smem;                      // [H][3] hull vertices
     __shared__ double r_val[OBB_T];
     __shared__ int r_idx[OBB_T];
     __shared__ double r_lo[OBB_T], r_hi[OBB_T];
+    if (counts) {
+        if ((int)blockIdx.x >= counts[1] || counts[3] != 0) return;
+        H = counts[0];
+        E = counts[2];
+    }
     const int b = blockIdx.x, t = threadIdx.x;
     const double n[3] = {normals[3 * b], normals[3 * b + 1], normals[3 * b + 2]};
     for (int i = t; i < 3 * H; i += OBB_T) sh[i] = hv[i];
@@ -882,11 +890,15 @@ __global__ __launch_bounds__(OBB_T) void k_obb_hull_search(const double* __restr
 }
 __global__ __launch_bounds__(OBB_T) void k_obb_hull_pick(const double* __restrict__ hv, int H, const double* __restrict__ normals, int N,
                                                          const double* __restrict__ evec, const double* __restrict__ work,
-                                                         float inflate, float* __restrict__ obb) {
+                                                         float inflate, float* __restrict__ obb, const int* __restrict__ counts) {
     __shared__ double r_val[OBB_T];
     __shared__ int r_idx[OBB_T];
     __shared__ double r_lo[3][OBB_T], r_hi[3][OBB_T];
     const int t = threadIdx.x;
+    if (counts) {
+        H = counts[0];
+        N = counts[3] != 0 ? 0 : counts[1];          // a failed hull: no candidate -> the all-zero record (the caller falls back)
+    }
     double best = 1e300;
     int bi = 0x7fffffff;
     for (int b = t; b < N; b += OBB_T)
@@ -967,6 +979,369 @@ extern "C" int mp_knn_build(const float* verts, const int* perm, float* vsorted,
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ convex hull on the device
+// The hull the minimum-volume box search needs (facet normals, hull vertices, edges with the normals of their two facets) by GIFT
+// WRAPPING, one workgroup: the reference's trimesh call (multiply.py:208-214) runs on the host behind a device -> host copy of
+// the posed vertices, and round 3 kept that copy for Qhull.  A posed body's hull has 150-600 vertices / 300-1 200 facets.
+//   pivot(a, b) = the vertex d with every other vertex q on the non-positive side of plane (a, b, d) (fp64 on the fp32
+// coordinates: differences exact, products rounded).  All vertices lie within a half-turn around a hull edge, so the pivot is
+// a reduction over an angle (hw_pivot_wave).  The wrap is LEVEL-SYNCHRONOUS: the open edges of the current front are pivoted in parallel, ONE WAVE PER EDGE
+// (a wave scans all vertices, 108 per lane, and reduces with shuffles: no workgroup barrier inside a pivot -- the first version
+// pivoted one edge at a time with the whole workgroup, five barriers per facet: 6 us per facet, 2.1 ms per body), then thread 0
+// inserts the round's facets one after the other -- a triangle reached from two of its edges in the same round is recognised
+// by its directed edge already being in the table -- and collects the next front.  ~25 rounds, ~0.3 ms per body.
+// Ties (exactly coplanar vertices) go to the lower index; should they ever produce a non-manifold patch (a directed edge used
+// twice) or the tables overflow, status is set and the caller falls back to the host-side hull.
+// LDS: the vertices (83 KB), an open-addressing table directed edge -> facet (48 KB), the facets (12 KB), two fronts (8 KB).
+constexpr int HW_T = 1024, HW_MAXF = 2048, HW_TAB = 8192, HW_MAXV = 6912, HW_FRONT = 1024;
+constexpr int HW_LDS = HW_MAXV * 12 + HW_TAB * 4 + HW_TAB * 2 + HW_MAXF * 6 + 2 * HW_FRONT * 4 + HW_FRONT * 4 + 64 * 4 + 16 * 24;
+// one WAVE: the pivot around the directed edge (v, u) away from a known supporting plane through it with OUTWARD normal n (the
+// facet across the edge, or the start's virtual planes; n need not be normalised): with g = n x (u - v) -- in that plane,
+// perpendicular to the edge, pointing away from the known facet -- every vertex q has w = q - v with s = -w . n >= 0, and the
+// wrap's next vertex is the one whose half-plane through the edge makes the SMALLEST angle atan2(s, w . g) with g.  Angles in
+// [0, pi] compare by cross-multiplication, c1 s2 - s1 c2 > 0, so a pivot is ONE branch-free pass (two fp64 dot products and a
+// select per vertex) and a shuffle reduction of (c, s, index).  [The first version compared candidates pairwise with an
+// orientation determinant and a plane that changed with the running best: every lane diverged, 38 k cycles per pivot.]
+struct HwKey { double c, s; int i; };
+__device__ __forceinline__ bool hw_key_better(const HwKey& cur, const HwKey& q) {      // does q beat cur?
+    if (q.i < 0) return false;
+    if (cur.i < 0) return true;
+    const double x = q.c * cur.s - q.s * cur.c;
+    if (x != 0.0) return x > 0.0;
+    if (q.c * cur.c + q.s * cur.s < 0.0) return q.c > 0.0;       // opposite directions (angle 0 against pi)
+    return q.i < cur.i;
+}
+// part / n_part: this wave scans vertices lane + 64 (part + n_part k) only (a pivot shared by n_part waves; hw_pivot_wave = all)
+__device__ HwKey hw_pivot_part(const float* P, int V, int v, int u, double n0, double n1, double n2, int part, int n_part) {
+    const int lane = threadIdx.x & 63;
+    const double vx = P[3 * v], vy = P[3 * v + 1], vz = P[3 * v + 2];
+    const double ex = (double)P[3 * u] - vx, ey = (double)P[3 * u + 1] - vy, ez = (double)P[3 * u + 2] - vz;
+    const double g0 = n1 * ez - n2 * ey, g1 = n2 * ex - n0 * ez, g2 = n0 * ey - n1 * ex;       // n x (u - v)
+    HwKey best = {0.0, 0.0, -1};
+    const int step = 64 * n_part;
+    for (int q0 = lane + 64 * part; q0 < V; q0 += 2 * step) {       // two vertices per trip: independent chains
+        HwKey k[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = q0 + j * step, qc = min(q, V - 1);
+            const double wx = (double)P[3 * qc] - vx, wy = (double)P[3 * qc + 1] - vy, wz = (double)P[3 * qc + 2] - vz;
+            k[j].c = wx * g0 + wy * g1 + wz * g2;
+            k[j].s = fmax(-(wx * n0 + wy * n1 + wz * n2), 0.0);                               // s < 0 is rounding only
+            // not: beyond the end, the edge's own vertices, points on its line
+            k[j].i = (q >= V || q == v || q == u || (k[j].c == 0.0 && k[j].s == 0.0)) ? -1 : q;
+        }
+        if (hw_key_better(k[0], k[1])) k[0] = k[1];
+        if (hw_key_better(best, k[0])) best = k[0];
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        HwKey other;
+        other.c = __shfl_xor(best.c, o);
+        other.s = __shfl_xor(best.s, o);
+        other.i = __shfl_xor(best.i, o);
+        if (hw_key_better(best, other)) best = other;
+    }
+    return best;
+}
+__device__ __forceinline__ int hw_pivot_wave(const float* P, int V, int v, int u, double n0, double n1, double n2) {
+    return hw_pivot_part(P, V, v, u, n0, n1, n2, 0, 1).i;
+}
+// outward (unnormalised) normal of facet f
+__device__ __forceinline__ void hw_facet_normal(const float* P, const unsigned short* fac, int f, double& n0, double& n1, double& n2) {
+    const int a = fac[3 * f], b = fac[3 * f + 1], c = fac[3 * f + 2];
+    const double ux = (double)P[3 * b] - P[3 * a], uy = (double)P[3 * b + 1] - P[3 * a + 1], uz = (double)P[3 * b + 2] - P[3 * a + 2];
+    const double wx = (double)P[3 * c] - P[3 * a], wy = (double)P[3 * c + 1] - P[3 * a + 1], wz = (double)P[3 * c + 2] - P[3 * a + 2];
+    n0 = uy * wz - uz * wy; n1 = uz * wx - ux * wz; n2 = ux * wy - uy * wx;
+}
+__device__ __forceinline__ unsigned hw_slot(unsigned key) { return (key * 2654435761u) >> 19; }   // 13 bits
+// directed edge (u, v) -> facet id, or -1
+__device__ int hw_find(const unsigned* keys, const unsigned short* vals, int u, int v) {
+    const unsigned key = ((unsigned)u << 16) | (unsigned)v | 0x80000000u;
+    for (unsigned s = hw_slot(key), n = 0; n < HW_TAB; s = (s + 1) & (HW_TAB - 1), ++n) {
+        if (keys[s] == key) return vals[s];
+        if (keys[s] == 0u) return -1;
+    }
+    return -1;
+}
+__device__ bool hw_insert(unsigned* keys, unsigned short* vals, int u, int v, int f) {
+    const unsigned key = ((unsigned)u << 16) | (unsigned)v | 0x80000000u;
+    for (unsigned s = hw_slot(key), n = 0; n < HW_TAB; s = (s + 1) & (HW_TAB - 1), ++n) {
+        if (keys[s] == key) return false;                 // the directed edge exists already: not a 2-manifold
+        if (keys[s] == 0u) { keys[s] = key; vals[s] = (unsigned short)f; return true; }
+    }
+    return false;
+}
+// ---- the wrap across HW_G workgroups: every one holds the vertices in its LDS and pivots a share of the front's edges (one
+// wave per edge, edges dealt across workgroups first so that a wave has its SIMD to itself while the front is short); the
+// MASTER workgroup alone keeps the edge table and the facets, inserts a round's facets IN PARALLEL (duplicates -- a triangle
+// reached from two or three of its edges -- found by comparing canonical keys, ids by a prefix sum, table slots claimed with
+// LDS compare-and-swap) and publishes the next front.  Two grid barriers per round on a counter in global memory; the exchanged
+// words (front records, pivots) go through agent-scope atomics.  Only workgroups with blockIdx % 8 == 0 work, the rest leave at
+// once: consecutive workgroup ids go round the 8 XCDs, so the HW_G workers share ONE XCD's L2 and the barrier stays inside it.
+constexpr int HW_G = 8;
+__device__ __forceinline__ void hw_store(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned hw_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void hw_grid_barrier(unsigned* bar, unsigned& target) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        target += HW_G;
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+}
+// exclusive prefix sum of one small count per thread over the workgroup (two barriers); tot = the sum
+__device__ __forceinline__ int hw_scan(int x, int* wsum, int& tot) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int inc = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(inc, o); if (lane >= o) inc += y; }
+    __syncthreads();
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int base = 0; tot = 0;
+    for (int w = 0; w < HW_T / 64; ++w) { const int y = wsum[w]; if (w < wave) base += y; tot += y; }
+    return base + inc - x;
+}
+__device__ __forceinline__ bool hw_insert_cas(unsigned* keys, unsigned short* vals, int u, int v, int f) {
+    const unsigned key = ((unsigned)u << 16) | (unsigned)v | 0x80000000u;
+    for (unsigned s = hw_slot(key), n = 0; n < HW_TAB; s = (s + 1) & (HW_TAB - 1), ++n) {
+        const unsigned old = atomicCAS(&keys[s], 0u, key);
+        if (old == 0u) { vals[s] = (unsigned short)f; return true; }
+        if (old == key) return false;                     // the directed edge exists already: not a 2-manifold
+    }
+    return false;
+}
+// xch (global, zeroed by the launcher): [0] barrier counter, [1] front size, [2] failed; records [HW_FRONT][4] at word 64:
+// {u << 16 | v, a << 16 | b, c, -} = the open edge and the facet it belongs to; pivots [HW_FRONT] after them.
+// out: counts {H, F, E, status, rounds, clocks}; hv [<= V][3], normals [<= HW_MAXF][3], evec / ena / enb [<= 3 HW_MAXF / 2][3]  (fp64)
+__global__ __launch_bounds__(HW_T) void k_hull_wrap(const float* __restrict__ verts, int V, unsigned* __restrict__ xch,
+                                                    int* __restrict__ counts, double* __restrict__ hv, double* __restrict__ normals,
+                                                    double* __restrict__ evec, double* __restrict__ ena, double* __restrict__ enb) {
+    if (blockIdx.x & 7) return;
+    const int wg = blockIdx.x >> 3;
+    const bool master = wg == 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* P = (float*)smem;
+    unsigned* keys = (unsigned*)(smem + HW_MAXV * 12);
+    unsigned short* vals = (unsigned short*)(smem + HW_MAXV * 12 + HW_TAB * 4);
+    unsigned short* fac = (unsigned short*)(smem + HW_MAXV * 12 + HW_TAB * 6);
+    unsigned* front = (unsigned*)(smem + HW_MAXV * 12 + HW_TAB * 6 + HW_MAXF * 6);            // [HW_FRONT]: (u << 16) | v
+    unsigned* ck0 = front + HW_FRONT;                                                         // [HW_FRONT] canonical triangle keys
+    int* cand = (int*)(front + 2 * HW_FRONT);                                                 // [HW_FRONT]
+    int* red = cand + HW_FRONT;                            // [0,16) wave results, [32..] control words
+    HwKey* pk = (HwKey*)(red + 64);                        // [16] the waves' partial pivots
+    unsigned* grec = xch + 64;
+    unsigned* gcand = xch + 64 + 4 * HW_FRONT;
+    const int t = threadIdx.x, wave = t >> 6;
+    unsigned bar_target = 0;
+    for (int i = t; i < 3 * V; i += HW_T) P[i] = verts[i];
+    if (master) for (int i = t; i < HW_TAB; i += HW_T) keys[i] = 0u;
+    __syncthreads();
+    // ---- the first facet (master): lowest x (ties: lowest index); pivot around the vertical line through it; pivot around that edge
+    if (master) {
+        int best = -1;
+        for (int q = t; q < V; q += HW_T)
+            if (best < 0 || P[3 * q] < P[3 * best] || (P[3 * q] == P[3 * best] && q < best)) best = q;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int other = __shfl_xor(best, o);
+            if (other >= 0 && (best < 0 || P[3 * other] < P[3 * best] || (P[3 * other] == P[3 * best] && other < best))) best = other;
+        }
+        if ((t & 63) == 0) red[wave] = best;
+        __syncthreads();
+        if (t == 0) {
+            int b = red[0];
+            for (int w = 1; w < HW_T / 64; ++w) {
+                const int other = red[w];
+                if (other >= 0 && (b < 0 || P[3 * other] < P[3 * b] || (P[3 * other] == P[3 * b] && other < b))) b = other;
+            }
+            red[32] = b;
+            // a virtual vertex straight above p0 (slot V of the coordinate array: HW_MAXV > V is guaranteed by the launcher)
+            P[3 * V] = P[3 * b]; P[3 * V + 1] = P[3 * b + 1]; P[3 * V + 2] = P[3 * b + 2] + 1.0f;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int p0 = red[32];
+            // the plane x = x(p0) supports the hull (outward normal -x): pivot around the vertical line through p0 -> a hull edge
+            const int p1 = hw_pivot_wave(P, V, p0, V, -1.0, 0.0, 0.0);
+            // the plane through that edge and the vertical supports the hull too (every vertex has w . ((p1 - p0) x z) >= 0):
+            // pivot around (p0, p1) -> the first facet, every vertex on its non-positive side
+            int p2 = -1;
+            if (p1 >= 0) {
+                const double dx = (double)P[3 * p1] - P[3 * p0], dy = (double)P[3 * p1 + 1] - P[3 * p0 + 1];
+                p2 = hw_pivot_wave(P, V, p0, p1, -dy, dx, 0.0);
+            }
+            if (t == 0) {
+                const bool ok = p1 >= 0 && p2 >= 0;
+                red[33] = ok ? 0 : 1;                      // failed
+                red[34] = 1;                               // F
+                red[35] = 0;                               // front size
+                if (ok) {
+                    fac[0] = (unsigned short)p0; fac[1] = (unsigned short)p1; fac[2] = (unsigned short)p2;
+                    hw_insert(keys, vals, p0, p1, 0); hw_insert(keys, vals, p1, p2, 0); hw_insert(keys, vals, p2, p0, 0);
+                    const int tri[4] = {p0, p1, p2, p0};
+                    for (int k = 0; k < 3; ++k) {
+                        front[k] = ((unsigned)tri[k] << 16) | (unsigned)tri[k + 1];
+                        hw_store(&grec[4 * k], front[k]);
+                        hw_store(&grec[4 * k + 1], ((unsigned)p0 << 16) | (unsigned)p1);
+                        hw_store(&grec[4 * k + 2], (unsigned)p2);
+                    }
+                    red[35] = 3;
+                }
+                hw_store(&xch[1], (unsigned)red[35]);
+                hw_store(&xch[2], (unsigned)red[33]);
+            }
+        }
+    }
+    // ---- wrap, one round per front: edge (u, v) of a facet has its twin (v, u) in the facet across it
+    long long t_piv = 0, t_ins = 0, t_all = clock64();
+    int n_round = 0;
+    for (int round = 0; round < 4 * HW_MAXF; ++round) {
+        hw_grid_barrier(xch, bar_target);                  // the front is published
+        const int n = (int)hw_load(&xch[1]);
+        if (n == 0 || hw_load(&xch[2]) != 0u) break;
+        ++n_round;
+        const long long t0 = clock64();
+        // this workgroup's edges are wg, wg + HW_G, ...; while there are fewer of them than waves, n_part waves share one pivot
+        const int n_wg = (n - wg + HW_G - 1) / HW_G;
+        int n_part = 1;
+        while (n_part < HW_T / 64 && 2 * n_part * n_wg <= HW_T / 64) n_part *= 2;
+        const int slots = (HW_T / 64) / n_part, slot = wave / n_part, part = wave % n_part;
+        for (int e0 = 0; e0 < n_wg; e0 += slots) {
+            const int e = wg + HW_G * (e0 + slot);
+            const bool has = e0 + slot < n_wg;
+            HwKey k = {0.0, 0.0, -1};
+            if (has) {
+                const unsigned r0 = hw_load(&grec[4 * e]), r1 = hw_load(&grec[4 * e + 1]), r2 = hw_load(&grec[4 * e + 2]);
+                const int u = (int)(r0 >> 16), v = (int)(r0 & 0xffffu);
+                const int a = (int)(r1 >> 16), b = (int)(r1 & 0xffffu), c = (int)r2;
+                const double ux = (double)P[3 * b] - P[3 * a], uy = (double)P[3 * b + 1] - P[3 * a + 1], uz = (double)P[3 * b + 2] - P[3 * a + 2];
+                const double wx = (double)P[3 * c] - P[3 * a], wy = (double)P[3 * c + 1] - P[3 * a + 1], wz = (double)P[3 * c + 2] - P[3 * a + 2];
+                k = hw_pivot_part(P, V, v, u, uy * wz - uz * wy, uz * wx - ux * wz, ux * wy - uy * wx, part, n_part);
+            }
+            if (n_part == 1) {
+                if (has && (t & 63) == 0) hw_store(&gcand[e], (unsigned)k.i);
+                continue;
+            }
+            if ((t & 63) == 0) { pk[wave].c = k.c; pk[wave].s = k.s; pk[wave].i = k.i; }
+            __syncthreads();
+            if (has && part == 0 && (t & 63) == 0) {
+                for (int j = 1; j < n_part; ++j) if (hw_key_better(k, pk[wave + j])) k = pk[wave + j];
+                hw_store(&gcand[e], (unsigned)k.i);
+            }
+            __syncthreads();
+        }
+        hw_grid_barrier(xch, bar_target);                  // the pivots are published
+        const long long t1 = clock64();
+        t_piv += t1 - t0;
+        if (!master) continue;
+        // ---- insert (n <= HW_FRONT = HW_T: one candidate per thread)
+        int F = red[34];
+        int u = 0, v = 0, d = -1;
+        bool mine = false;
+        if (t < n) {
+            u = (int)(front[t] >> 16); v = (int)(front[t] & 0xffffu); d = (int)hw_load(&gcand[t]);
+            if (d < 0) red[33] = 1;
+            // the triangle (v, u, d) rotated to start at its lowest vertex
+            int a = v, b = u, c = d;
+            if (b < a && b < c) { a = u; b = d; c = v; } else if (c < a && c < b) { a = d; b = v; c = u; }
+            ck0[t] = ((unsigned)a << 16) | (unsigned)b; cand[t] = c;
+        }
+        __syncthreads();
+        if (t < n && d >= 0) {
+            mine = true;
+            const unsigned k0 = ck0[t]; const int k1 = cand[t];
+            for (int e = 0; e < t; ++e) if (ck0[e] == k0 && cand[e] == k1) { mine = false; break; }
+        }
+        int n_new;
+        const int f = F + hw_scan(mine ? 1 : 0, red, n_new);
+        if (F + n_new > HW_MAXF) { if (t == 0) red[33] = 1; }
+        else if (mine) {
+            fac[3 * f] = (unsigned short)v; fac[3 * f + 1] = (unsigned short)u; fac[3 * f + 2] = (unsigned short)d;
+            if (!(hw_insert_cas(keys, vals, v, u, f) & hw_insert_cas(keys, vals, u, d, f) & hw_insert_cas(keys, vals, d, v, f))) red[33] = 1;
+        }
+        __syncthreads();
+        // the new facets' two other edges are open unless their twins exist (now: every facet of the round is in the table)
+        const bool failed = red[33] != 0;
+        const bool o0 = mine && !failed && hw_find(keys, vals, d, u) < 0;      // edge (u, d)
+        const bool o1 = mine && !failed && hw_find(keys, vals, v, d) < 0;      // edge (d, v)
+        int m;
+        int at = hw_scan((o0 ? 1 : 0) + (o1 ? 1 : 0), red, m);
+        __syncthreads();                                   // (front[] was read above; it is rewritten below)
+        if (m > HW_FRONT) { if (t == 0) red[33] = 1; m = 0; }
+        else {
+            const unsigned fa = ((unsigned)v << 16) | (unsigned)u;
+            if (o0) { front[at] = ((unsigned)u << 16) | (unsigned)d; hw_store(&grec[4 * at], front[at]); hw_store(&grec[4 * at + 1], fa);
+                      hw_store(&grec[4 * at + 2], (unsigned)d); ++at; }
+            if (o1) { front[at] = ((unsigned)d << 16) | (unsigned)v; hw_store(&grec[4 * at], front[at]); hw_store(&grec[4 * at + 1], fa);
+                      hw_store(&grec[4 * at + 2], (unsigned)d); }
+        }
+        __syncthreads();
+        if (t == 0) {
+            red[34] = F + n_new; red[35] = m;
+            hw_store(&xch[1], red[33] != 0 ? 0u : (unsigned)m);
+            hw_store(&xch[2], (unsigned)red[33]);
+        }
+        t_ins += clock64() - t1;
+    }
+    if (!master) return;
+    if (t == 0) { counts[4] = n_round; counts[5] = (int)(t_piv >> 4); counts[6] = (int)(t_ins >> 4); counts[7] = (int)((clock64() - t_all) >> 4); }
+    const int F = red[34];
+    const bool fail = red[33] != 0 || red[35] != 0;
+    __syncthreads();
+    // ---- outputs
+    int* cnt = red + 40;                                   // [0] hull vertices, [1] edges
+    if (t == 0) { cnt[0] = 0; cnt[1] = 0; }
+    unsigned* used = keys;                                 // (the table is read below: the marks go to the facet-normal pass first)
+    __syncthreads();
+    if (fail) {
+        if (t == 0) { counts[0] = 0; counts[1] = 0; counts[2] = 0; counts[3] = 1; }
+        return;
+    }
+    for (int f = t; f < F; f += HW_T) {                    // outward unit normals; the search's copy with the reference's sign rule
+        const int a = fac[3 * f], b = fac[3 * f + 1], c = fac[3 * f + 2];
+        const double ux = (double)P[3 * b] - P[3 * a], uy = (double)P[3 * b + 1] - P[3 * a + 1], uz = (double)P[3 * b + 2] - P[3 * a + 2];
+        const double vx = (double)P[3 * c] - P[3 * a], vy = (double)P[3 * c + 1] - P[3 * a + 1], vz = (double)P[3 * c + 2] - P[3 * a + 2];
+        double nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
+        const double ln = sqrt(nx * nx + ny * ny + nz * nz), inv = ln > 0.0 ? 1.0 / ln : 0.0;
+        nx *= inv; ny *= inv; nz *= inv;
+        const bool flip = nx < 0.0 || (nx == 0.0 && ny < 0.0) || (nx == 0.0 && ny == 0.0 && nz < 0.0);     // obb.py _hull_parts
+        normals[3 * f] = flip ? -nx : nx; normals[3 * f + 1] = flip ? -ny : ny; normals[3 * f + 2] = flip ? -nz : nz;
+    }
+    for (int f = t; f < F; f += HW_T)                      // edges (u < v) with the OUTWARD normals of their two facets
+        for (int k = 0; k < 3; ++k) {
+            const int u = fac[3 * f + k], v = fac[3 * f + (k + 1) % 3];
+            if (u > v) continue;
+            const int g = hw_find(keys, vals, v, u);
+            const int e = atomicAdd(&cnt[1], 1);
+            for (int a = 0; a < 3; ++a) evec[3 * e + a] = (double)P[3 * v + a] - (double)P[3 * u + a];
+            for (int side = 0; side < 2; ++side) {
+                const int ff = side == 0 ? f : g;
+                const int a = fac[3 * ff], b = fac[3 * ff + 1], c = fac[3 * ff + 2];
+                const double ux = (double)P[3 * b] - P[3 * a], uy = (double)P[3 * b + 1] - P[3 * a + 1], uz = (double)P[3 * b + 2] - P[3 * a + 2];
+                const double vx = (double)P[3 * c] - P[3 * a], vy = (double)P[3 * c + 1] - P[3 * a + 1], vz = (double)P[3 * c + 2] - P[3 * a + 2];
+                double nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
+                const double ln = sqrt(nx * nx + ny * ny + nz * nz), inv = ln > 0.0 ? 1.0 / ln : 0.0;
+                double* o = side == 0 ? ena : enb;
+                o[3 * e] = nx * inv; o[3 * e + 1] = ny * inv; o[3 * e + 2] = nz * inv;
+            }
+        }
+    __syncthreads();
+    // hull vertices: marks in the (now idle) key table region
+    for (int i = t; i < V; i += HW_T) used[i] = 0u;
+    __syncthreads();
+    for (int i = t; i < 3 * F; i += HW_T) used[fac[i]] = 1u;
+    __syncthreads();
+    for (int i = t; i < V; i += HW_T)
+        if (used[i]) {
+            const int h = atomicAdd(&cnt[0], 1);
+            hv[3 * h] = P[3 * i]; hv[3 * h + 1] = P[3 * i + 1]; hv[3 * h + 2] = P[3 * i + 2];
+        }
+    __syncthreads();
+    if (t == 0) { counts[0] = cnt[0]; counts[1] = F; counts[2] = cnt[1]; counts[3] = 0; }
+}
+
 extern "C" int mp_obb(const float* verts, float inflate, float* obb, void* stream) {
     hipLaunchKernelGGL(k_obb, dim3(1), dim3(256), 0, (hipStream_t)stream, verts, inflate, obb);
     return (int)hipGetLastError();
@@ -981,9 +1356,9 @@ extern "C" int mp_obb_hull(const double* hull_verts, int n_hull_verts, const dou
     hipStream_t st = (hipStream_t)stream;
     MP_LDS_ATTR((k_obb_hull_search), 96 * 1024);
     hipLaunchKernelGGL(k_obb_hull_search, dim3(n_normals), dim3(OBB_T), lds, st, hull_verts, n_hull_verts, normals, edge_vec, edge_na,
-                       edge_nb, n_edges, work);
+                       edge_nb, n_edges, work, (const int*)nullptr);
     hipLaunchKernelGGL(k_obb_hull_pick, dim3(1), dim3(OBB_T), 0, st, hull_verts, n_hull_verts, normals, n_normals, edge_vec, work,
-                       inflate, obb);
+                       inflate, obb, (const int*)nullptr);
     return (int)hipGetLastError();
 }
 
@@ -1095,5 +1470,32 @@ extern "C" int mp_warp_jacobian(const float* xc, const unsigned char* need, cons
     const int threads = warp_threads(n_slab), nw = threads / 64;
     hipLaunchKernelGGL(k_warp_jacobian, dim3(warp_grid(n_slab, nw)), dim3(threads), WARP_LDS, st, xc, need, hit_count,
                        max_rays, n_s, n_pts, vsorted_c, cbound_c, (const float4*)blend_table, jinv, nn_index, seed, verts_c);
+    return (int)hipGetLastError();
+}
+
+// work (bytes, 8-byte aligned): the workgroups' exchange area (HW_XCH_BYTES; the launcher zeroes its head); then fp64 arrays hv [HW_MAXV][3], normals [HW_MAXF][3], evec / ena / enb
+// [3 HW_MAXF / 2][3] each, search scratch [2 HW_MAXF]
+constexpr int HW_XCH_BYTES = 256 + 4 * (4 * HW_FRONT + HW_FRONT);
+extern "C" int mp_obb_hull_device_work_bytes(void) { return HW_XCH_BYTES + 8 * (3 * HW_MAXV + 3 * HW_MAXF + 3 * (9 * HW_MAXF / 2) + 2 * HW_MAXF); }
+extern "C" int mp_obb_hull_device(const float* verts, int n_verts, float inflate, void* work, float* obb, int* status, void* stream) {
+    if (n_verts < 4 || n_verts >= HW_MAXV || n_verts > 65535) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    int* counts = status;                                   // {H, F, E, status}: the caller reads [3] with its other counts
+    unsigned* xch = (unsigned*)work;                        // barrier counter + front size + failed, records, pivots
+    hipMemsetAsync(xch, 0, 256, st);
+    double* hv = (double*)((char*)work + HW_XCH_BYTES);
+    double* normals = hv + 3 * HW_MAXV;
+    double* evec = normals + 3 * HW_MAXF;
+    double* ena = evec + 9 * HW_MAXF / 2;
+    double* enb = ena + 9 * HW_MAXF / 2;
+    double* swork = enb + 9 * HW_MAXF / 2;
+    MP_LDS_ATTR(k_hull_wrap, HW_LDS);
+    hipLaunchKernelGGL(k_hull_wrap, dim3(8 * HW_G - 7), dim3(HW_T), HW_LDS, st, verts, n_verts, xch, counts, hv, normals, evec, ena, enb);
+    MP_LDS_ATTR((k_obb_hull_search), 96 * 1024);
+    // the search's LDS tile holds the hull vertices: a closed triangulated surface of F facets has F / 2 + 2 of them
+    const int lds = (HW_MAXF / 2 + 2) * 3 * (int)sizeof(double);
+    hipLaunchKernelGGL(k_obb_hull_search, dim3(HW_MAXF), dim3(OBB_T), lds, st, hv, 0, normals, evec, ena, enb, 0, swork,
+                       (const int*)counts);
+    hipLaunchKernelGGL(k_obb_hull_pick, dim3(1), dim3(OBB_T), 0, st, hv, 0, normals, 0, evec, swork, inflate, obb, (const int*)counts);
     return (int)hipGetLastError();
 }

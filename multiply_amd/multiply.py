@@ -171,7 +171,7 @@ class Multiply(nn.Module):
         with torch.no_grad():
             return self._forward_eval(input, id, canonical_pose)
 
-    def _setup(self, input, id, canonical_pose, side_stream=False, _beta=None):
+    def _setup(self, input, id, canonical_pose, side_stream=False, _beta=None, host_hull=False):
         """Rays, SMPL posing, nearest-vertex structures and the box cull for every person of the call
         (multiply.py:177-266).  Ends with the one host sync of the call (hit counts size the workspaces).
 
@@ -210,7 +210,7 @@ class Multiply(nn.Module):
                     cache = self.__dict__["_eval_beta"] = (key, val)
                 beta_in = cache[1]
             with torch.cuda.stream(side):
-                cx = self._setup(input, id, canonical_pose, _beta=beta_in if beta_in is not None else "defer")
+                cx = self._setup(input, id, canonical_pose, _beta=beta_in if beta_in is not None else "defer", host_hull=host_hull)
 
             def hand_over(o):
                 if torch.is_tensor(o):
@@ -261,6 +261,7 @@ class Multiply(nn.Module):
         # SMPL posing, nearest-vertex structures, box cull  (multiply.py:196-214, 256-266)
         per = {}
         counts = torch.zeros(len(persons), **i32)
+        hull_status = None
         scan_tmp = torch.empty(R + (R + 1023) // 1024 + 8, **i32)
         for n, p in enumerate(persons):
             server = self.smpl_server_list[p]
@@ -294,8 +295,18 @@ class Multiply(nn.Module):
                 hip.check(L.mp_ray_hits_from_index(hip.ptr(hit_index), hi.numel(), R, hip.ptr(counts[n:n + 1]),
                                                    hip.ptr(inv_index), st), "mp_ray_hits_from_index")
             else:
-                if self._obb_mode_now() == "hull":
-                    # hull on the host (Qhull, ~3 ms; the one extra device sync of this mode), search + box on the device
+                if self._obb_mode_now() == "hull" and not host_hull:
+                    # the convex hull (gift wrapping), the candidate search and the box all on the device: no host round trip;
+                    # its status word is read with the hit counts below (a failure -- exactly coplanar vertices tying into a
+                    # non-manifold patch -- repeats the setup with the host-side hull)
+                    if hull_status is None:
+                        hull_status = torch.zeros(len(persons), 8, **i32)
+                    work = torch.empty(int(L.mp_obb_hull_device_work_bytes()), dtype=torch.uint8, device=dev)
+                    obb = torch.empty(16, **f32)
+                    hip.check(L.mp_obb_hull_device(hip.ptr(verts), NUM_VERTS, C.c_float(self.obb_inflate), hip.ptr(work), hip.ptr(obb),
+                                                   hip.ptr(hull_status[n]), st), "mp_obb_hull_device")
+                elif self._obb_mode_now() == "hull":
+                    # hull on the host (Qhull, ~3 ms; one extra device sync), search + box on the device
                     from .obb import hull_search_inputs, obb_record
                     vhost = verts.cpu().numpy()
                     buf, nh, nn_, ne = hull_search_inputs(vhost)
@@ -328,9 +339,17 @@ class Multiply(nn.Module):
             per[p] = dict(verts=verts, tfs=tfs, btab=btab, vsorted=vsorted, cbound=cbound, hit_index=hit_index, obb=obb,
                           inv_index=inv_index, count=counts[n:n + 1], cond=cond, prm=prm,
                           rest_joints=server.rest_joints() if self.training else None)
-        n_hit = counts.tolist()          # the one host sync of the call: sizes the per-person workspaces
+        if hull_status is not None:      # the one host sync of the call: sizes the per-person workspaces (+ the hulls' status)
+            both = torch.cat([counts, hull_status[:, 3]]).tolist()
+            n_hit = both[:len(persons)]
+            if any(both[len(persons):]):
+                import warnings
+                warnings.warn("device convex hull failed (degenerate vertex configuration): falling back to the host-side hull")
+                return self._setup(input, id, canonical_pose, _beta=_beta, host_hull=True)
+        else:
+            n_hit = counts.tolist()
         return dict(dev=dev, R=R, uv=uv, K=K, pose=pose, dirs=dirs, far=far, per=per, persons=persons, n_hit=n_hit,
-                    group=group, beta=beta, counts=counts)
+                    group=group, beta=beta, counts=counts, hull_status=hull_status)
 
     def _vote_groups_equal(self, n_groups, grp):
         """one-off check (cached) that every rank of the vote's process group holds `n_groups` convergence groups"""

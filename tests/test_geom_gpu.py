@@ -109,7 +109,7 @@ def test_general_k_weight_query_and_skinning(smpl_tables):
 def test_hull_box_cull_hit_sets_match_the_published_algorithm():
     """The cull box of TRAINING mode (obb_mode 'auto' -> 'hull'; no outlier override there, the hit set decides which samples
     exist: multiply.py:142-143, 208-214, 256-266) is the minimum-volume oriented box the reference asks trimesh for: hull on
-    the host, candidate search on the device (mp_obb_hull).  On 20 random poses the hit sets equal the brute-force
+    the device (round 4: mp_obb_hull_device; rounds 2-3: Qhull on the host), candidate search on the device.  On 20 random poses the hit sets equal the brute-force
     restatement's (oracle/obb_oracle.py: float64, explicit 2-D hulls) on the oracle's posed vertices -- except rays that graze
     the box within 1e-4 -- and the device's box has the volume of the host statement's (multiply_amd/obb.py)."""
     import torch
@@ -135,6 +135,23 @@ def test_hull_box_cull_hit_sets_match_the_published_algorithm():
         gin = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in cur.items()}
         cx = model._setup(gin, -1, False)
         torch.cuda.synchronize()
+        # round 4: the hull itself is built on the device (gift wrapping, csrc/geom.hip k_hull_wrap) -- no host copy of the vertices;
+        # the host-side hull (Qhull) stays as the fall-back and as the cross-check here: same box volume, same hit sets
+        hs = cx["hull_status"].cpu().numpy()
+        assert hs.shape == (len(cx["persons"]), 8) and (hs[:, 3] == 0).all(), hs
+        assert (hs[:, 1] == 2 * hs[:, 0] - 4).all() and (2 * hs[:, 2] == 3 * hs[:, 1]).all(), hs     # Euler: F = 2 H - 4, E = 3 F / 2
+        if trial < 5:
+            cx_h = model._setup(gin, -1, False, host_hull=True)
+            torch.cuda.synchronize()
+            assert cx_h["hull_status"] is None
+            for n, p in enumerate(cx["persons"]):
+                bd, bh = cx["per"][p]["obb"].cpu().numpy(), cx_h["per"][p]["obb"].cpu().numpy()
+                assert abs(np.prod(bd[12:15]) / np.prod(bh[12:15]) - 1.0) < 1e-5, (trial, p, bd, bh)
+                a = set(cx["per"][p]["hit_index"][:cx["n_hit"][n]].tolist())
+                b = set(cx_h["per"][p]["hit_index"][:cx_h["n_hit"][n]].tolist())
+                assert len(a.symmetric_difference(b)) <= 2, (trial, p, len(a), len(b))
+            if trial == 0:
+                print(f"[parity] device hulls: {hs[:, :3].tolist()} (vertices, facets, edges); rounds, pivot / insert / total clocks x16: {hs[:, 4:].tolist()}")
         if trial == 0:
             model.obb_mode = "pca"
             cx_pca = model._setup(gin, -1, False)
