@@ -139,12 +139,13 @@ int mp_obb_hull(const double* hull_verts, int n_hull_verts, const double* normal
 
 /* The same box with the convex hull ALSO built on the device (gift wrapping: 8 workgroups on one XCD share the pivots of a
  * level-synchronous front, one of them keeps the edge table; fp64 predicates; ~0.35 ms for a 6 890-vertex body): no device -> host
- * copy of the posed vertices, no host hull.  verts [n_verts][3] fp32 (n_verts < 6912); work: mp_obb_hull_device_work_bytes() bytes,
- * 8-byte aligned; status [8] (device ints): {hull vertices, facets, edges, failed, rounds, pivot / insert / total clocks x 16}:
- * failed != 0 (a non-manifold patch from exactly coplanar vertices, or more than 2048 facets) leaves obb all-zero -- the caller
+ * copy of the posed vertices, no host hull.  A BATCH of n_bodies (<= 64) bodies in one call, their wraps side by side:
+ * verts [n_bodies][n_verts][3] fp32 (n_verts < 6912); work [n_bodies][mp_obb_hull_device_work_bytes()] bytes, 8-byte aligned;
+ * obb [n_bodies][16]; status [n_bodies][8] (device ints): {hull vertices, facets, edges, failed, rounds, pivot / insert / total
+ * clocks x 16}: failed != 0 (a non-manifold patch from exactly coplanar vertices, or more than 2048 facets) leaves obb all-zero -- the caller
  * reads it with its other device counts and falls back to mp_obb_hull with a host-side hull. */
 int mp_obb_hull_device_work_bytes(void);
-int mp_obb_hull_device(const float* verts, int n_verts, float inflate, void* work, float* obb, int* status, void* stream);
+int mp_obb_hull_device(const float* verts, int n_verts, int n_bodies, float inflate, void* work, float* obb, int* status, void* stream);
 
 /* ---- rays -------------------------------------------------------------------------------------
  * rend_util.get_camera_params (lib/utils/rend_util.py:45-87) + far sphere root (:131-147).

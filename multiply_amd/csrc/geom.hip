@@ -835,12 +835,17 @@ __device__ __forceinline__ void obb_frame(const double* n, const double* e, doub
 __global__ __launch_bounds__(OBB_T) void k_obb_hull_search(const double* __restrict__ hv, int H, const double* __restrict__ normals,
                                                            const double* __restrict__ evec, const double* __restrict__ ena,
                                                            const double* __restrict__ enb, int E, double* __restrict__ work,
-                                                           const int* __restrict__ counts) {
+                                                           const int* __restrict__ counts, long long body_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sh = (double*)smem;                      // [H][3] hull vertices
     __shared__ double r_val[OBB_T];
     __shared__ int r_idx[OBB_T];
     __shared__ double r_lo[OBB_T], r_hi[OBB_T];
+    {   // blockIdx.y = the body of a batch: its arrays lie body_stride doubles after the first body's, its counts 8 ints
+        const long long o = (long long)blockIdx.y * body_stride;
+        hv += o; normals += o; evec += o; ena += o; enb += o; work += o;
+        if (counts) counts += 8 * blockIdx.y;
+    }
     if (counts) {
         if ((int)blockIdx.x >= counts[1] || counts[3] != 0) return;
         H = counts[0];
@@ -890,11 +895,17 @@ __global__ __launch_bounds__(OBB_T) void k_obb_hull_search(const double* __restr
 }
 __global__ __launch_bounds__(OBB_T) void k_obb_hull_pick(const double* __restrict__ hv, int H, const double* __restrict__ normals, int N,
                                                          const double* __restrict__ evec, const double* __restrict__ work,
-                                                         float inflate, float* __restrict__ obb, const int* __restrict__ counts) {
+                                                         float inflate, float* __restrict__ obb, const int* __restrict__ counts,
+                                                         long long body_stride) {
     __shared__ double r_val[OBB_T];
     __shared__ int r_idx[OBB_T];
     __shared__ double r_lo[3][OBB_T], r_hi[3][OBB_T];
     const int t = threadIdx.x;
+    {
+        const long long o = (long long)blockIdx.x * body_stride;
+        hv += o; normals += o; evec += o; work += o; obb += 16 * blockIdx.x;
+        if (counts) counts += 8 * blockIdx.x;
+    }
     if (counts) {
         H = counts[0];
         N = counts[3] != 0 ? 0 : counts[1];          // a failed hull: no candidate -> the all-zero record (the caller falls back)
@@ -1076,8 +1087,9 @@ __device__ bool hw_insert(unsigned* keys, unsigned short* vals, int u, int v, in
 // MASTER workgroup alone keeps the edge table and the facets, inserts a round's facets IN PARALLEL (duplicates -- a triangle
 // reached from two or three of its edges -- found by comparing canonical keys, ids by a prefix sum, table slots claimed with
 // LDS compare-and-swap) and publishes the next front.  Two grid barriers per round on a counter in global memory; the exchanged
-// words (front records, pivots) go through agent-scope atomics.  Only workgroups with blockIdx % 8 == 0 work, the rest leave at
-// once: consecutive workgroup ids go round the 8 XCDs, so the HW_G workers share ONE XCD's L2 and the barrier stays inside it.
+// words (front records, pivots) go through agent-scope atomics.  Consecutive workgroup ids go round the 8 XCDs: the HW_G
+// workers of a body are the workgroups 8 j + x of ONE x, so they share one XCD's L2 and the barrier stays inside it; the bodies
+// of a batch take different XCDs (body % 8), workgroups without a body leave at once.
 constexpr int HW_G = 8;
 __device__ __forceinline__ void hw_store(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned hw_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1117,10 +1129,16 @@ __device__ __forceinline__ bool hw_insert_cas(unsigned* keys, unsigned short* va
 // out: counts {H, F, E, status, rounds, clocks}; hv [<= V][3], normals [<= HW_MAXF][3], evec / ena / enb [<= 3 HW_MAXF / 2][3]  (fp64)
 __global__ __launch_bounds__(HW_T) void k_hull_wrap(const float* __restrict__ verts, int V, unsigned* __restrict__ xch,
                                                     int* __restrict__ counts, double* __restrict__ hv, double* __restrict__ normals,
-                                                    double* __restrict__ evec, double* __restrict__ ena, double* __restrict__ enb) {
-    if (blockIdx.x & 7) return;
-    const int wg = blockIdx.x >> 3;
+                                                    double* __restrict__ evec, double* __restrict__ ena, double* __restrict__ enb,
+                                                    long long body_stride, int n_bodies) {
+    const int body = 8 * ((blockIdx.x >> 3) / HW_G) + (blockIdx.x & 7), wg = (blockIdx.x >> 3) % HW_G;
+    if (body >= n_bodies) return;
     const bool master = wg == 0;
+    {   // this body's vertices, exchange area, outputs
+        const long long o = (long long)body * body_stride;
+        verts += (long long)body * 3 * V; xch += 2 * o; counts += 8 * body;
+        hv += o; normals += o; evec += o; ena += o; enb += o;
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* P = (float*)smem;
     unsigned* keys = (unsigned*)(smem + HW_MAXV * 12);
@@ -1356,9 +1374,9 @@ extern "C" int mp_obb_hull(const double* hull_verts, int n_hull_verts, const dou
     hipStream_t st = (hipStream_t)stream;
     MP_LDS_ATTR((k_obb_hull_search), 96 * 1024);
     hipLaunchKernelGGL(k_obb_hull_search, dim3(n_normals), dim3(OBB_T), lds, st, hull_verts, n_hull_verts, normals, edge_vec, edge_na,
-                       edge_nb, n_edges, work, (const int*)nullptr);
+                       edge_nb, n_edges, work, (const int*)nullptr, 0LL);
     hipLaunchKernelGGL(k_obb_hull_pick, dim3(1), dim3(OBB_T), 0, st, hull_verts, n_hull_verts, normals, n_normals, edge_vec, work,
-                       inflate, obb, (const int*)nullptr);
+                       inflate, obb, (const int*)nullptr, 0LL);
     return (int)hipGetLastError();
 }
 
@@ -1477,12 +1495,14 @@ extern "C" int mp_warp_jacobian(const float* xc, const unsigned char* need, cons
 // [3 HW_MAXF / 2][3] each, search scratch [2 HW_MAXF]
 constexpr int HW_XCH_BYTES = 256 + 4 * (4 * HW_FRONT + HW_FRONT);
 extern "C" int mp_obb_hull_device_work_bytes(void) { return HW_XCH_BYTES + 8 * (3 * HW_MAXV + 3 * HW_MAXF + 3 * (9 * HW_MAXF / 2) + 2 * HW_MAXF); }
-extern "C" int mp_obb_hull_device(const float* verts, int n_verts, float inflate, void* work, float* obb, int* status, void* stream) {
-    if (n_verts < 4 || n_verts >= HW_MAXV || n_verts > 65535) return -1;
+extern "C" int mp_obb_hull_device(const float* verts, int n_verts, int n_bodies, float inflate, void* work, float* obb, int* status,
+                                  void* stream) {
+    if (n_verts < 4 || n_verts >= HW_MAXV || n_verts > 65535 || n_bodies < 1 || n_bodies > 64) return -1;
     hipStream_t st = (hipStream_t)stream;
-    int* counts = status;                                   // {H, F, E, status}: the caller reads [3] with its other counts
+    int* counts = status;                                   // per body {H, F, E, status, ...}: the caller reads [3] with its other counts
+    const long long stride = mp_obb_hull_device_work_bytes() / 8;       // per body, in doubles
     unsigned* xch = (unsigned*)work;                        // barrier counter + front size + failed, records, pivots
-    hipMemsetAsync(xch, 0, 256, st);
+    for (int b = 0; b < n_bodies; ++b) hipMemsetAsync((char*)work + 8 * stride * b, 0, 256, st);
     double* hv = (double*)((char*)work + HW_XCH_BYTES);
     double* normals = hv + 3 * HW_MAXV;
     double* evec = normals + 3 * HW_MAXF;
@@ -1490,12 +1510,14 @@ extern "C" int mp_obb_hull_device(const float* verts, int n_verts, float inflate
     double* enb = ena + 9 * HW_MAXF / 2;
     double* swork = enb + 9 * HW_MAXF / 2;
     MP_LDS_ATTR(k_hull_wrap, HW_LDS);
-    hipLaunchKernelGGL(k_hull_wrap, dim3(8 * HW_G - 7), dim3(HW_T), HW_LDS, st, verts, n_verts, xch, counts, hv, normals, evec, ena, enb);
+    hipLaunchKernelGGL(k_hull_wrap, dim3(8 * HW_G * ((n_bodies + 7) / 8)), dim3(HW_T), HW_LDS, st, verts, n_verts, xch, counts, hv,
+                       normals, evec, ena, enb, stride, n_bodies);
     MP_LDS_ATTR((k_obb_hull_search), 96 * 1024);
     // the search's LDS tile holds the hull vertices: a closed triangulated surface of F facets has F / 2 + 2 of them
     const int lds = (HW_MAXF / 2 + 2) * 3 * (int)sizeof(double);
-    hipLaunchKernelGGL(k_obb_hull_search, dim3(HW_MAXF), dim3(OBB_T), lds, st, hv, 0, normals, evec, ena, enb, 0, swork,
-                       (const int*)counts);
-    hipLaunchKernelGGL(k_obb_hull_pick, dim3(1), dim3(OBB_T), 0, st, hv, 0, normals, 0, evec, swork, inflate, obb, (const int*)counts);
+    hipLaunchKernelGGL(k_obb_hull_search, dim3(HW_MAXF, n_bodies), dim3(OBB_T), lds, st, hv, 0, normals, evec, ena, enb, 0, swork,
+                       (const int*)counts, stride);
+    hipLaunchKernelGGL(k_obb_hull_pick, dim3(n_bodies), dim3(OBB_T), 0, st, hv, 0, normals, 0, evec, swork, inflate, obb,
+                       (const int*)counts, stride);
     return (int)hipGetLastError();
 }

@@ -263,6 +263,9 @@ class Multiply(nn.Module):
         counts = torch.zeros(len(persons), **i32)
         hull_status = None
         scan_tmp = torch.empty(R + (R + 1023) // 1024 + 8, **i32)
+        verts_all = torch.empty(len(persons), NUM_VERTS, 3, **f32)
+        given_hits = "hit_index" in input and input["hit_index"] is not None
+        device_hull = not given_hits and self._obb_mode_now() == "hull" and not host_hull
         for n, p in enumerate(persons):
             server = self.smpl_server_list[p]
             prm = torch.cat([smpl_params[0, p, 0:1], smpl_trans[0, p], smpl_pose[0, p], smpl_shape[0, p]]).contiguous()
@@ -272,7 +275,7 @@ class Multiply(nn.Module):
                 prm[4:76] = 0
                 prm[4 + 5] = np.pi / 6
                 prm[4 + 8] = -np.pi / 6
-            verts = torch.empty(NUM_VERTS, 3, **f32)
+            verts = verts_all[n]
             tfs = torch.empty(NUM_JOINTS, 4, 4, **f32)
             jnts = torch.empty(NUM_JOINTS, 3, **f32)
             server.pose_into(prm, verts, tfs, jnts)
@@ -286,8 +289,25 @@ class Multiply(nn.Module):
                       "mp_blend_table")
             hit_index = torch.empty(R, **i32)
             inv_index = torch.empty(R, **i32)
+            cond = (smpl_pose[0, p, 3:] / np.pi).contiguous()          # multiply.py:270
+            per[p] = dict(verts=verts, tfs=tfs, btab=btab, vsorted=vsorted, cbound=cbound, hit_index=hit_index, obb=None,
+                          inv_index=inv_index, count=counts[n:n + 1], cond=cond, prm=prm,
+                          rest_joints=server.rest_joints() if self.training else None)
+        obb_all = None
+        if device_hull:
+            # the convex hulls (gift wrapping), the candidate searches and the boxes of ALL bodies in one batch on the device: no
+            # host round trip; the status words are read with the hit counts below (a failure -- exactly coplanar vertices
+            # tying into a non-manifold patch -- repeats the setup with the host-side hull)
+            hull_status = torch.zeros(len(persons), 8, **i32)
+            work = torch.empty(len(persons), int(L.mp_obb_hull_device_work_bytes()), dtype=torch.uint8, device=dev)
+            obb_all = torch.empty(len(persons), 16, **f32)
+            hip.check(L.mp_obb_hull_device(hip.ptr(verts_all), NUM_VERTS, len(persons), C.c_float(self.obb_inflate), hip.ptr(work),
+                                           hip.ptr(obb_all), hip.ptr(hull_status), st), "mp_obb_hull_device")
+        for n, p in enumerate(persons):
+            q = per[p]
+            verts, hit_index, inv_index, cbound = q["verts"], q["hit_index"], q["inv_index"], q["cbound"]
             obb = None
-            if "hit_index" in input and input["hit_index"] is not None:
+            if given_hits:
                 hi = input["hit_index"][p].to(dev).to(torch.int32).contiguous()
                 if hi.numel() == 0:      # multiply.py:262-263: no ray meets the box -> ray 0
                     hi = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -295,16 +315,8 @@ class Multiply(nn.Module):
                 hip.check(L.mp_ray_hits_from_index(hip.ptr(hit_index), hi.numel(), R, hip.ptr(counts[n:n + 1]),
                                                    hip.ptr(inv_index), st), "mp_ray_hits_from_index")
             else:
-                if self._obb_mode_now() == "hull" and not host_hull:
-                    # the convex hull (gift wrapping), the candidate search and the box all on the device: no host round trip;
-                    # its status word is read with the hit counts below (a failure -- exactly coplanar vertices tying into a
-                    # non-manifold patch -- repeats the setup with the host-side hull)
-                    if hull_status is None:
-                        hull_status = torch.zeros(len(persons), 8, **i32)
-                    work = torch.empty(int(L.mp_obb_hull_device_work_bytes()), dtype=torch.uint8, device=dev)
-                    obb = torch.empty(16, **f32)
-                    hip.check(L.mp_obb_hull_device(hip.ptr(verts), NUM_VERTS, C.c_float(self.obb_inflate), hip.ptr(work), hip.ptr(obb),
-                                                   hip.ptr(hull_status[n]), st), "mp_obb_hull_device")
+                if device_hull:
+                    obb = obb_all[n]
                 elif self._obb_mode_now() == "hull":
                     # hull on the host (Qhull, ~3 ms; one extra device sync), search + box on the device
                     from .obb import hull_search_inputs, obb_record
@@ -335,10 +347,7 @@ class Multiply(nn.Module):
                     hip.check(L.mp_ray_cull(hip.ptr(dirs), hip.ptr(pose), hip.ptr(obb), R, group, hip.ptr(hit_index),
                                             hip.ptr(counts[n:n + 1]), hip.ptr(inv_index), hip.ptr(scan_tmp), st),
                               "mp_ray_cull")
-            cond = (smpl_pose[0, p, 3:] / np.pi).contiguous()          # multiply.py:270
-            per[p] = dict(verts=verts, tfs=tfs, btab=btab, vsorted=vsorted, cbound=cbound, hit_index=hit_index, obb=obb,
-                          inv_index=inv_index, count=counts[n:n + 1], cond=cond, prm=prm,
-                          rest_joints=server.rest_joints() if self.training else None)
+            q["obb"] = obb
         if hull_status is not None:      # the one host sync of the call: sizes the per-person workspaces (+ the hulls' status)
             both = torch.cat([counts, hull_status[:, 3]]).tolist()
             n_hit = both[:len(persons)]

@@ -33,7 +33,7 @@ from multiply_amd.config import load_config
 from multiply_amd.loss import Loss
 model.train()
 loss_fn = Loss(load_config().loss)
-opt = torch.optim.Adam(model.parameters(), lr=5e-4)
+opt = torch.optim.Adam(model.parameters(), lr=5e-4, fused=True)
 g = torch.Generator().manual_seed(0)
 R = gin["uv"].shape[1]
 acc = {"fwd": 0.0, "loss": 0.0, "bwd": 0.0, "adam": 0.0, "sync": 0.0}

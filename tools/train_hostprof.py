@@ -18,7 +18,7 @@ gin = bench.to_dev(inp)
 model.train()
 model.async_setup = True
 loss_fn = Loss(load_config().loss)
-opt = torch.optim.Adam(model.parameters(), lr=5e-4)
+opt = torch.optim.Adam(model.parameters(), lr=5e-4, fused=True)
 g = torch.Generator().manual_seed(0)
 R = gin["uv"].shape[1]
 batches = []
