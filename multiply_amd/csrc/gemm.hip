@@ -568,10 +568,14 @@ __device__ __forceinline__ void tn_b3_tile(const float* __restrict__ A, int lda,
             const int r = r0 + 4 * rb + e;
             if constexpr (FAST) rr[e] = r < r_end ? *(const f32x4*)(src + (size_t)r * ld + c0) : (f32x4){0, 0, 0, 0};
             else rr[e] = r < r_end ? ld4(src + (size_t)r * ld + c0, al && c0 + 3 < cmax, cmax - c0) : (f32x4){0, 0, 0, 0};
-            if (do_sum && r < colsum_rows) csum += rr[e];
         }
     };
-    auto sstore = [&](int buf, const f32x4 (&rr)[4]) {
+    // (the column sums are taken at the LDS store, where the rows are consumed anyway -- not at the load, which would wait for it)
+    auto sstore = [&](int buf, const f32x4 (&rr)[4], int r0) {
+        if (do_sum)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (r0 + 4 * rb + e < colsum_rows) csum += rr[e];
         __bf16* tile = Ts + ((buf * 2 + (is_b ? 1 : 0)) * 2) * HALF + (rb * BM + 4 * mg) * 4;
         bf16x8 h[2], l[2];
 #pragma unroll
@@ -591,7 +595,7 @@ __device__ __forceinline__ void tn_b3_tile(const float* __restrict__ A, int lda,
 #pragma unroll
     for (int s_ = 0; s_ < PT; ++s_)
         if (s_ < nk) gload(rr_[s_], r_begin + s_ * BK);
-    if (nk > 0) sstore(0, rr_[0]);
+    if (nk > 0) sstore(0, rr_[0], r_begin);
     __syncthreads();
     // lane (li, kg): k slots = the 8 rows of row blocks 2 kg and 2 kg + 1, for its column
     auto frag = [&](const __bf16* tile, int col) {
@@ -623,7 +627,7 @@ __device__ __forceinline__ void tn_b3_tile(const float* __restrict__ A, int lda,
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
                     }
                 }
-                if (kt + 1 < nk) sstore(buf ^ 1, rr_[(u + 1) % PT]);
+                if (kt + 1 < nk) sstore(buf ^ 1, rr_[(u + 1) % PT], r_begin + (kt + 1) * BK);
                 __syncthreads();
             }
         }
@@ -698,6 +702,179 @@ __global__ __launch_bounds__(NT_THREADS, 2) void k_gemm_tn_b3g(TnGroups T, int m
     const int r_begin = (slice - T.slice0[gi]) * T.rows_per_block;
     tn_b3_tile<true>(G.A, G.lda, G.B, G.ldb, G.C, G.ldc, G.M, G.N, m0, n0, r_begin, min(G.K, r_begin + T.rows_per_block), G.colsum,
                      G.colsum_rows, by == 0);
+}
+
+
+// WIDE form of the grouped contraction: ONE workgroup computes the whole 256 x 256 output of its row slice, so every operand row
+// is read from HBM exactly once.  [The 128 x 128 tiles above read every column block twice; their four workgroups of a slice
+// sit on one XCD but drift apart by more than its 4 MB L2 holds, the second read misses, and the kernel runs at the HBM rate on
+// 2x its algorithmic bytes: 10.6 k cycles per 32-row stage, the matrix pipe 15 % busy.]  One workgroup per CU, 8 waves as 2 x 4,
+// each a 128 (m) x 64 (n) sub-tile = 128 accumulator registers per lane; a 32-row stage is 64 KB of operands, staged as above
+// (register transposition to [row block of 4][column][4 x bf16], hi and lo tiles), ONE stage ahead in registers (a second
+// stage in flight spills: 1.2 ms).  Measured (15 contractions of 50-60 k rows, one body): 0.65 ms = 3 TB/s, against 0.99 ms of
+// the 128 x 128 form.  Ablations: without the global loads 0.52 ms, without the matrix instructions 0.53 ms, plain stores
+// instead of atomics 0.62 ms: a stage costs ~10 k cycles of LDS staging + fragment reads + conversions + MFMA that the
+// lock-step of one barrier per stage does not overlap, and the loads fly only during the compute phase of one stage.
+constexpr int WT_ = 256;                                  // output tile (both ways)
+constexpr int WT_RB = WT_;                                // 8-byte slots between row blocks (padding them apart by 8 changed nothing)
+constexpr int LDS_B3W = 2 * 2 * 2 * (BK / 4) * WT_RB * 4 * 2;    // [stage][A | B][hi | lo][row block][column][4] bf16 = 128 KB
+#ifndef MP_EXP_TNW
+#define MP_EXP_TNW 0
+#endif
+__global__ __launch_bounds__(NT_THREADS, 1) void k_gemm_tn_b3w(TnGroups T, int n_slice) {
+    const int slice = blockIdx.x;
+    if (slice >= n_slice) return;
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < MP_TN_MAX_GROUPS; ++i)
+        if (i < T.n && slice >= T.slice0[i]) gi = i;
+    const MpTnGroup& G = T.g[gi];
+    const int r_begin = (slice - T.slice0[gi]) * T.rows_per_block, r_end = min(G.K, r_begin + T.rows_per_block);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int HALF = (BK / 4) * WT_RB * 4;              // bf16 elements of one [row block][column][4] tile
+    __bf16* Ts = (__bf16*)smem;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+    const int li = lane & 15, kg = lane >> 4;
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+    // staging: threads 0..255 take A, 256..511 take B; each TWO 4-row x 4-column blocks (row blocks rb and rb + 4) of the stage
+    const bool is_b = t >= 256;
+    const int tt = t & 255, mg = tt & 63, rb = tt >> 6;
+    const float* src = (is_b ? G.B : G.A) + 4 * mg;
+    const int ld = is_b ? G.ldb : G.lda;
+    float* colsum = G.colsum;
+    const int colsum_rows = G.colsum_rows;
+    const bool do_sum = colsum != nullptr && !is_b;
+#ifndef MP_TNW_PT
+#define MP_TNW_PT 1
+#endif
+    constexpr int PT = MP_TNW_PT;      // stages in flight in registers (32 registers each)
+    f32x4 rr_[PT][8], csum = {0.f, 0.f, 0.f, 0.f};
+    auto gload = [&](f32x4 (&rr)[8], int r0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = r0 + 4 * (rb + 4 * h) + e;
+#if MP_EXP_TNW & 2      // ablation: no global loads
+                rr[4 * h + e] = (f32x4){(float)r, 1.f, 2.f, 3.f};
+#else
+                rr[4 * h + e] = r < r_end ? *(const f32x4*)(src + (size_t)r * ld) : (f32x4){0, 0, 0, 0};
+#endif
+            }
+    };
+    // (the bias gradient's column sums are taken HERE, where the rows are consumed anyway: summed in gload they made the staging
+    // waves wait for their loads at once -- every stage paid the full memory latency)
+    auto sstore = [&](int buf, const f32x4 (&rr)[8], int r0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (do_sum)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (r0 + 4 * (rb + 4 * h) + e < colsum_rows) csum += rr[4 * h + e];
+            __bf16* tile = Ts + ((buf * 2 + (is_b ? 1 : 0)) * 2) * HALF + ((rb + 4 * h) * WT_RB + 4 * mg) * 4;
+            bf16x8 hh[2], ll[2];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 v = {rr[4 * h][c], rr[4 * h + 1][c], rr[4 * h + 2][c], rr[4 * h + 3][c]};
+                const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+                const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { hh[c >> 1][(c & 1) * 4 + e] = hi[e]; ll[c >> 1][(c & 1) * 4 + e] = lo[e]; }
+            }
+            *(bf16x8*)(tile) = hh[0];
+            *(bf16x8*)(tile + 8) = hh[1];
+            *(bf16x8*)(tile + HALF) = ll[0];
+            *(bf16x8*)(tile + HALF + 8) = ll[1];
+        }
+    };
+    const int nk = (r_end - r_begin + BK - 1) / BK;
+#pragma unroll
+    for (int s_ = 0; s_ < PT; ++s_)
+        if (s_ < nk) gload(rr_[s_], r_begin + s_ * BK);
+    if (nk > 0) sstore(0, rr_[0], r_begin);
+    __syncthreads();
+    auto frag = [&](const __bf16* tile, int col) {
+        const bf16x4 p = *(const bf16x4*)(tile + ((2 * kg) * WT_RB + col) * 4);
+        const bf16x4 q = *(const bf16x4*)(tile + ((2 * kg + 1) * WT_RB + col) * 4);
+        bf16x8 f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { f[e] = p[e]; f[4 + e] = q[e]; }
+        return f;
+    };
+    for (int kt0 = 0; kt0 < nk; kt0 += PT) {
+#pragma unroll
+        for (int u = 0; u < PT; ++u) {
+            const int kt = kt0 + u, buf = kt & 1;
+            if (kt < nk) {
+                if (kt + PT < nk) gload(rr_[u], r_begin + (kt + PT) * BK);
+                const __bf16* ta = Ts + (buf * 2 + 0) * 2 * HALF;
+                const __bf16* tb = Ts + (buf * 2 + 1) * 2 * HALF;
+                // the n half (32 columns) outermost: its four B fragments stay in registers, A's are read once per half (all 256
+                // registers of a lane are taken: 128 accumulators, 64 of the two stages in flight)
+#pragma unroll
+                for (int jh = 0; jh < 2; ++jh) {
+                    bf16x8 bh[2], bl[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        bh[j] = frag(tb, wn + 32 * jh + 16 * j + li);
+                        bl[j] = frag(tb + HALF, wn + 32 * jh + 16 * j + li);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const bf16x8 ah = frag(ta, wm + 16 * i + li), al_ = frag(ta + HALF, wm + 16 * i + li);
+#if MP_EXP_TNW & 1      // ablation: no matrix instructions
+                        acc[i][2 * jh][0] += (float)ah[0] + (float)al_[0] + (float)bh[0][0] + (float)bl[0][0] + (float)bh[1][0] + (float)bl[1][0];
+                        continue;
+#endif
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][2 * jh + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al_, bh[j], acc[i][2 * jh + j], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][2 * jh + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][2 * jh + j], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][2 * jh + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][2 * jh + j], 0, 0, 0);
+                        if (i & 1) __builtin_amdgcn_sched_barrier(0);      // (keeps the scheduler from hoisting every fragment read)
+                    }
+                }
+                if (kt + 1 < nk) sstore(buf ^ 1, rr_[(u + 1) % PT], r_begin + (kt + 1) * BK);
+                __syncthreads();
+            }
+        }
+    }
+    const int cn = lane & 15, cr = (lane >> 4) * 4;
+    float* Cm = G.C;
+    const int ldc = G.ldc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = wn + 16 * j + cn;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#if MP_EXP_TNW & 4      // ablation: plain stores instead of the split-K atomics (wrong sums)
+                Cm[(size_t)(wm + 16 * i + cr + r) * ldc + n] = acc[i][j][r];
+#else
+                atomicAdd(Cm + (size_t)(wm + 16 * i + cr + r) * ldc + n, acc[i][j][r]);
+#endif
+        }
+    if (colsum != nullptr) {   // A-staging threads with the same mg hold partial sums of the same 4 columns
+        __syncthreads();
+        float* red = smem;
+        for (int i = t; i < WT_; i += NT_THREADS) red[i] = 0.f;
+        __syncthreads();
+        if (!is_b)
+            for (int e = 0; e < 4; ++e) atomicAdd(&red[4 * mg + e], csum[e]);
+        __syncthreads();
+        for (int i = t; i < WT_; i += NT_THREADS)
+            if (red[i] != 0.f) atomicAdd(colsum + i, red[i]);
+    }
 }
 
 }  // namespace
@@ -826,12 +1003,44 @@ extern "C" int mp_gemm_tn_bf16x3_grouped(const MpTnGroup* groups, int n_groups, 
         mt = g.M / BM > mt ? g.M / BM : mt;
         nt = g.N / BN > nt ? g.N / BN : nt;
     }
+#ifndef MP_TNW_WGS
+#define MP_TNW_WGS 256    // workgroups of a wide launch: one per CU
+#endif
+    bool wide = true;
+    for (int i = 0; i < n_groups; ++i) wide = wide && groups[i].M == WT_ && groups[i].N == WT_;
+    if (wide) {
+        long long rows = (work / 4 + MP_TNW_WGS - 1) / MP_TNW_WGS;
+        rows = (rows + BK - 1) / BK * BK;
+        if (rows < 8 * BK) rows = 8 * BK;
+        int z = MP_TNW_WGS + 1;
+        while (z > MP_TNW_WGS) {         // every group rounds its slice count up: lengthen the slices until ONE round holds them all
+            z = 0;
+            for (int i = 0; i < n_groups; ++i) z += (int)((groups[i].K + rows - 1) / rows);
+            if (z > MP_TNW_WGS) rows += BK;
+        }
+        T.rows_per_block = (int)rows;
+        z = 0;
+        for (int i = 0; i < n_groups; ++i) {
+            T.slice0[i] = z;
+            z += (int)((groups[i].K + rows - 1) / rows);
+        }
+        T.slice0[n_groups] = z;
+        MP_LDS_ATTR(k_gemm_tn_b3w, LDS_B3W);
+        hipLaunchKernelGGL(k_gemm_tn_b3w, dim3(z), dim3(NT_THREADS), LDS_B3W, (hipStream_t)stream, T, z);
+        return (int)hipGetLastError();
+    }
 #ifndef MP_TNG_WGS
 #define MP_TNG_WGS 1024   // workgroups of a grouped launch: 2 resident per CU, two rounds
 #endif
     long long rows = (work + MP_TNG_WGS - 1) / MP_TNG_WGS;
     rows = (rows + BK - 1) / BK * BK;
     if (rows < 8 * BK) rows = 8 * BK;
+    for (;;) {                           // (as above: no third, nearly empty round of workgroups)
+        long long wgs = 0;
+        for (int i = 0; i < n_groups; ++i) wgs += (long long)(groups[i].M / BM) * (groups[i].N / BN) * ((groups[i].K + rows - 1) / rows);
+        if (wgs <= MP_TNG_WGS) break;
+        rows += BK;
+    }
     T.rows_per_block = (int)rows;
     int z = 0;
     for (int i = 0; i < n_groups; ++i) {
