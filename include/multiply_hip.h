@@ -183,7 +183,13 @@ int mp_blend_table(const float* skin_w, const float* tfs, int n_verts, float* ta
 int mp_warp_inverse(const float* pts, const float* dirs, const float* pose, const int* hit_index, const int* hit_count,
                     const float* z, int z_stride, int n_s, int max_rays, const float* vsorted, const float* cbound,
                     const float* blend_table, int mode, const int* ray_active, const int* launch_active,
-                    float* xc, unsigned char* outlier, float* sdf_out, int* worklist, int* work_count, void* stream);
+                    float* xc, unsigned char* outlier, float* sdf_out, int* worklist, int* work_count, void* bin_work,
+                    void* stream);
+/* bin_work (optional, mode 0 with implicit samples only; mp_warp_bin_work_bytes(max_rays * n_s) bytes, 16-byte aligned): the
+ * points are first grouped by their nearest vertex cluster, so that the 64 points of a wave open the same few clusters -- a
+ * training batch's random pixels otherwise scatter every wave over the whole body (50 of 108 clusters opened per wave).  Results
+ * are identical (they go out by point id); only the order of the worklist changes. */
+int mp_warp_bin_work_bytes(int n_points);
 /* The same for the final samples of the shading pass (z rows hold n_s+1 depths).  eval_mode: outliers get sdf 4 and are
  * dropped from the worklist only when their compositing alpha 1-exp(-sigma(4) dt) is exactly 0 in fp32.
  * need_flag [id] (optional) = 1 for every point that was appended; nn_index [id] (optional) = the nearest posed vertex
@@ -192,7 +198,7 @@ int mp_warp_inverse_shade(const float* dirs, const float* pose, const int* hit_i
                           const float* z, int z_stride, int n_s, int max_rays, const float* vsorted, const float* cbound,
                           const float* blend_table, int eval_mode, const float* beta, float* xc,
                           unsigned char* outlier, unsigned char* need_flag, float* sdf_out, int* worklist,
-                          int* work_count, int* nn_index, void* stream);
+                          int* work_count, int* nn_index, void* bin_work, void* stream);
 /* Jacobian of forward skinning at canonical points (deformer.py:31-35 + multiply.py:625-641): nearest CANONICAL
  * vertex -> weights -> J = (sum_j w_j T_j)[:3,:3] -> jinv [id][9].
  * n_s > 0: points are the samples of the hit rays (id = k*n_s + s, as in mp_warp_inverse_shade) and only ids with

@@ -414,7 +414,8 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
     const float4* __restrict__ btab, int mode, const int* __restrict__ ray_active,
     const float* __restrict__ beta_p, const int* __restrict__ launch_active, float* __restrict__ xc,
     unsigned char* __restrict__ outlier, unsigned char* __restrict__ need_flag, float* __restrict__ sdf_out,
-    int* __restrict__ worklist, int* __restrict__ work_count, int* __restrict__ nn_index) {
+    int* __restrict__ worklist, int* __restrict__ work_count, int* __restrict__ nn_index,
+    const float4* __restrict__ binned, const int* __restrict__ bincount) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (launch_active && *launch_active == 0) return;  // no ray of this launch is still being sampled
     float4* vs = (float4*)smem;
@@ -435,8 +436,12 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     GP_BEGIN();
-    const bool rays = pts == nullptr;
+    const bool rays = pts == nullptr && binned == nullptr;
     const int n_rays = rays ? min(*hit_count, max_rays) : 0;
+    if (binned) {          // the points in the order of k_warp_bin / k_warp_binned: n_pts = how many there are
+        n_pts = 0;
+        for (int c = 0; c < NC; ++c) n_pts += bincount[c];
+    }
     const int n_slab = rays ? ((n_rays + 63) / 64) * n_s : (n_pts + 63) / 64;
     float cam[3] = {0.f, 0.f, 0.f};
     if (rays) { cam[0] = pose[3]; cam[1] = pose[7]; cam[2] = pose[11]; }
@@ -455,6 +460,9 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
                 pid = k * n_s + s;
                 if (mode == 2) dt = z[(size_t)k * z_stride + s + 1] - t;
             }
+        } else if (binned) {
+            const int i = slab * 64 + lane;
+            if (i < n_pts) { const float4 q = binned[i]; x = q.x; y = q.y; zz = q.z; pid = __float_as_int(q.w); }
         } else {
             const int i = slab * 64 + lane;
             if (i < n_pts) { x = pts[3 * i]; y = pts[3 * i + 1]; zz = pts[3 * i + 2]; pid = i; }
@@ -522,6 +530,78 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
 #endif
     }
     GP_END();
+}
+
+// ---- TRAINING: the points of a wave grouped by their nearest vertex cluster -----------------------------------------------------
+// A training batch is 512 RANDOM pixels: the 64 hit rays of a slab are scattered over the body's box, and most samples of a ray
+// lie in free space far from the surface, where many clusters are about equally far.  The cluster scan is wave-uniform (a
+// cluster is scanned when ANY lane may improve in it), so such a slab opened 50 of the 108 clusters (measured: 226 k cycles per
+// slab, 1.15 ms per iteration).  Which 64 points share a wave is the kernel's own business -- results go out by point id -- so
+// the points are first binned by the cluster whose bounding sphere is nearest (k_warp_bin: one atomic per point gives bin and
+// rank), laid out bin after bin (k_warp_binned: position, point id), and k_warp_inverse walks that array.
+__device__ __forceinline__ bool warp_sample_point(const float* dirs, const float* pose, const int* hit_index, const float* z,
+                                                  int z_stride, int n_s, int n_rays, const int* ray_active, int i, float& x, float& y,
+                                                  float& zz) {
+    if (i >= n_rays * n_s) return false;
+    const int k = i / n_s, s = i - k * n_s;
+    if (ray_active && !ray_active[k]) return false;
+    const int r = hit_index[k];
+    const float t = z[(size_t)k * z_stride + s];
+    x = pose[3] + t * dirs[3 * r]; y = pose[7] + t * dirs[3 * r + 1]; zz = pose[11] + t * dirs[3 * r + 2];
+    return true;
+}
+__global__ __launch_bounds__(1024) void k_warp_bin(const float* __restrict__ dirs, const float* __restrict__ pose,
+                                                   const int* __restrict__ hit_index, const int* __restrict__ hit_count,
+                                                   const float* __restrict__ z, int z_stride, int n_s, int max_rays,
+                                                   const float* __restrict__ cbound, const int* __restrict__ ray_active,
+                                                   const int* __restrict__ launch_active, int* __restrict__ binrank,
+                                                   int* __restrict__ bincount) {
+    if (launch_active && *launch_active == 0) return;
+    __shared__ float4 cb[NC];
+    __shared__ int lcount[NC], lbase[NC];      // this workgroup's histogram, then its base rank in every bin
+    for (int i = threadIdx.x; i < NC; i += blockDim.x) { cb[i] = ((const float4*)cbound)[i]; lcount[i] = 0; }
+    __syncthreads();
+    const int n_rays = min(*hit_count, max_rays);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float x, y, zz;
+    const bool on = warp_sample_point(dirs, pose, hit_index, z, z_stride, n_s, n_rays, ray_active, i, x, y, zz);
+    int bc = 0, lrank = 0;
+    if (on) {
+        float best = FLT_MAX;
+        for (int c = 0; c < NC; ++c) {
+            const float4 b = cb[c];
+            const float ex = x - b.x, ey = y - b.y, ez = zz - b.z;
+            const float gap = sqrtf(ex * ex + ey * ey + ez * ez) - b.w;
+            if (gap < best) { best = gap; bc = c; }
+        }
+        lrank = atomicAdd(&lcount[bc], 1);     // (LDS: the global counters see one add per workgroup and bin, not one per point --
+    }                                          //  60 k same-address atomics on 108 words took 110 us)
+    __syncthreads();
+    for (int c = threadIdx.x; c < NC; c += blockDim.x) lbase[c] = lcount[c] ? atomicAdd(&bincount[c], lcount[c]) : 0;
+    __syncthreads();
+    if (on) binrank[i] = (bc << 24) | (lbase[bc] + lrank);
+    else if (i < max_rays * n_s) binrank[i] = -1;
+}
+__global__ __launch_bounds__(256) void k_warp_binned(const float* __restrict__ dirs, const float* __restrict__ pose,
+                                                     const int* __restrict__ hit_index, const int* __restrict__ hit_count,
+                                                     const float* __restrict__ z, int z_stride, int n_s, int max_rays,
+                                                     const int* __restrict__ launch_active, const int* __restrict__ binrank,
+                                                     const int* __restrict__ bincount, float4* __restrict__ binned) {
+    if (launch_active && *launch_active == 0) return;
+    __shared__ int start[NC];
+    if (threadIdx.x == 0) {
+        int a = 0;
+        for (int c = 0; c < NC; ++c) { start[c] = a; a += bincount[c]; }
+    }
+    __syncthreads();
+    const int n_rays = min(*hit_count, max_rays);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rays * n_s) return;
+    const int br = binrank[i];
+    if (br < 0) return;
+    float x, y, zz;
+    warp_sample_point(dirs, pose, hit_index, z, z_stride, n_s, n_rays, nullptr, i, x, y, zz);
+    binned[start[br >> 24] + (br & 0xffffff)] = make_float4(x, y, zz, __int_as_float(i));
 }
 
 // Points are addressed like in k_warp_inverse (slab = 64 neighbouring hit rays x one sample index, so the 64 canonical
@@ -1441,21 +1521,44 @@ extern "C" int mp_blend_table(const float* skin_w, const float* tfs, int n_verts
     return (int)hipGetLastError();
 }
 
+// bin_work (mp_warp_bin_work_bytes(max_rays * n_s) bytes, 16-byte aligned): [128] bin counts, [n] bin << 24 | rank, [n] float4
+extern "C" int mp_warp_bin_work_bytes(int n_points) { return 512 + 4 * ((n_points + 3) / 4 * 4) + 16 * n_points; }
+static void warp_bin(const float* dirs, const float* pose, const int* hit_index, const int* hit_count, const float* z, int z_stride,
+                     int n_s, int max_rays, const float* cbound, const int* ray_active, const int* launch_active, void* bin_work,
+                     hipStream_t st, const float4*& binned, const int*& bincount) {
+    const int n = max_rays * n_s;
+    int* cnt = (int*)bin_work;
+    int* binrank = cnt + 128;
+    float4* out = (float4*)((char*)bin_work + 512 + 4 * ((n + 3) / 4 * 4));
+    hipMemsetAsync(cnt, 0, 512, st);
+    hipLaunchKernelGGL(k_warp_bin, dim3((n + 1023) / 1024), dim3(1024), 0, st, dirs, pose, hit_index, hit_count, z, z_stride, n_s, max_rays,
+                       cbound, ray_active, launch_active, binrank, cnt);
+    hipLaunchKernelGGL(k_warp_binned, dim3((n + 255) / 256), dim3(256), 0, st, dirs, pose, hit_index, hit_count, z, z_stride, n_s,
+                       max_rays, launch_active, (const int*)binrank, (const int*)cnt, out);
+    binned = out;
+    bincount = cnt;
+}
+
 extern "C" int mp_warp_inverse(const float* pts, const float* dirs, const float* pose, const int* hit_index,
                                const int* hit_count, const float* z, int z_stride, int n_s, int max_rays,
                                const float* vsorted, const float* cbound, const float* blend_table,
                                int mode, const int* ray_active, const int* launch_active, float* xc,
-                               unsigned char* outlier, float* sdf_out, int* worklist, int* work_count, void* stream) {
+                               unsigned char* outlier, float* sdf_out, int* worklist, int* work_count, void* bin_work,
+                               void* stream) {
     // when pts != NULL, max_rays carries the number of explicit points and sdf_out may carry beta for mode 2 (unused)
     if (max_rays <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     MP_LDS_ATTR((k_warp_inverse), WARP_LDS);
     const int n_slab = pts ? (max_rays + 63) / 64 : ((max_rays + 63) / 64) * n_s;
     const int threads = warp_threads(n_slab), nw = threads / 64;
+    const float4* binned = nullptr;
+    const int* bincount = nullptr;
+    if (bin_work && !pts && (mode & 3) == 0) warp_bin(dirs, pose, hit_index, hit_count, z, z_stride, n_s, max_rays, cbound, ray_active,
+                                                      launch_active, bin_work, st, binned, bincount);
     hipLaunchKernelGGL(k_warp_inverse, dim3(warp_grid(n_slab, nw)), dim3(threads), WARP_LDS, st, pts, dirs, pose,
                        hit_index, hit_count, z, z_stride, n_s, max_rays, pts ? max_rays : 0, vsorted, cbound,
                        (const float4*)blend_table, mode & 3, ray_active, (const float*)nullptr, launch_active, xc, outlier, (unsigned char*)nullptr, sdf_out,
-                       worklist, work_count, (int*)nullptr);
+                       worklist, work_count, (int*)nullptr, binned, bincount);
     return (int)hipGetLastError();
 }
 
@@ -1464,16 +1567,21 @@ extern "C" int mp_warp_inverse_shade(const float* dirs, const float* pose, const
                                      const float* z, int z_stride, int n_s, int max_rays, const float* vsorted,
                                      const float* cbound, const float* blend_table, int eval_mode,
                                      const float* beta, float* xc, unsigned char* outlier, unsigned char* need_flag,
-                                     float* sdf_out, int* worklist, int* work_count, int* nn_index, void* stream) {
+                                     float* sdf_out, int* worklist, int* work_count, int* nn_index, void* bin_work,
+                                     void* stream) {
     if (max_rays <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     MP_LDS_ATTR((k_warp_inverse), WARP_LDS);
     const int n_slab = ((max_rays + 63) / 64) * n_s;
     const int threads = warp_threads(n_slab), nw = threads / 64;
+    const float4* binned = nullptr;
+    const int* bincount = nullptr;
+    if (bin_work && !eval_mode) warp_bin(dirs, pose, hit_index, hit_count, z, z_stride, n_s, max_rays, cbound, nullptr, nullptr, bin_work,
+                                         st, binned, bincount);
     hipLaunchKernelGGL(k_warp_inverse, dim3(warp_grid(n_slab, nw)), dim3(threads), WARP_LDS, st,
                        (const float*)nullptr, dirs, pose, hit_index, hit_count, z, z_stride, n_s, max_rays, 0, vsorted,
                        cbound, (const float4*)blend_table, eval_mode ? 2 : 0, (const int*)nullptr, beta, (const int*)nullptr, xc, outlier,
-                       need_flag, sdf_out, worklist, work_count, nn_index);
+                       need_flag, sdf_out, worklist, work_count, nn_index, binned, bincount);
     return (int)hipGetLastError();
 }
 

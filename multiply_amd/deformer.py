@@ -63,7 +63,7 @@ class SMPLDeformer(nn.Module):
         outl = torch.empty(n, dtype=torch.uint8, device=dev)
         hip.check(L.mp_warp_inverse(hip.ptr(x), None, None, None, None, None, 0, 1, n, hip.ptr(vs), hip.ptr(cb),
                                     hip.ptr(self._blend_table(smpl_tfs)), 0, None, None, hip.ptr(xc),
-                                    hip.ptr(outl), None, None, None, hip.stream()), "mp_warp_inverse")
+                                    hip.ptr(outl), None, None, None, None, hip.stream()), "mp_warp_inverse")
         return xc, outl.bool()
 
     def _blend_table(self, smpl_tfs):

@@ -410,6 +410,8 @@ class Multiply(nn.Module):
         xc_new = torch.empty(Rp * NE, 3, **f32)
         work = torch.empty(Rp * NE, **i32)
         wcount = torch.zeros(rs.max_total_iters + 1, **i32)
+        # training: the rays are random pixels -- the warp first groups a call's samples by their nearest vertex cluster
+        bin_work = torch.empty(int(L.mp_warp_bin_work_bytes(Rp * NE)), dtype=torch.uint8, device=dev) if train else None
         for it in range(rs.max_total_iters):
             with self._ph("sampler_warp"):
                 hip.check(L.mp_warp_inverse(None, hip.ptr(dirs), hip.ptr(pose), hip.ptr(pp["hit_index"]),
@@ -417,7 +419,8 @@ class Multiply(nn.Module):
                                             hip.ptr(pp["cbound"]), hip.ptr(pp["btab"]), 0 if train else 1,
                                             hip.ptr(active), hip.ptr(any_active[it:it + 1]), hip.ptr(xc_new), None,
                                             hip.ptr(sdfnew), hip.ptr(work),
-                                            hip.ptr(wcount[it:it + 1]), st), "mp_warp_inverse")
+                                            hip.ptr(wcount[it:it + 1]), hip.ptr(bin_work) if train else None, st),
+                          "mp_warp_inverse")
             with self._ph("sampler_mlp_sdf"):
                 hip.check(L.mp_mlp_sdf(C.byref(pk_sdf.net), hip.ptr(pk_sdf.wpack), hip.ptr(pk_sdf.bias),
                                        hip.ptr(xc_new), hip.ptr(work), hip.ptr(wcount[it:it + 1]), Rp * NE,
@@ -522,7 +525,7 @@ class Multiply(nn.Module):
             hip.check(L.mp_warp_inverse_shade(hip.ptr(dirs), hip.ptr(pose), hip.ptr(pp["hit_index"]), hip.ptr(pp["count"]),
                                               hip.ptr(zfinal), NZ, S, Rp, hip.ptr(pp["vsorted"]), hip.ptr(pp["cbound"]),
                                               hip.ptr(pp["btab"]), 1, hip.ptr(beta), hip.ptr(xc), None,
-                                              hip.ptr(need), hip.ptr(sdf), hip.ptr(work2), hip.ptr(wc2), hip.ptr(nn_posed), st),
+                                              hip.ptr(need), hip.ptr(sdf), hip.ptr(work2), hip.ptr(wc2), hip.ptr(nn_posed), None, st),
                       "mp_warp_inverse_shade")
             ph.__exit__()
             jinv = torch.empty(npts, 9, **f32)

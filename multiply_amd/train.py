@@ -173,11 +173,18 @@ class ImplicitTrain:
         dZ = dZ_last
         dcond = None
         dIN = torch.zeros(rows, E, dtype=F32, device=dZ.device) if want_dx else None
+        # the 256 x 256 weight gradients wait for ONE grouped launch at the end (six small contractions launched one by one
+        # cost 64 us each; their operands stay alive in `held`)
+        groups, held = [], []
         for l in range(len(self.lins) - 1, -1, -1):
             lw, Xl = self.lins[l], self.X[l]
             out = lw.out_dim
             kin = E if l == 0 else lw.in_dim
-            gemm_tn(_p(dZ), out, _p(Xl), Xl.shape[1], _p(lw.dW), lw.in_dim, out, kin, rows, _p(lw.db), P)
+            if TRAIN_PRECISION == "bf16x3" and l > 0 and out == 256 and kin == 256 and Xl.shape[1] == 256:
+                groups.append(tn_group(_p(dZ), out, _p(Xl), 256, _p(lw.dW), lw.in_dim, out, kin, rows, _p(lw.db), P))
+                held.append(dZ)
+            else:
+                gemm_tn(_p(dZ), out, _p(Xl), Xl.shape[1], _p(lw.dW), lw.in_dim, out, kin, rows, _p(lw.db), P)
             if l == 0:
                 # hoisted conditioning: dW0[:, E:] += db (x) cond ; d cond = W0[:, E:]^T db
                 _chk(L.mp_tr_hoist_bwd(_p(lw.db), out, lw.in_dim, E, net.cond_dim, _p(self.cond), _p(lw.dW), hip.stream()),
@@ -201,6 +208,8 @@ class ImplicitTrain:
             _chk(L.mp_tr_softplus_bwd(_p(self.Z[l - 1]), prev_out, rows, prev_out, Pm, C.c_float(scale), _p(dX), lw.in_dim,
                                       0, _p(dZp), prev_out, hip.stream()), "mp_tr_softplus_bwd")
             dZ = dZp
+        if groups:
+            gemm_tn_grouped(groups)
         return dcond
 
     def params(self):
@@ -936,9 +945,11 @@ class TrainGraph:
             # unseeded search opens every cluster: 228 us instead of ~30 per person)
             nn_posed = torch.empty(npts, dtype=torch.int32, device=dev)
             nn_cano = torch.empty(npts, dtype=torch.int32, device=dev) if self.pose_grad else None
+            # (a training batch's rays are random pixels: the warp first groups the samples by their nearest vertex cluster)
+            bin_work = torch.empty(int(L.mp_warp_bin_work_bytes(npts)), dtype=torch.uint8, device=dev)
             _chk(L.mp_warp_inverse_shade(_p(dirs), _p(pose), _p(pp["hit_index"]), _p(pp["count"]), _p(zfinal), NZ, S, Rp,
                                          _p(pp["vsorted"]), _p(pp["cbound"]), _p(pp["btab"]), 0, _p(beta),
-                                         _p(X), None, None, None, None, None, _p(nn_posed), st), "mp_warp_inverse_shade")
+                                         _p(X), None, None, None, None, None, _p(nn_posed), _p(bin_work), st), "mp_warp_inverse_shade")
             jinv = torch.empty(npts, 9, **f32)
             _chk(L.mp_warp_jacobian(_p(X), None, None, 0, 0, npts, _p(dfm.vsorted_c), _p(dfm.cbound_c), _p(pp["btab"]),
                                     _p(jinv), _p(nn_cano), _p(nn_posed), _p(dfm.verts_c_flat), st), "mp_warp_jacobian")
