@@ -876,23 +876,37 @@ def _table(ts, dev):
     return torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device=dev)
 
 
+def _random_prefixes(sizes, k, dev, gen):
+    """row i = the first k entries of a uniform random permutation of range(sizes[i]) (what torch.randperm(n)[:k] draws), all
+    rows in three launches: the k smallest of n independent uniform keys, in the order of their keys, ARE such a prefix.
+    [One torch.randperm per row is ~7 launches each: 84 of an iteration's ~570.]"""
+    n = max(sizes)
+    keys = torch.rand(len(sizes), n, device=dev, generator=gen)
+    if min(sizes) < n:
+        lim = torch.tensor(sizes, device=dev).unsqueeze(1)
+        keys = torch.where(torch.arange(n, device=dev).unsqueeze(0) < lim, keys, keys.new_full((), 2.0))
+    return torch.topk(keys, k, dim=1, largest=False, sorted=True).indices
+
+
 def make_draws(model, cx, gen=None):
     """The randomness one training forward consumes (ray_sampler.py:38,171,202; multiply.py:325; sampler.py:100):
     per person  t_rand [R_p,NE], u_final [R_p,N], extra_idx [max_iters,N_extra], eik_idx [512], eik_noise [512,3];
-    shared      bg_rand [R,N_bg].  Drawn on the device with torch's generator (torch.rand/randperm/randn = what the
-    reference calls)."""
+    shared      bg_rand [R,N_bg].  Drawn on the device with torch's generator; the permutation prefixes (the reference's
+    torch.randperm(n)[:k]) come from _random_prefixes, all persons at once."""
     rs, dev = model.ray_sampler, cx["dev"]
     NE, NS, NX = rs.N_samples_eval, rs.N_samples, rs.N_samples_extra
     kw = dict(device=dev, generator=gen)
     draws = {"person": {}}
-    for n, p in enumerate(cx["persons"]):
+    persons = list(cx["persons"])
+    T = rs.max_total_iters
+    extra = _random_prefixes([NE * k for k in range(1, T + 1)] * len(persons), NX, dev, gen).to(torch.int32).reshape(len(persons), T, NX)
+    nvs = [model.smpl_server_list[p].verts_c.reshape(-1, 3).shape[0] for p in persons]
+    eik = _random_prefixes(nvs, N_EIKONAL, dev, gen)
+    for n, p in enumerate(persons):
         Rp = max(int(cx["n_hit"][n]), 1)
-        nv = model.smpl_server_list[p].verts_c.reshape(-1, 3).shape[0]
         draws["person"][p] = dict(
-            t_rand=torch.rand(Rp, NE, **kw), u_final=torch.rand(Rp, NS, **kw),
-            extra_idx=torch.stack([torch.randperm(NE * k, **kw)[:NX] for k in range(1, rs.max_total_iters + 1)]
-                                  ).to(torch.int32).contiguous(),
-            eik_idx=torch.randperm(nv, **kw)[:N_EIKONAL], eik_noise=torch.randn(N_EIKONAL, 3, **kw))
+            t_rand=torch.rand(Rp, NE, **kw), u_final=torch.rand(Rp, NS, **kw), extra_idx=extra[n].contiguous(),
+            eik_idx=eik[n], eik_noise=torch.randn(N_EIKONAL, 3, **kw))
     draws["bg_rand"] = torch.rand(cx["R"], rs.N_samples_inverse_sphere, **kw)
     return draws
 
