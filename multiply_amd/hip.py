@@ -216,17 +216,18 @@ class PackedNet:
               "mp_pack_layer")
 
     def param_version(self):
-        vs = []
+        vs = [_GENERATION[0]]
         for p in self.plans:
             for t in self._params(p.lin):
                 if t is not None:
                     vs.append((t.data_ptr(), t._version))
         return tuple(vs)
 
-    def refresh(self, hoist_vec=None):
-        """(Re)packs the weights if a parameter changed, and the hoisted layer-0 bias for this call's conditioning."""
+    def refresh(self, hoist_vec=None, force=False):
+        """(Re)packs the weights if a parameter changed (or `force`: training mode, see invalidate_packed), and the hoisted
+        layer-0 bias for this call's conditioning."""
         ver = self.param_version()
-        full = ver != self.version
+        full = force or ver != self.version
         for i, p in enumerate(self.plans):
             if full:
                 self._pack_layer(i, True, hoist_vec if p.hoist is not None else None)
@@ -329,6 +330,19 @@ def rendering_plans(net):
         else:
             plans.append(LayerPlan(lin, rows, reg_cols=np.arange(net.dims[l]), act=act, out_chunk=0 if last else -1))
     return plans
+
+
+# The packed weights are keyed on the parameters' (data_ptr, _version).  That is NOT enough for every optimizer: torch's fused
+# Adam (torch._fused_adam_) updates the parameters WITHOUT bumping their version counters, so a cache keyed on them alone would
+# keep rendering with the weights of the first step.  Two guards: a forward in training mode always repacks (force=True: the
+# weights are expected to change between calls there), and every train() / eval() switch of the model bumps this generation,
+# which is part of every cache key -- the first eval render after training packs afresh whatever the optimizer did.
+_GENERATION = [0]
+
+
+def invalidate_packed():
+    """Forget every packed-weight cache (call after modifying parameters in a way that does not bump their _version)."""
+    _GENERATION[0] += 1
 
 
 def packed(module, role, ks_in):

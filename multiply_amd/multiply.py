@@ -154,6 +154,13 @@ class Multiply(nn.Module):
         torch.cuda.synchronize()
         return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.phase_events.items()}
 
+    def train(self, mode=True):
+        """nn.Module.train, and every switch of mode drops the packed-weight caches (hip.invalidate_packed: an optimizer may have
+        updated the parameters without bumping their version counters -- torch's fused Adam does)"""
+        if bool(mode) != self.training:
+            hip.invalidate_packed()
+        return super().train(mode)
+
     def _obb_mode_now(self):
         if self.obb_mode not in ("auto", "hull", "pca"):
             raise ValueError(f"obb_mode {self.obb_mode!r}: expected 'auto', 'hull' or 'pca'")
@@ -200,7 +207,7 @@ class Multiply(nn.Module):
                 cache = self.__dict__.get("_eval_beta")
                 # keyed on the parameter OBJECT, its storage and its version: writes through .data and a replaced Parameter with the
                 # same version number must not leave a stale value behind (a load_state_dict bumps the version: copy_ in place)
-                key = (id(b), b.data_ptr(), b._version, str(b.device))
+                key = (id(b), b.data_ptr(), b._version, str(b.device), hip._GENERATION[0])
                 if cache is None or cache[0] != key:
                     val = (b.detach().abs() + self.density.beta_min).reshape(1).float().contiguous()   # caller's stream
                     ev = torch.cuda.Event()
@@ -391,7 +398,7 @@ class Multiply(nn.Module):
         imp = self.foreground_implicit_network_list[p]
         skin_w = self.smpl_server_list[p].tables.lbs_weights
         pk_sdf = hip.packed(imp, "sdf", 2)
-        pk_sdf.refresh(pp["cond"])
+        pk_sdf.refresh(pp["cond"], force=self.training)
         zs = torch.empty(Rp, ZM, **f32); sdfs = torch.empty(Rp, ZM, **f32)
         nz = torch.empty(Rp, **i32); znew = torch.empty(Rp, NE, **f32); sdfnew = torch.empty(Rp, NE, **f32)
         betar = torch.empty(Rp, **f32); active = torch.empty(Rp, **i32)

@@ -82,6 +82,15 @@ def gemm_tn_grouped(groups):
         _chk(hip.lib().mp_gemm_tn_bf16x3_grouped(arr, len(chunk), hip.stream()), "mp_gemm_tn_bf16x3_grouped")
 
 
+def _big_empty(n_floats, dev, grain=1 << 26):
+    """fp32 scratch of at least n_floats, allocated in multiples of `grain` floats (256 MiB).  The per-iteration stashes are
+    gigabytes whose exact size follows the number of rays that hit each body, i.e. changes every iteration: an exact-size
+    request misses torch's caching allocator whenever it exceeds every cached block, and a fresh hipMalloc of 3 GB stalls the
+    host for milliseconds (measured: 520 torch.empty calls = 12 ms of host time per iteration, nearly all of it in the two
+    arena allocations).  A few coarse sizes are cached after the first iterations and always hit."""
+    return torch.empty((n_floats + grain - 1) // grain * grain, dtype=F32, device=dev)
+
+
 def off(t, n_floats):
     """device pointer `n_floats` floats into tensor t"""
     return C.c_void_p(t.data_ptr() + 4 * n_floats)
@@ -599,7 +608,7 @@ class ImplicitTrainFused(ImplicitTrainRev):
         self.lins, self.nl = fs.lins, len(fs.lins)
         arena = C.c_longlong(0)
         _chk(L.mp_tf_sdf_sizes(P, C.byref(arena), None), "mp_tf_sdf_sizes")
-        self.arena = torch.empty(int(arena.value), dtype=F32, device=dev)
+        self.arena = _big_empty(int(arena.value), dev)
         R1 = 256 * (P + 1)                               # every [P][256] stash tensor carries one pad row (csrc/tfuse.hip)
         self.o_dZ = lambda l: l * R1
         self.o_V = lambda l: (8 + l) * R1
@@ -820,7 +829,7 @@ class RenderTrainFused:
         self.lins = cs.lins
         stash = C.c_longlong(0)
         _chk(L.mp_tf_col_sizes(n, C.byref(stash), None), "mp_tf_col_sizes")
-        self.stash = torch.empty(int(stash.value), dtype=F32, device=dev)
+        self.stash = _big_empty(int(stash.value), dev)
         self.rgb = torch.empty(n, 3, dtype=F32, device=dev)
         _chk(L.mp_tf_col_fwd(_p(cs.wpack), _p(cs.bias_all), _p(self.stash), _p(feat), _p(XA), n, _p(self.rgb), st), "mp_tf_col_fwd")
 

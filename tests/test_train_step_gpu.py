@@ -219,6 +219,36 @@ def test_training_step_reduces_loss():
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
 
 
+def test_eval_after_a_fused_optimizer_step_uses_the_updated_weights():
+    """torch's fused Adam updates the parameters WITHOUT bumping their version counters, which the packed-weight caches of the
+    f16 kernels are keyed on: the eval render after such a step must not come from the stale pack (Multiply.train() drops the
+    caches, training-mode forwards always repack).  The eval pixels after the step must differ from those before it and equal a
+    render of a FRESH model loaded with the same state dict."""
+    model, oracle, inp, gin, gt, loss_fn, train = _train_setup()
+    ein = {k: v for k, v in gin.items() if k not in ("current_epoch", "index_outside", "smpl_pose_last")}
+    model.eval()
+    with torch.no_grad():
+        before = model(ein)["rgb_values"].clone()
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=5e-3, fused=True)
+    for _ in range(2):
+        lo = loss_fn(model(gin), gt)
+        opt.zero_grad()
+        lo["loss"].backward()
+        opt.step()
+    model.eval()
+    with torch.no_grad():
+        after = model(ein)["rgb_values"].clone()
+    fresh, _, _ = build(H=11, W=11)      # a model that never saw the optimizer: no cache to be stale
+    fresh.load_state_dict(model.state_dict())
+    fresh.eval()
+    with torch.no_grad():
+        want = fresh(ein)["rgb_values"]
+    print("[info] eval pixels moved by", float((after - before).abs().max()), "; vs fresh model", float((after - want).abs().max()))
+    assert float((after - before).abs().max()) > 1e-4
+    assert float((after - want).abs().max()) == 0.0
+
+
 def test_smpl_pose_backward_matches_autograd(smpl_tables):
     """mp_smpl_pose_bwd: adjoint of the bone transforms w.r.t. [scale, transl, thetas, betas] vs torch autograd on the
     oracle's SMPLServer restatement (incl. the |theta + 1e-8| Rodrigues quirk and a zero rotation)."""

@@ -48,4 +48,4 @@ for i in range(3, 8):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(28)
+st.sort_stats("tottime").print_stats(45)
