@@ -1173,14 +1173,24 @@ __device__ bool hw_insert(unsigned* keys, unsigned short* vals, int u, int v, in
 constexpr int HW_G = 8;
 __device__ __forceinline__ void hw_store(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned hw_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void hw_grid_barrier(unsigned* bar, unsigned& target) {
+// false: the wrap was abandoned -- a peer waited ~0.3 s for this barrier (xch[3]).  The HW_G workgroups of a body spin on each
+// other, so they must all be resident; should something else hold the XCD's CUs for good (several processes sharing the GPU,
+// each with a partly scheduled wrap), the kernel gives up instead of hanging and the caller takes the host-side hull.
+__device__ __forceinline__ bool hw_grid_barrier(unsigned* xch, unsigned& target, int* lds_flag) {
     __syncthreads();
     if (threadIdx.x == 0) {
         target += HW_G;
-        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        __hip_atomic_fetch_add(xch, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 1;
+        for (unsigned spins = 0; __hip_atomic_load(xch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target; ++spins) {
+            if (hw_load(&xch[3]) != 0u) { ok = 0; break; }
+            if (spins > (1u << 18)) { hw_store(&xch[3], 1u); ok = 0; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        *lds_flag = ok;
     }
     __syncthreads();
+    return *lds_flag != 0;
 }
 // exclusive prefix sum of one small count per thread over the workgroup (two barriers); tot = the sum
 __device__ __forceinline__ int hw_scan(int x, int* wsum, int& tot) {
@@ -1204,7 +1214,7 @@ __device__ __forceinline__ bool hw_insert_cas(unsigned* keys, unsigned short* va
     }
     return false;
 }
-// xch (global, zeroed by the launcher): [0] barrier counter, [1] front size, [2] failed; records [HW_FRONT][4] at word 64:
+// xch (global, zeroed by the launcher): [0] barrier counter, [1] front size, [2] failed, [3] abandoned; records [HW_FRONT][4] at word 64:
 // {u << 16 | v, a << 16 | b, c, -} = the open edge and the facet it belongs to; pivots [HW_FRONT] after them.
 // out: counts {H, F, E, status, rounds, clocks}; hv [<= V][3], normals [<= HW_MAXF][3], evec / ena / enb [<= 3 HW_MAXF / 2][3]  (fp64)
 __global__ __launch_bounds__(HW_T) void k_hull_wrap(const float* __restrict__ verts, int V, unsigned* __restrict__ xch,
@@ -1295,8 +1305,9 @@ __global__ __launch_bounds__(HW_T) void k_hull_wrap(const float* __restrict__ ve
     // ---- wrap, one round per front: edge (u, v) of a facet has its twin (v, u) in the facet across it
     long long t_piv = 0, t_ins = 0, t_all = clock64();
     int n_round = 0;
+    bool abandoned = false;
     for (int round = 0; round < 4 * HW_MAXF; ++round) {
-        hw_grid_barrier(xch, bar_target);                  // the front is published
+        if (!hw_grid_barrier(xch, bar_target, red + 39)) { abandoned = true; break; }      // the front is published
         const int n = (int)hw_load(&xch[1]);
         if (n == 0 || hw_load(&xch[2]) != 0u) break;
         ++n_round;
@@ -1330,7 +1341,7 @@ __global__ __launch_bounds__(HW_T) void k_hull_wrap(const float* __restrict__ ve
             }
             __syncthreads();
         }
-        hw_grid_barrier(xch, bar_target);                  // the pivots are published
+        if (!hw_grid_barrier(xch, bar_target, red + 39)) { abandoned = true; break; }      // the pivots are published
         const long long t1 = clock64();
         t_piv += t1 - t0;
         if (!master) continue;
@@ -1386,7 +1397,7 @@ __global__ __launch_bounds__(HW_T) void k_hull_wrap(const float* __restrict__ ve
     if (!master) return;
     if (t == 0) { counts[4] = n_round; counts[5] = (int)(t_piv >> 4); counts[6] = (int)(t_ins >> 4); counts[7] = (int)((clock64() - t_all) >> 4); }
     const int F = red[34];
-    const bool fail = red[33] != 0 || red[35] != 0;
+    const bool fail = abandoned || red[33] != 0 || red[35] != 0;
     __syncthreads();
     // ---- outputs
     int* cnt = red + 40;                                   // [0] hull vertices, [1] edges

@@ -332,6 +332,42 @@ def rendering_plans(net):
     return plans
 
 
+class _PinnedInts:
+    """Small integer tables (device pointer lists, sizes) host -> device WITHOUT a host wait.  torch.tensor(list, device=dev)
+    is a blocking copy from pageable memory: torch synchronises the current stream behind it, i.e. the host waits for every
+    kernel enqueued so far -- seven such tables per training iteration kept the host from ever running ahead of the GPU.
+    Here the values go into a ring of pinned memory and are copied with non_blocking=True (stream-ordered, no wait); a slot is
+    reused after 64 k entries, long after its copy has run."""
+
+    def __init__(self, n=1 << 16):
+        self.buf = torch.empty(n, dtype=torch.int64).pin_memory()
+        self.view = self.buf.numpy()
+        self.pos = 0
+
+    def put(self, values, dev):
+        k = len(values)
+        if self.pos + k > self.buf.numel():
+            self.pos = 0
+        sl = slice(self.pos, self.pos + k)
+        self.view[sl] = values
+        self.pos += k
+        return self.buf[sl].to(dev, non_blocking=True)
+
+
+_PINNED = {}
+
+
+def device_ints(values, dev):
+    """int64 device tensor of a short Python list (see _PinnedInts); CPU device: a plain tensor"""
+    dev = torch.device(dev)
+    if dev.type != "cuda":
+        return torch.tensor(list(values), dtype=torch.int64, device=dev)
+    ring = _PINNED.get("ring")
+    if ring is None:
+        ring = _PINNED["ring"] = _PinnedInts()
+    return ring.put(list(values), dev)
+
+
 # The packed weights are keyed on the parameters' (data_ptr, _version).  That is NOT enough for every optimizer: torch's fused
 # Adam (torch._fused_adam_) updates the parameters WITHOUT bumping their version counters, so a cache keyed on them alone would
 # keep rendering with the weights of the first step.  Two guards: a forward in training mode always repacks (force=True: the

@@ -586,7 +586,8 @@ class Multiply(nn.Module):
         rs = self.ray_sampler
         dev = cx["dev"]
         key = "image_id" if "image_id" in input else "idx"      # multiply.py:407-410
-        code = self.frame_latent_encoder.weight.detach()[int(torch.as_tensor(input[key]).reshape(-1)[0])]
+        w_lat = self.frame_latent_encoder.weight.detach()        # (row looked up on the device: no device -> host wait)
+        code = w_lat.index_select(0, torch.as_tensor(input[key]).reshape(-1)[:1].to(w_lat.device, torch.long))[0]
         t = torch.linspace(0.0, 1.0, rs.N_samples_inverse_sphere, device=dev)
         z_bg = torch.flip(t * (1.0 / rs.scene_bounding_sphere), dims=[0]).contiguous()
         with self._ph("background"):
@@ -603,7 +604,7 @@ class Multiply(nn.Module):
         NZ = self.ray_sampler.N_samples + self.ray_sampler.N_samples_extra + 2
 
         def table(key):
-            return torch.tensor([per[p][key].data_ptr() for p in persons], dtype=torch.int64, device=dev)
+            return hip.device_ints([per[p][key].data_ptr() for p in persons], dev)
         t_inv, t_z, t_sdf, t_rgb, t_nrm = table("inv_index"), table("zfinal"), table("sdf"), table("rgb"), table("nrm")
         rgb_values = torch.empty(R, 3, **f32); fg_rgb_values = torch.empty(R, 3, **f32)
         normal_values = torch.empty(R, 3, **f32); acc_map = torch.empty(R, **f32)

@@ -882,7 +882,7 @@ SDF_TRAIN_MODE = __import__("os").environ.get("MP_SDF_TRAIN_MODE", "fused")
 
 
 def _table(ts, dev):
-    return torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device=dev)
+    return hip.device_ints([t.data_ptr() for t in ts], dev)      # (no host wait: hip._PinnedInts)
 
 
 def _random_prefixes(sizes, k, dev, gen):
@@ -890,9 +890,10 @@ def _random_prefixes(sizes, k, dev, gen):
     rows in three launches: the k smallest of n independent uniform keys, in the order of their keys, ARE such a prefix.
     [One torch.randperm per row is ~7 launches each: 84 of an iteration's ~570.]"""
     n = max(sizes)
+    assert k <= min(sizes), "a permutation prefix longer than the permutation"
     keys = torch.rand(len(sizes), n, device=dev, generator=gen)
     if min(sizes) < n:
-        lim = torch.tensor(sizes, device=dev).unsqueeze(1)
+        lim = hip.device_ints(sizes, dev).unsqueeze(1)
         keys = torch.where(torch.arange(n, device=dev).unsqueeze(0) < lim, keys, keys.new_full((), 2.0))
     return torch.topk(keys, k, dim=1, largest=False, sorted=True).indices
 
@@ -1074,8 +1075,11 @@ class TrainGraph:
         bg_rgb = None
         if self.input.get("idx", None) is not None:
             key = "image_id" if "image_id" in self.input else "idx"
-            self.frame = int(torch.as_tensor(self.input[key]).reshape(-1)[0])
-            code = m.frame_latent_encoder.weight.detach()[self.frame].contiguous()
+            # the frame's row of the latent table, looked up ON THE DEVICE: int(<device tensor>) is a device -> host copy that
+            # waits for everything enqueued so far (the whole previous iteration), i.e. the host could never run ahead
+            w_lat = m.frame_latent_encoder.weight
+            self.frame = torch.as_tensor(self.input[key]).reshape(-1)[:1].to(w_lat.device, torch.long, non_blocking=True)
+            code = w_lat.detach().index_select(0, self.frame)[0].contiguous()
             NB = rs.N_samples_inverse_sphere
             Rb = s1 - s0                                              # this rank's rays of the background branch
             bdirs = dirs[s0:s1].contiguous()
@@ -1239,7 +1243,7 @@ class TrainGraph:
             collect(bit); collect(brt)
             w = m.frame_latent_encoder.weight
             gw = torch.zeros_like(w)
-            gw[self.frame] = dcode
+            gw.index_copy_(0, self.frame, dcode.reshape(1, -1))
             grads[id(w)] = gw
         bp = m.density.beta
         grads[id(bp)] = (d_beta.reshape(bp.shape) * torch.sign(bp.detach())).to(bp.dtype)     # density.py:31-33
