@@ -101,9 +101,7 @@ def soft_blend_selected(verts, faces, colors, sel, R, T, focal, principal, H, W,
     def edge(p, a, b):
         return (p[..., 0] - a[..., 0]) * (b[..., 1] - a[..., 1]) - (p[..., 1] - a[..., 1]) * (b[..., 0] - a[..., 0])
 
-    parts = []
-    for i in range(0, act.shape[0], chunk):
-        rc = act[i:i + chunk]
+    def blend(sxy, z, cols, rc):
         fsel = sel[rc[:, 0], rc[:, 1]].long()                                     # (n, K)
         mask = fsel >= 0
         tri = faces[fsel.clamp(min=0)]                                            # (n, K, 3)
@@ -129,7 +127,19 @@ def soft_blend_selected(verts, faces, colors, sel, R, T, focal, principal, H, W,
         delta = torch.exp((eps - zmax) / SOFT_GAMMA).clamp(min=eps)
         den = w.sum(-1, keepdim=True) + delta
         rgb = ((w[..., None] * tex).sum(-2) + delta) / den                         # white background
-        parts.append(torch.cat([rgb, 1.0 - alpha[:, None]], 1))
+        return torch.cat([rgb, 1.0 - alpha[:, None]], 1)
+
+    # a chunk's (n, K = 100, ...) intermediates are recomputed in the backward pass instead of kept: without the checkpoint
+    # autograd holds every chunk's until backward (several GB for a 512 x 512 frame with the blur halo)
+    grad = torch.is_grad_enabled() and (sxy.requires_grad or cols.requires_grad)
+    parts = []
+    for i in range(0, act.shape[0], chunk):
+        rc = act[i:i + chunk]
+        if grad:
+            from torch.utils.checkpoint import checkpoint
+            parts.append(checkpoint(blend, sxy, z, cols, rc, use_reentrant=False))
+        else:
+            parts.append(blend(sxy, z, cols, rc))
     return act, torch.cat(parts)
 
 
