@@ -82,12 +82,16 @@ def gemm_tn_grouped(groups):
         _chk(hip.lib().mp_gemm_tn_bf16x3_grouped(arr, len(chunk), hip.stream()), "mp_gemm_tn_bf16x3_grouped")
 
 
-def _big_empty(n_floats, dev, grain=1 << 26):
+def _big_empty(n_floats, dev, grain=1 << 26, cap=None, cap_bytes=6 << 30):
     """fp32 scratch of at least n_floats, allocated in multiples of `grain` floats (256 MiB).  The per-iteration stashes are
     gigabytes whose exact size follows the number of rays that hit each body, i.e. changes every iteration: an exact-size
     request misses torch's caching allocator whenever it exceeds every cached block, and a fresh hipMalloc of 3 GB stalls the
     host for milliseconds (measured: 520 torch.empty calls = 12 ms of host time per iteration, nearly all of it in the two
-    arena allocations).  A few coarse sizes are cached after the first iterations and always hit."""
+    arena allocations).  A few coarse sizes are cached after the first iterations and always hit.  cap (floats): an upper bound of
+    every request of this call site; when it is affordable (<= cap_bytes) it is what is allocated -- one size for good, so that no
+    later iteration with a few more hit rays pays a fresh hipMalloc inside a timed region."""
+    if cap is not None and n_floats <= cap and 4 * cap <= cap_bytes:
+        n_floats = cap
     return torch.empty((n_floats + grain - 1) // grain * grain, dtype=F32, device=dev)
 
 
@@ -597,7 +601,9 @@ class ImplicitTrainFused(ImplicitTrainRev):
     Same interface: self.out [P][257], self.grad [P][3], backward(dZ_last, dgrad) -> d cond.  The adjoint of the input points
     (pose optimisation) is not produced here: TrainGraph takes ImplicitTrainRev when it is needed."""
 
-    def __init__(self, net, x, cond_vec, lins=None):
+    def __init__(self, net, x, cond_vec, lins=None, p_cap=None):
+        """p_cap: the largest P this caller can ever pass (all rays hit the body): the stash is then sized for it, i.e. the SAME
+        allocation every iteration (_big_empty)"""
         L, st = hip.lib(), hip.stream()
         assert fused_sdf_supported(net)
         self.net, self.x, self.cond = net, x, cond_vec
@@ -608,7 +614,12 @@ class ImplicitTrainFused(ImplicitTrainRev):
         self.lins, self.nl = fs.lins, len(fs.lins)
         arena = C.c_longlong(0)
         _chk(L.mp_tf_sdf_sizes(P, C.byref(arena), None), "mp_tf_sdf_sizes")
-        self.arena = _big_empty(int(arena.value), dev)
+        cap = None
+        if p_cap is not None and p_cap >= P:
+            capv = C.c_longlong(0)
+            _chk(L.mp_tf_sdf_sizes(int(p_cap), C.byref(capv), None), "mp_tf_sdf_sizes")
+            cap = int(capv.value)
+        self.arena = _big_empty(int(arena.value), dev, cap=cap)
         R1 = 256 * (P + 1)                               # every [P][256] stash tensor carries one pad row (csrc/tfuse.hip)
         self.o_dZ = lambda l: l * R1
         self.o_V = lambda l: (8 + l) * R1
@@ -994,7 +1005,7 @@ class TrainGraph:
             rev = mode != "forward"
             li, lr = self.ts.lins[id(imp)], self.ts.lins[id(ren)]
             if mode == "fused":
-                it = ImplicitTrainFused(imp, X, pp["cond"], lins=li)
+                it = ImplicitTrainFused(imp, X, pp["cond"], lins=li, p_cap=R * S + E)
             else:
                 it = ImplicitTrainRev(imp, X, pp["cond"], lins=li) if rev else ImplicitTrain(imp, X, pp["cond"], fwd=True, lins=li)
             gptr = _p(it.grad) if rev else None
