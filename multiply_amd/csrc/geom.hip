@@ -1072,18 +1072,20 @@ extern "C" int mp_knn_build(const float* verts, const int* perm, float* vsorted,
 
 // ------------------------------------------------------------------------------------------------ convex hull on the device
 // The hull the minimum-volume box search needs (facet normals, hull vertices, edges with the normals of their two facets) by GIFT
-// WRAPPING, one workgroup: the reference's trimesh call (multiply.py:208-214) runs on the host behind a device -> host copy of
-// the posed vertices, and round 3 kept that copy for Qhull.  A posed body's hull has 150-600 vertices / 300-1 200 facets.
+// WRAPPING: the reference's trimesh call (multiply.py:208-214) runs on the host behind a device -> host copy of the posed
+// vertices, and round 3 kept that copy for Qhull.  A posed body's hull has 150-600 vertices / 300-1 200 facets.
 //   pivot(a, b) = the vertex d with every other vertex q on the non-positive side of plane (a, b, d) (fp64 on the fp32
 // coordinates: differences exact, products rounded).  All vertices lie within a half-turn around a hull edge, so the pivot is
-// a reduction over an angle (hw_pivot_wave).  The wrap is LEVEL-SYNCHRONOUS: the open edges of the current front are pivoted in parallel, ONE WAVE PER EDGE
-// (a wave scans all vertices, 108 per lane, and reduces with shuffles: no workgroup barrier inside a pivot -- the first version
-// pivoted one edge at a time with the whole workgroup, five barriers per facet: 6 us per facet, 2.1 ms per body), then thread 0
-// inserts the round's facets one after the other -- a triangle reached from two of its edges in the same round is recognised
-// by its directed edge already being in the table -- and collects the next front.  ~25 rounds, ~0.3 ms per body.
+// a reduction over an angle (hw_pivot_part).  The wrap is LEVEL-SYNCHRONOUS: the open edges of the current front are pivoted in
+// parallel, one wave per edge -- or several waves per edge while the front is short -- by the HW_G workgroups of a body (see
+// k_hull_wrap), then the master workgroup inserts the round's facets and collects the next front.  ~15 rounds, 0.37 ms for the
+// bodies of a call.  [History: one workgroup pivoting one edge at a time, five barriers per facet: 2.1 ms per body; one
+// workgroup, one wave per edge, pairwise orientation tests: 1.2 ms; the angle reduction alone changed nothing -- a single CU
+// evaluates 700 pivots x 6 890 vertices whatever the predicate; spreading the pivots over 8 CUs did.]
 // Ties (exactly coplanar vertices) go to the lower index; should they ever produce a non-manifold patch (a directed edge used
 // twice) or the tables overflow, status is set and the caller falls back to the host-side hull.
-// LDS: the vertices (83 KB), an open-addressing table directed edge -> facet (48 KB), the facets (12 KB), two fronts (8 KB).
+// LDS per workgroup: the vertices (83 KB), an open-addressing table directed edge -> facet (48 KB, master only), the facets
+// (12 KB), the front and the candidates' keys (12 KB).
 constexpr int HW_T = 1024, HW_MAXF = 2048, HW_TAB = 8192, HW_MAXV = 6912, HW_FRONT = 1024;
 constexpr int HW_LDS = HW_MAXV * 12 + HW_TAB * 4 + HW_TAB * 2 + HW_MAXF * 6 + 2 * HW_FRONT * 4 + HW_FRONT * 4 + 64 * 4 + 16 * 24;
 // one WAVE: the pivot around the directed edge (v, u) away from a known supporting plane through it with OUTWARD normal n (the
