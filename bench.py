@@ -418,6 +418,9 @@ def main():
         gin, assemble = to_dev(inp), None
 
     model.profile = True                     # the warm-up also creates the pool of timing events the phases use
+    # the frame's inputs are resident before the loop: the setup (SMPL, culls) and its one host sync run on a side stream, so that
+    # the host keeps enqueuing ahead of the GPU from frame to frame (Multiply._setup, async_setup)
+    model.async_setup = os.environ.get("MP_BENCH_ASYNC_EVAL", "1") == "1"
     for _ in range(args.warmup):
         o = model(gin)
         if assemble is not None:
@@ -428,6 +431,7 @@ def main():
         gather_evs.clear()
     elapsed, shaded, sdf_evals = timed_frames(model, gin, args.steps, barrier, assemble)
     model.profile = False
+    model.async_setup = False
     per_rank = None
     if dist:
         # what a scaling run is diagnosed with: every rank's own wall time per frame, its share of the rays and the time it

@@ -207,7 +207,8 @@ class Multiply(nn.Module):
                 cache = self.__dict__.get("_eval_beta")
                 # keyed on the parameter OBJECT, its storage and its version: writes through .data and a replaced Parameter with the
                 # same version number must not leave a stale value behind (a load_state_dict bumps the version: copy_ in place)
-                key = (id(b), b.data_ptr(), b._version, str(b.device), hip._GENERATION[0])
+                # (`id` is this method's person-id argument: the parameter is identified by its storage)
+                key = (b.data_ptr(), b._version, str(b.device), hip._GENERATION[0])
                 if cache is None or cache[0] != key:
                     val = (b.detach().abs() + self.density.beta_min).reshape(1).float().contiguous()   # caller's stream
                     ev = torch.cuda.Event()

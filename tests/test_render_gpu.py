@@ -208,6 +208,31 @@ def _gpu(inp):
     return {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inp.items()}
 
 
+def test_eval_with_the_setup_on_a_side_stream_renders_the_same_pixels():
+    """model.async_setup (a render loop over resident frames: SMPL, culls and the call's one host sync on a side stream, the
+    near cull's beta read once per parameter version): bit-identical to the default call, also on the second frame (cached
+    beta) and after a parameter update (new cache key)"""
+    model, oracle, inp = build()
+    gin = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inp.items()}
+    with torch.no_grad():
+        ref = model(gin)
+        model.async_setup = True
+        a = model(gin)
+        b = model(gin)
+        def same(x, y):                                    # bit-identical, NaN rows (a ray through the sphere's centre) included
+            print("[info] max |diff|", float(torch.nan_to_num(x - y).abs().max()), "NaNs", int(x.isnan().sum()), int(y.isnan().sum()))
+            return torch.equal(x.isnan(), y.isnan()) and torch.equal(torch.nan_to_num(x), torch.nan_to_num(y))
+        for k in ("rgb_values", "acc_map", "normal_values"):
+            assert same(a[k], ref[k]) and same(b[k], ref[k]), k
+        model.density.beta.data.mul_(1.5)                  # a write that does not bump the version counter ...
+        model.train(); model.eval()                        # ... is picked up at the latest on a mode switch
+        c = model(gin)
+        model.async_setup = False
+        d = model(gin)
+        torch.cuda.synchronize()
+        assert same(c["rgb_values"], d["rgb_values"]) and not same(c["acc_map"], ref["acc_map"])
+
+
 def test_single_person_id_and_no_background():
     """forward(id=p) renders one person only (multiply.py:244-247); idx=None -> white background (multiply.py:541-542)."""
     model, oracle, inp = build(H=14, W=14)
