@@ -63,6 +63,45 @@ def build_model(n_samples, seed=0, H=512, W=512, P=2, tile=8):
     return model, inp, tables, sc
 
 
+def person_mode_renderer(model, gin, mode, world, rank, group, chunk, person_slots, keep):
+    """BASELINE.json configs[3]: ONE frame per step on `world` ranks with the PERSONS sharded --
+    mode 'person': rank g evaluates persons {p : p % world == g} for all rays, one all_to_all per person slot turns "all rays of
+    my persons" into "all persons of my rays", compositing + background ray-partitioned (parallel.render_person_sharded);
+    mode 'hybrid': world = ray_shards x person_slots, a team of person_slots ranks per ray shard (parallel.render_hybrid).
+    The frame goes through in chunks of `chunk` rays (whole convergence groups; the dense exchange block of a chunk is
+    chunk x (NZ + 7 S + 1) floats per person slot), the kept outputs are all-gathered ONCE per frame (parallel.gather_hybrid).
+    Returns render() -> {key: (R, 3)} and the event lists [(start, end)] of the exchanges and of the image gather."""
+    from multiply_amd import parallel as PX
+    R = gin["uv"].shape[1]
+    step = max(group * world, (chunk // (group * world)) * group * world)
+    ex_evs, gather_evs = [], []
+    ray_shards = world // person_slots if mode == "hybrid" else 1
+
+    def render(_gin=None):
+        rows, ids, shaded, sdf_evals = [], [], [], []
+        for c0 in range(0, R, step):
+            sub = dict(gin)
+            sub["uv"] = gin["uv"][:, c0:c0 + step].contiguous()
+            if mode == "hybrid":
+                out, rid = PX.render_hybrid(model, sub, person_slots, ray_shards, group, exchange_events=ex_evs)
+                rid = rid.to(gin["uv"].device) + c0
+            else:
+                out, (s0, s1) = PX.render_person_sharded(model, sub, exchange_events=ex_evs)
+                rid = torch.arange(c0 + s0, c0 + s1, device=gin["uv"].device)
+            rows.append(torch.cat([out[k] for k in keep], dim=1))
+            ids.append(rid)
+            shaded += list(model.last_stats.get("n_shaded", []))
+            sdf_evals += list(model.last_stats.get("n_sdf_evals", []))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        full = PX.gather_hybrid(torch.cat(rows, 0), torch.cat(ids, 0), R)
+        e1.record()
+        gather_evs.append((e0, e1))
+        return dict(zip(keep, full.split([3] * len(keep), dim=1))), shaded, sdf_evals
+
+    return render, ex_evs, gather_evs
+
+
 def to_dev(inp):
     return {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inp.items()}
 
@@ -88,11 +127,14 @@ def host_cpu():
     return torch.get_num_threads(), (len(cores) or None), model
 
 
-def cpu_baseline(model, inp, tables, sc, n_samples, n_rays=8192):
+def cpu_baseline(model, inp, tables, sc, n_samples, n_rays=8192, budget_s=330.0, min_rays=4096):
     """Times the CPU oracle on a bounded sample of the same frame: `n_rays` rays = a centred block of image rows that crosses
     both bodies, every pixel of those rows (>= 16 k rays or 3 frames asked, 8 192 taken by default = ~8 min of
     oracle so that the whole bench.py run stays inside the driver's timeout; extrapolated and labelled).  Also returns the
-    GPU-vs-oracle pixel error on that sample."""
+    GPU-vs-oracle pixel error on that sample.
+    WALL-TIME GUARD: the oracle walks the sample one convergence group (512 rays) at a time and stops at the first group
+    boundary past `budget_s` seconds once `min_rays` rays are done (a slower host must not turn the headline run into a driver
+    timeout); the rate, the parity figures and the `sample` label refer to the rays actually processed."""
     from oracle import multiply_oracle as O
     H = W = int(round(np.sqrt(inp["uv"].shape[1])))
     rows = max(1, n_rays // W)
@@ -117,20 +159,27 @@ def cpu_baseline(model, inp, tables, sc, n_samples, n_rays=8192):
     G = int(model.convergence_group or len(sel))
     parts = []
     t0 = time.time()
+    done = 0
     for c0 in range(0, len(sel), G):
         chunk = dict(sub)
         chunk["uv"] = sub["uv"][:, c0:c0 + G]
         hg = [h[(h >= c0) & (h < c0 + G)] - c0 for h in hit]
         hg = [h if len(h) else torch.zeros(1, dtype=torch.long) for h in hg]        # multiply.py:262-263 per chunk
         parts.append(oracle.forward_eval(chunk, hg)["rgb_values"])
+        done = min(len(sel), c0 + G)
+        if time.time() - t0 > budget_s and done >= min(min_rays, len(sel)):
+            break
     dt = time.time() - t0
     want = {"rgb_values": torch.cat(parts, 0)}
-    err = (got["rgb_values"].cpu() - want["rgb_values"]).abs()
+    err = (got["rgb_values"].cpu()[:done] - want["rgb_values"]).abs()
     err = err[~err.isnan()]
     threads, phys, name = host_cpu()
-    return dict(value=len(sel) / dt, unit="rays/s", cores=threads, physical_cores=phys, cpu_model=name, kind="port",
-                sample=f"{len(sel)} rays (image rows {r0}..{r0 + rows - 1} of the same {H}x{W} frame, hit rays "
-                       f"{[int(len(h)) for h in hit]}), fp32 torch oracle on {threads} threads, {dt:.1f} s; the frame rate "
+    hit_done = [int((h < done).sum()) for h in hit]
+    cut = "" if done == len(sel) else f" (stopped by the {budget_s:.0f} s wall-time guard: {done} of the {len(sel)} rays asked for)"
+    return dict(value=done / dt, unit="rays/s", cores=threads, physical_cores=phys, cpu_model=name, kind="port",
+                rays=done, seconds=dt,
+                sample=f"{done} rays{cut} (image rows {r0}.. of the same {H}x{W} frame, row-major from row {r0}, hit rays "
+                       f"{hit_done}), fp32 torch oracle on {threads} threads, {dt:.1f} s; the frame rate "
                        f"is this rate extrapolated", parity_rgb_max_abs=float(err.max()), parity_rgb_mean_abs=float(err.mean()))
 
 
@@ -173,10 +222,12 @@ def train_iterations(model, gin, steps, warmup, dist, barrier, seed=0, rays=512)
         batches.append((tin, {"rgb": torch.rand(1, rays, 3, generator=g).to(dev)}))
     torch.cuda.synchronize()
     it_no = [0]
+    host_s = [0.0]
 
     def one(timed):
         tin, gt = batches[it_no[0]]
         it_no[0] += 1
+        h0 = time.perf_counter()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         ev[0].record()
         out = model(tin)
@@ -192,6 +243,7 @@ def train_iterations(model, gin, steps, warmup, dist, barrier, seed=0, rays=512)
         ev[4].record()
         if timed:                  # read after the loop: no host wait inside the timed region
             evs.append(ev)
+            host_s[0] += time.perf_counter() - h0      # the host's own time to enqueue the iteration (incl. the setup's one sync)
         return lo
 
     for _ in range(warmup):
@@ -209,7 +261,7 @@ def train_iterations(model, gin, steps, warmup, dist, barrier, seed=0, rays=512)
     model.async_setup = False
     model.sampler_vote_group = None
     model.grad_bucket_sync = None
-    return dt, [a / max(steps, 1) for a in acc], float(lo["loss"]), model.last_stats
+    return dt, [a / max(steps, 1) for a in acc], float(lo["loss"]), model.last_stats, 1e3 * host_s[0] / max(steps, 1)
 
 
 def train_cpu_baseline(model, gin, inp, tables, sc, n_samples, rays=512, iters=3, seed=0):
@@ -320,18 +372,24 @@ def relaunch_under_torchrun(n):
     os.execv(sys.executable, cmd)
 
 
-def timed_frames(model, gin, steps, barrier, after=None):
+def timed_frames(model, gin, steps, barrier, after=None, frame_fn=None):
     """EXACTLY `steps` forward passes between two barriers; after(out) runs inside the timed region (the all_gather of the
-    strong-scaling mode).  Returns elapsed seconds and the per-step statistics."""
+    strong-scaling mode).  frame_fn(gin) replaces model(gin) (person / hybrid modes: a frame is several calls; it returns the
+    frame's (n_shaded, n_sdf_evals) lists itself).  Returns elapsed seconds and the per-step statistics."""
     shaded, sdf_evals = [], []
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        out = model(gin)
+        if frame_fn is not None:
+            out, sh, se = frame_fn(gin)
+            shaded.append(sh)
+            sdf_evals.append(se)
+        else:
+            out = model(gin)
+            shaded.append(model.last_stats["n_shaded"])
+            sdf_evals.append(model.last_stats["n_sdf_evals"])
         if after is not None:
             after(out)
-        shaded.append(model.last_stats["n_shaded"])
-        sdf_evals.append(model.last_stats["n_sdf_evals"])
     barrier()
     return time.perf_counter() - t0, shaded, sdf_evals
 
@@ -348,7 +406,15 @@ def main():
     ap.add_argument("--train-warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=8192, help="rays of the CPU oracle's render sample (~1 min per 1000 on the box's host)")
-    ap.add_argument("--cpu-train-iters", type=int, default=5, help="timed oracle training iterations (one more, cold, is run first and discarded)")
+    ap.add_argument("--cpu-train-iters", type=int, default=2, help="timed oracle training iterations (one more, cold, is run first and discarded)")
+    ap.add_argument("--cpu-budget-s", type=float, default=330.0, help="wall-time guard of the CPU oracle's render sample: it stops at the "
+                    "first 512-ray group boundary past this many seconds (once 4096 rays are done)")
+    ap.add_argument("--persons", type=int, default=2, help="persons of the synthetic scene (BASELINE.json configs[3]: --persons 4 --samples 256)")
+    ap.add_argument("--mode", choices=("ray", "person", "hybrid"), default="ray",
+                    help="N > 1: how ONE frame is split -- ray: convergence groups dealt to the ranks (configs[2], default); person: persons "
+                         "sharded, one all_to_all (configs[3] on <= P ranks); hybrid: person teams x ray shards (configs[3] on 8 ranks)")
+    ap.add_argument("--person-slots", type=int, default=0, help="--mode hybrid: ranks per team (default: min(persons, world))")
+    ap.add_argument("--chunk-rays", type=int, default=16384, help="--mode person / hybrid: rays per exchange (whole convergence groups)")
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the frame-per-rank weak-scaling leg")
     ap.add_argument("--breakdown", action="store_true", help="print per-phase GPU times to stderr")
     args = ap.parse_args()
@@ -367,6 +433,7 @@ def main():
     local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     td = None
+    ranks_seen = None
     if dist:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -375,6 +442,15 @@ def main():
         else:
             td.init_process_group(backend)
         assert td.get_world_size() == args.gpus, "process group size differs from --gpus"
+        # what the driver's SCALE record can be checked against: an all_reduce of ones over the data-path backend (nccl = RCCL)
+        one = torch.ones(1, device="cuda")
+        td.all_reduce(one)
+        torch.cuda.synchronize()
+        ranks_seen = int(round(float(one.item())))
+        assert ranks_seen == td.get_world_size(), f"all_reduce of ones saw {ranks_seen} ranks, the group has {td.get_world_size()}"
+    if args.mode != "ray" and not dist:
+        raise SystemExit("bench.py: --mode person / hybrid split ONE frame over several ranks: use --gpus N > 1 (the single-GPU line of "
+                         "configs[3] is `--persons 4 --samples 256`)")
 
     def barrier():
         torch.cuda.synchronize()
@@ -391,10 +467,19 @@ def main():
 
     GROUP = 512                              # the reference renders frames in chunks of pixel_per_batch = 512 rays
     # strong scaling: every rank holds the SAME frame (seed 0) and renders its round-robin share of the convergence groups
-    model, inp, tables, sc = build_model(args.samples, seed=0, H=args.res, W=args.res, tile=args.tile)
+    model, inp, tables, sc = build_model(args.samples, seed=0, H=args.res, W=args.res, P=args.persons, tile=args.tile)
     model.convergence_group = GROUP
     R = inp["uv"].shape[1]
-    if dist:
+    exchange_evs, frame_fn = None, None
+    if dist and args.mode != "ray":
+        slots = args.person_slots or min(args.persons, world)
+        if args.mode == "hybrid" and (slots < 1 or world % slots):
+            raise SystemExit(f"bench.py: --mode hybrid needs world ({world}) = ray shards x person slots ({slots})")
+        gin = to_dev(inp)                     # every rank holds the whole frame's rays; persons (and ray shards) split the work
+        frame_fn, exchange_evs, gather_evs = person_mode_renderer(model, gin, args.mode, world, rank, GROUP, args.chunk_rays, slots,
+                                                                  ("rgb_values", "normal_values", "fg_rgb_values"))
+        assemble = None                       # the image all_gather is part of the frame function
+    elif dist:
         from multiply_amd.parallel import gather_rays_interleaved, shard_input_interleaved
         # groups per band of the image: with tile x tile ray order a group of 512 rays is a (512 / tile)-pixel wide block
         GPR = max(1, (args.res * args.tile) // GROUP) if args.tile else max(1, args.res // GROUP)
@@ -422,14 +507,16 @@ def main():
     # the host keeps enqueuing ahead of the GPU from frame to frame (Multiply._setup, async_setup)
     model.async_setup = os.environ.get("MP_BENCH_ASYNC_EVAL", "1") == "1"
     for _ in range(args.warmup):
-        o = model(gin)
+        o = frame_fn(gin)[0] if frame_fn is not None else model(gin)
         if assemble is not None:
             assemble(o)
     torch.cuda.synchronize()
     model.phase_events = {}
     if dist:
         gather_evs.clear()
-    elapsed, shaded, sdf_evals = timed_frames(model, gin, args.steps, barrier, assemble)
+    if exchange_evs is not None:
+        exchange_evs.clear()
+    elapsed, shaded, sdf_evals = timed_frames(model, gin, args.steps, barrier, assemble, frame_fn)
     model.profile = False
     model.async_setup = False
     per_rank = None
@@ -442,13 +529,20 @@ def main():
         td.all_gather(allr, mine)
         per_rank = {"ms_per_step": [float(t[0]) for t in allr], "rays": [int(t[1]) for t in allr],
                     "all_gather_ms_per_step": [float(t[2]) for t in allr]}
+        if exchange_evs is not None:         # person / hybrid: the all_to_all exchanges' own time (incl. waiting for the team's slowest rank)
+            mine = torch.tensor([sum(a.elapsed_time(b) for a, b in exchange_evs) / args.steps, len(exchange_evs) / args.steps],
+                                device="cuda", dtype=torch.float64)
+            allx = [torch.empty_like(mine) for _ in range(world)]
+            td.all_gather(allx, mine)
+            per_rank["exchange_ms_per_step"] = [float(t[0]) for t in allx]
+            per_rank["exchanges_per_step"] = [float(t[1]) for t in allx]
     elapsed = max_over_ranks(elapsed)
     render_stats = model.last_stats
     phases = model.phase_times_ms()
 
     weak = None
-    if dist and not args.no_weak:            # frame-per-rank: rank r renders frame r of the synthetic sequence, no collective
-        wmodel, winp, _, _ = build_model(args.samples, seed=rank, H=args.res, W=args.res, tile=args.tile)
+    if dist and not args.no_weak and args.mode == "ray":            # frame-per-rank: rank r renders frame r of the synthetic sequence, no collective
+        wmodel, winp, _, _ = build_model(args.samples, seed=rank, H=args.res, W=args.res, P=args.persons, tile=args.tile)
         wmodel.convergence_group = GROUP
         wgin = to_dev(winp)
         for _ in range(args.warmup):
@@ -474,7 +568,7 @@ def main():
             train_peak_note = "the dense 16-bit MFMA peak / 3 (three MFMAs per product) = 833 TFLOP/s"
         rays_rank = 512 // world             # strong scaling: the reference's 512 pixels per iteration split over the ranks
         full = to_dev(inp)
-        tdt, tph, tloss, tstats = train_iterations(model, full, args.train_steps, args.train_warmup, dist, barrier, seed=rank,
+        tdt, tph, tloss, tstats, thost = train_iterations(model, full, args.train_steps, args.train_warmup, dist, barrier, seed=rank,
                                                    rays=rays_rank)
         tdt = max_over_ranks(tdt)
         # exact op count of the iteration's differentiable MLP work: fg SDF net 6 GEMM passes over
@@ -488,6 +582,7 @@ def main():
                  "rays_per_iter_per_gpu": rays_rank, "rays_per_iter": rays_rank * world, "scaling": "strong",
                  "dtype": train_dtype, "dtype_note": train_note, "obb_mode": model.obb_mode,
                  "gpu_ms": {"forward+loss": tph[0], "backward": tph[1], "allreduce": tph[2], "adam": tph[3]},
+                 "host_ms_per_iter": thost,
                  "hit_rays": tstats["n_hit"], "last_loss": tloss,
                  "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": train_peak, "flop_per_iter_this_rank": tflop,
                               "achieved": tflop / (tdt / args.train_steps) / 1e12,
@@ -497,7 +592,7 @@ def main():
 
     n_shaded = float(sum(int(w.sum()) for s_ in shaded for w in s_)) / args.steps          # per frame (this rank's share)
     n_sdf = float(sum(int(w[:-1].sum()) for s_ in sdf_evals for w in s_)) / args.steps
-    R_rank = gin["uv"].shape[1]
+    R_rank = gin["uv"].shape[1] if frame_fn is None else (R + world - 1) // world     # person / hybrid: background is ray-partitioned
     flops = {"mlp_shade": n_shaded * 4 * M_IMP, "sampler_mlp_sdf": n_sdf * 2 * M_IMP, "mlp_color": n_shaded * 2 * M_REN,
              "background": R_rank * 32 * 2 * (M_BGIMP + M_BGREN)}
     dom = max(flops, key=lambda k: phases.get(k, (0, 0.0))[1])
@@ -518,10 +613,10 @@ def main():
     traffic = None
     kernels = {"mlp_shade": ["k_mlp_fwdsave", "k_mlp_grad"] if model.shade_mode == "reverse" else ["k_mlp_shade"],
                "mlp_color": ["k_mlp_color"], "background": ["k_background"], "sampler_mlp_sdf": ["k_mlp_sdf"]}[dom]
-    pmc_file = next((os.path.join(REPO, "profiles", f) for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json")
+    pmc_file = next((os.path.join(REPO, "profiles", f) for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json")
                      if os.path.exists(os.path.join(REPO, "profiles", f))), None)
     traffic_note = None
-    if pmc_file and args.res == 512 and args.samples == 128 and world == 1:
+    if pmc_file and args.res == 512 and args.samples == 128 and args.persons == 2 and world == 1:
         with open(pmc_file) as f:
             pmc = json.load(f)                      # per-dispatch averages of ONE frame (bench.py --steps 1 --warmup 0)
         # a committed measurement is attached only when it is a measurement of THIS tree on THIS workload (tools/write_profiles.py
@@ -558,14 +653,22 @@ def main():
             "dtype_note": "MLP operands IEEE half (f16: the bf16 operand width and MFMA rate BASELINE.json's configs[1] names, 3 more "
                           "mantissa bits), fp32 accumulation; everything else fp32.  The reference is fp32; stated tolerances vs the "
                           "fp32 oracle: tests/tolerances.py, cpu_baseline.parity_* below",
-            "collective_backend": (backend if dist else None), "data": "synthetic",
-            "config": {"workload": f"2-person synthetic SMPL scene, {args.res}x{args.res} rays/frame, N_samples="
+            "collective_backend": (backend if dist else None), "rccl_ranks_seen": ranks_seen, "data": "synthetic",
+            "config": {"workload": f"{args.persons}-person synthetic SMPL scene, {args.res}x{args.res} rays/frame, N_samples="
                                    f"{args.samples} (+32 extra +2 bounds = {args.samples + 33} composited samples/ray/"
                                    f"person), N_samples_eval={max(128, args.samples)}, 32 background samples, "
                                    f"convergence groups of 512 rays (reference pixel_per_batch), geometric-init weights",
                        "rays_per_step": R, "frames": args.steps,
-                       "parallelism": (f"ray-sharded dp{world}: one frame per step, convergence groups dealt on a diagonal lattice, "
-                                       f"all_gather of the image on every rank") if dist else "single GPU"},
+                       "persons": args.persons,
+                       "parallelism": ("single GPU" if not dist else
+                                       f"ray-sharded dp{world}: one frame per step, convergence groups dealt on a diagonal lattice, "
+                                       f"all_gather of the image on every rank" if args.mode == "ray" else
+                                       f"person-sharded x{world}: rank g evaluates persons p % {world} == g for all rays, one all_to_all per "
+                                       f"person slot and {args.chunk_rays}-ray chunk, compositing + background ray-partitioned, one all_gather "
+                                       f"of the image" if args.mode == "person" else
+                                       f"hybrid: {world // (args.person_slots or min(args.persons, world))} ray shards x "
+                                       f"{args.person_slots or min(args.persons, world)} person slots (teams exchange inside, one all_gather "
+                                       f"of the image over the world)")},
             "roofline": {"bound": "mfma", "kernel": dom + " = " + " + ".join(kernels), "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                          "avg_launch_ms": 1e3 * per_launch_s, "launches_per_step": launches_per_frame,
@@ -580,7 +683,7 @@ def main():
         if train is not None:
             out["train_iter"] = train
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, inp, tables, sc, args.samples, n_rays=args.cpu_rays)
+            out["cpu_baseline"] = cpu_baseline(model, inp, tables, sc, args.samples, n_rays=args.cpu_rays, budget_s=args.cpu_budget_s)
             if train is not None:
                 train["cpu_baseline"] = train_cpu_baseline(model, to_dev(inp), inp, tables, sc, args.samples,
                                                            iters=args.cpu_train_iters)

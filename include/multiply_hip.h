@@ -146,6 +146,10 @@ int mp_obb_hull(const double* hull_verts, int n_hull_verts, const double* normal
  * reads it with its other device counts and falls back to mp_obb_hull with a host-side hull. */
 int mp_obb_hull_device_work_bytes(void);
 int mp_obb_hull_device(const float* verts, int n_verts, int n_bodies, float inflate, void* work, float* obb, int* status, void* stream);
+/* Test hook: on != 0 makes every following mp_obb_hull_device call take its give-up path (the wrap's workgroups spin on each other
+ * and abandon the wrap after ~30 ms when they are not all resident: status[..][3] = 1, the caller falls back to the host hull).
+ * Returns the previous setting. */
+int mp_debug_hull_abandon(int on);
 
 /* ---- rays -------------------------------------------------------------------------------------
  * rend_util.get_camera_params (lib/utils/rend_util.py:45-87) + far sphere root (:131-147).

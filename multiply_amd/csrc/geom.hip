@@ -1175,7 +1175,8 @@ __device__ bool hw_insert(unsigned* keys, unsigned short* vals, int u, int v, in
 constexpr int HW_G = 8;
 __device__ __forceinline__ void hw_store(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned hw_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// false: the wrap was abandoned -- a peer waited ~0.3 s for this barrier (xch[3]).  The HW_G workgroups of a body spin on each
+// false: the wrap was abandoned -- a peer waited ~30 ms for this barrier (xch[3]; round 4 waited ~0.3 s: a stall that long per
+// iteration is worse than the fall-back it avoids).  The HW_G workgroups of a body spin on each
 // other, so they must all be resident; should something else hold the XCD's CUs for good (several processes sharing the GPU,
 // each with a partly scheduled wrap), the kernel gives up instead of hanging and the caller takes the host-side hull.
 __device__ __forceinline__ bool hw_grid_barrier(unsigned* xch, unsigned& target, int* lds_flag) {
@@ -1186,7 +1187,7 @@ __device__ __forceinline__ bool hw_grid_barrier(unsigned* xch, unsigned& target,
         int ok = 1;
         for (unsigned spins = 0; __hip_atomic_load(xch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target; ++spins) {
             if (hw_load(&xch[3]) != 0u) { ok = 0; break; }
-            if (spins > (1u << 18)) { hw_store(&xch[3], 1u); ok = 0; break; }
+            if (spins > (1u << 15)) { hw_store(&xch[3], 1u); ok = 0; break; }   // ~30 ms; a round's barrier normally takes ~10 us
             __builtin_amdgcn_s_sleep(1);
         }
         *lds_flag = ok;
@@ -1615,6 +1616,11 @@ extern "C" int mp_warp_jacobian(const float* xc, const unsigned char* need, cons
 // work (bytes, 8-byte aligned): the workgroups' exchange area (HW_XCH_BYTES; the launcher zeroes its head); then fp64 arrays hv [HW_MAXV][3], normals [HW_MAXF][3], evec / ena / enb
 // [3 HW_MAXF / 2][3] each, search scratch [2 HW_MAXF]
 constexpr int HW_XCH_BYTES = 256 + 4 * (4 * HW_FRONT + HW_FRONT);
+// test hook: every following mp_obb_hull_device call starts with its bodies' "abandoned" words set, i.e. takes the give-up path
+// of a wrap whose workgroups never became co-resident (status[3] = 1, obb untouched) without having to starve the GPU for it
+static int g_hw_force_abandon = 0;
+extern "C" int mp_debug_hull_abandon(int on) { const int was = g_hw_force_abandon; g_hw_force_abandon = on; return was; }
+
 extern "C" int mp_obb_hull_device_work_bytes(void) { return HW_XCH_BYTES + 8 * (3 * HW_MAXV + 3 * HW_MAXF + 3 * (9 * HW_MAXF / 2) + 2 * HW_MAXF); }
 extern "C" int mp_obb_hull_device(const float* verts, int n_verts, int n_bodies, float inflate, void* work, float* obb, int* status,
                                   void* stream) {
@@ -1623,7 +1629,10 @@ extern "C" int mp_obb_hull_device(const float* verts, int n_verts, int n_bodies,
     int* counts = status;                                   // per body {H, F, E, status, ...}: the caller reads [3] with its other counts
     const long long stride = mp_obb_hull_device_work_bytes() / 8;       // per body, in doubles
     unsigned* xch = (unsigned*)work;                        // barrier counter + front size + failed, records, pivots
-    for (int b = 0; b < n_bodies; ++b) hipMemsetAsync((char*)work + 8 * stride * b, 0, 256, st);
+    for (int b = 0; b < n_bodies; ++b) {
+        hipMemsetAsync((char*)work + 8 * stride * b, 0, 256, st);
+        if (g_hw_force_abandon) hipMemsetD32Async((hipDeviceptr_t)((char*)work + 8 * stride * b + 12), 1, 1, st);   // xch[3]
+    }
     double* hv = (double*)((char*)work + HW_XCH_BYTES);
     double* normals = hv + 3 * HW_MAXV;
     double* evec = normals + 3 * HW_MAXF;

@@ -368,19 +368,24 @@ class Multiply(nn.Module):
         return dict(dev=dev, R=R, uv=uv, K=K, pose=pose, dirs=dirs, far=far, per=per, persons=persons, n_hit=n_hit,
                     group=group, beta=beta, counts=counts, hull_status=hull_status)
 
-    def _vote_groups_equal(self, n_groups, grp):
-        """one-off check (cached) that every rank of the vote's process group holds `n_groups` convergence groups"""
+    def _vote_groups_check(self, n_groups, grp):
+        """Every rank of the vote's process group must contribute the same number of convergence-group flags (uneven ray shards
+        with convergence_group set would mismatch the collective's sizes -- undefined behaviour on RCCL).  A FIXED-size collective,
+        issued by every rank on every call in which the flag count is not 1 by construction (convergence_group set), whatever
+        its own n_groups: a rank that skipped it would desynchronise the collective sequence it is meant to protect."""
         import torch.distributed as dist
         t = torch.tensor([n_groups, -n_groups], device=self.density.beta.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=grp)
-        ok = int(t[0]) == n_groups and int(-t[1]) == n_groups
-        self.sampler_vote_groups_checked = ok
-        return ok
+        hi, lo = int(t[0]), int(-t[1])
+        if hi != n_groups or lo != n_groups:
+            raise RuntimeError(f"sampler vote: the ranks hold different numbers of convergence groups (this rank {n_groups}, "
+                               f"range {lo}..{hi}); shard the rays at multiples of convergence_group, equally many per rank")
 
-    def _sample_person(self, cx, n, p, draws=None):
-        """ErrorBoundSampler.get_z_vals for person p's rays (ray_sampler.py:66-220): returns zfinal [R_p][N+N_extra+2],
-        the iteration counters and the per-iteration SDF worklist counts.  draws = None: eval-mode determinism;
-        else the training randomness {t_rand [R_p,NE], u_final [R_p,N], extra_idx [max_iters,N_extra] int32}."""
+    # ---- ErrorBoundSampler.get_z_vals (ray_sampler.py:66-220) in four steps, so that the persons of a call can advance
+    #      iteration by iteration together (one convergence-vote collective per iteration for ALL persons, _sample_persons)
+    def _sampler_open(self, cx, n, p, draws=None):
+        """workspaces of person p's sampler + mp_sampler_init.  draws = None: eval-mode determinism; else the training
+        randomness {t_rand [R_p,NE], u_final [R_p,N], extra_idx [max_iters,N_extra] int32}."""
         L = hip.lib()
         dev = cx["dev"]
         f32 = dict(dtype=torch.float32, device=dev)
@@ -393,11 +398,9 @@ class Multiply(nn.Module):
         ZM = NE * rs.max_total_iters
         R, group = cx["R"], cx["group"]
         n_groups = (R + group - 1) // group
-        dirs, far, pose, beta = cx["dirs"], cx["far"], cx["pose"], cx["beta"]
         pp = cx["per"][p]
         Rp = max(int(cx["n_hit"][n]), 1)
         imp = self.foreground_implicit_network_list[p]
-        skin_w = self.smpl_server_list[p].tables.lbs_weights
         pk_sdf = hip.packed(imp, "sdf", 2)
         pk_sdf.refresh(pp["cond"], force=self.training)
         zs = torch.empty(Rp, ZM, **f32); sdfs = torch.empty(Rp, ZM, **f32)
@@ -411,49 +414,97 @@ class Multiply(nn.Module):
                                    zfinal.data_ptr(), iters.data_ptr(), any_active.data_ptr())
         train = draws is not None
         t_rand = hip.ptr(draws["t_rand"]) if train else None
-        u_final = hip.ptr(draws["u_final"]) if train else None
-        extra_idx = hip.ptr(draws["extra_idx"]) if train else None
-        hip.check(L.mp_sampler_init(C.byref(cfg), C.byref(state), hip.ptr(far), hip.ptr(pp["hit_index"]),
+        hip.check(L.mp_sampler_init(C.byref(cfg), C.byref(state), hip.ptr(cx["far"]), hip.ptr(pp["hit_index"]),
                                     hip.ptr(pp["count"]), Rp, group, R, t_rand, st), "mp_sampler_init")
         xc_new = torch.empty(Rp * NE, 3, **f32)
         work = torch.empty(Rp * NE, **i32)
         wcount = torch.zeros(rs.max_total_iters + 1, **i32)
         # training: the rays are random pixels -- the warp first groups a call's samples by their nearest vertex cluster
         bin_work = torch.empty(int(L.mp_warp_bin_work_bytes(Rp * NE)), dtype=torch.uint8, device=dev) if train else None
-        for it in range(rs.max_total_iters):
-            with self._ph("sampler_warp"):
-                hip.check(L.mp_warp_inverse(None, hip.ptr(dirs), hip.ptr(pose), hip.ptr(pp["hit_index"]),
-                                            hip.ptr(pp["count"]), hip.ptr(znew), NE, NE, Rp, hip.ptr(pp["vsorted"]),
-                                            hip.ptr(pp["cbound"]), hip.ptr(pp["btab"]), 0 if train else 1,
-                                            hip.ptr(active), hip.ptr(any_active[it:it + 1]), hip.ptr(xc_new), None,
-                                            hip.ptr(sdfnew), hip.ptr(work),
-                                            hip.ptr(wcount[it:it + 1]), hip.ptr(bin_work) if train else None, st),
-                          "mp_warp_inverse")
-            with self._ph("sampler_mlp_sdf"):
-                hip.check(L.mp_mlp_sdf(C.byref(pk_sdf.net), hip.ptr(pk_sdf.wpack), hip.ptr(pk_sdf.bias),
-                                       hip.ptr(xc_new), hip.ptr(work), hip.ptr(wcount[it:it + 1]), Rp * NE,
-                                       hip.ptr(sdfnew), st), "mp_mlp_sdf")
-            with self._ph("sampler_bound"):
-                hip.check(L.mp_sampler_bound(C.byref(cfg), C.byref(state), hip.ptr(beta), hip.ptr(pp["hit_index"]),
-                                             hip.ptr(pp["count"]), Rp, group, R, it, st), "mp_sampler_bound")
-            if self.sampler_vote_group is not None:
-                # ray-sharded data parallelism: the reference's convergence vote (`not_converge = beta.max() > beta0`,
-                # ray_sampler.py:137) spans ALL rays of the call -- here the rays of every rank.  One MAX all-reduce of this
-                # iteration's group flags (n_groups ints, 1 in training) between the bound and the resampling kernels makes the
-                # N-rank step sample exactly like the single-process step (option (a)).
-                import torch.distributed as dist
-                grp = None if self.sampler_vote_group is True else self.sampler_vote_group
-                # every rank must contribute the same number of flags: one per call (training: group = all rays), or equally many
-                # convergence groups per rank -- uneven ray shards with convergence_group set would mismatch the collective
-                assert n_groups == 1 or getattr(self, "sampler_vote_groups_checked", False) or self._vote_groups_equal(n_groups, grp), \
-                    "sampler vote: the ranks hold different numbers of convergence groups"
-                dist.all_reduce(gflag[it * n_groups:(it + 1) * n_groups], op=dist.ReduceOp.MAX, group=grp)
-            with self._ph("sampler_resample"):
-                hip.check(L.mp_sampler_resample(C.byref(cfg), C.byref(state), hip.ptr(beta), hip.ptr(far),
-                                                hip.ptr(pp["hit_index"]), hip.ptr(pp["count"]), Rp, group, R, it,
-                                                u_final, extra_idx, st), "mp_sampler_resample")
-        pp["_sampler_keep"] = (zs, sdfs, nz, znew, sdfnew, betar, active, gflag, any_active, xc_new, work, draws)
-        return zfinal, iters, wcount
+        return dict(cx=cx, p=p, pp=pp, Rp=Rp, NE=NE, cfg=cfg, state=state, train=train, draws=draws, pk_sdf=pk_sdf, n_groups=n_groups,
+                    zs=zs, sdfs=sdfs, nz=nz, znew=znew, sdfnew=sdfnew, betar=betar, active=active, gflag=gflag, zfinal=zfinal,
+                    iters=iters, any_active=any_active, xc_new=xc_new, work=work, wcount=wcount, bin_work=bin_work)
+
+    def _sampler_query(self, s, it):
+        """iteration `it`, first half: warp the new samples, query the SDF net, evaluate the error bound (sets the group flags)"""
+        L, st = hip.lib(), hip.stream()
+        cx, pp, Rp, NE, train = s["cx"], s["pp"], s["Rp"], s["NE"], s["train"]
+        pk_sdf, any_active, wcount = s["pk_sdf"], s["any_active"], s["wcount"]
+        with self._ph("sampler_warp"):
+            hip.check(L.mp_warp_inverse(None, hip.ptr(cx["dirs"]), hip.ptr(cx["pose"]), hip.ptr(pp["hit_index"]),
+                                        hip.ptr(pp["count"]), hip.ptr(s["znew"]), NE, NE, Rp, hip.ptr(pp["vsorted"]),
+                                        hip.ptr(pp["cbound"]), hip.ptr(pp["btab"]), 0 if train else 1,
+                                        hip.ptr(s["active"]), hip.ptr(any_active[it:it + 1]), hip.ptr(s["xc_new"]), None,
+                                        hip.ptr(s["sdfnew"]), hip.ptr(s["work"]),
+                                        hip.ptr(wcount[it:it + 1]), hip.ptr(s["bin_work"]) if train else None, st),
+                      "mp_warp_inverse")
+        with self._ph("sampler_mlp_sdf"):
+            self._sampler_sdf(s, it)
+        with self._ph("sampler_bound"):
+            hip.check(L.mp_sampler_bound(C.byref(s["cfg"]), C.byref(s["state"]), hip.ptr(cx["beta"]), hip.ptr(pp["hit_index"]),
+                                         hip.ptr(pp["count"]), Rp, cx["group"], cx["R"], it, st), "mp_sampler_bound")
+
+    def _sampler_sdf(self, s, it):
+        """the sampler's network queries of iteration `it`: the fused half-precision kernel (csrc/mlp.hip k_mlp_sdf)"""
+        L, st = hip.lib(), hip.stream()
+        pk_sdf, wcount = s["pk_sdf"], s["wcount"]
+        hip.check(L.mp_mlp_sdf(C.byref(pk_sdf.net), hip.ptr(pk_sdf.wpack), hip.ptr(pk_sdf.bias),
+                               hip.ptr(s["xc_new"]), hip.ptr(s["work"]), hip.ptr(wcount[it:it + 1]), s["Rp"] * s["NE"],
+                               hip.ptr(s["sdfnew"]), st), "mp_mlp_sdf")
+
+    def _sampler_resample(self, s, it):
+        """iteration `it`, second half: new samples where the bound is not met (or, converged, the final inverse-CDF draw)"""
+        L, st = hip.lib(), hip.stream()
+        cx, pp, draws = s["cx"], s["pp"], s["draws"]
+        u_final = hip.ptr(draws["u_final"]) if s["train"] else None
+        extra_idx = hip.ptr(draws["extra_idx"]) if s["train"] else None
+        with self._ph("sampler_resample"):
+            hip.check(L.mp_sampler_resample(C.byref(s["cfg"]), C.byref(s["state"]), hip.ptr(cx["beta"]), hip.ptr(cx["far"]),
+                                            hip.ptr(pp["hit_index"]), hip.ptr(pp["count"]), s["Rp"], cx["group"], cx["R"], it,
+                                            u_final, extra_idx, st), "mp_sampler_resample")
+
+    def _sampler_close(self, s):
+        s["pp"]["_sampler_keep"] = tuple(s[k] for k in ("zs", "sdfs", "nz", "znew", "sdfnew", "betar", "active", "gflag",
+                                                       "any_active", "xc_new", "work", "draws"))
+        return s["zfinal"], s["iters"], s["wcount"]
+
+    def _sample_persons(self, cx, draws_by_person=None, persons=None):
+        """The sampler of EVERY person of the call, advancing iteration by iteration together -> {p: (zfinal, iters, wcount)}.
+        The persons' samplers are independent (same launches as one after the other, other order); what the interleaving buys
+        is the data-parallel convergence vote: the reference's `not_converge = beta.max() > beta0` (ray_sampler.py:137) spans
+        ALL rays of the call -- here the rays of every rank -- and with `sampler_vote_group` set ONE MAX all-reduce per sampler
+        iteration carries the flags of all persons (P x n_groups ints; P x max_total_iters collectives before), between the
+        bound and the resampling kernels: the N-rank step samples exactly like the single-process step."""
+        persons = list(cx["persons"]) if persons is None else list(persons)
+        order = {p: n for n, p in enumerate(cx["persons"])}
+        states = [self._sampler_open(cx, order[p], p, None if draws_by_person is None else draws_by_person[p]) for p in persons]
+        vote = self.sampler_vote_group is not None
+        if vote and states:
+            import torch.distributed as dist
+            grp = None if self.sampler_vote_group is True else self.sampler_vote_group
+            ng = states[0]["n_groups"]
+            if self.convergence_group is not None:      # (None: one flag per person and call on every rank, by construction)
+                self._vote_groups_check(ng, grp)
+        for it in range(self.ray_sampler.max_total_iters):
+            for s in states:
+                self._sampler_query(s, it)
+            if vote and states:
+                flags = [s["gflag"][it * ng:(it + 1) * ng] for s in states]
+                if len(flags) == 1:
+                    dist.all_reduce(flags[0], op=dist.ReduceOp.MAX, group=grp)
+                else:
+                    packed = torch.cat(flags)
+                    dist.all_reduce(packed, op=dist.ReduceOp.MAX, group=grp)
+                    torch._foreach_copy_(flags, list(packed.split(ng)))
+                self.vote_collectives = getattr(self, "vote_collectives", 0) + 1
+            for s in states:
+                self._sampler_resample(s, it)
+        return {s["p"]: self._sampler_close(s) for s in states}
+
+    def _sample_person(self, cx, n, p, draws=None):
+        """ErrorBoundSampler.get_z_vals for person p's rays (ray_sampler.py:66-220): returns zfinal [R_p][N+N_extra+2],
+        the iteration counters and the per-iteration SDF worklist counts."""
+        return self._sample_persons(cx, None if draws is None else {p: draws}, persons=[p])[p]
 
     def sample_rays(self, ray_dirs, cam_loc, cond, smpl_tfs, smpl_verts, person_id, draws=None):
         """The sampler on explicit rays, outside forward(): what ErrorBoundSampler.get_z_vals(ray_dirs, cam_loc, model, cond,

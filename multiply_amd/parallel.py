@@ -196,11 +196,11 @@ def _exchange_by_rays(dense, world, backend_alltoall, group=None):
     return torch.stack([b.reshape(world, n_slice, *dense.shape[1:])[rank] for b in bufs], 0)
 
 
-def render_person_sharded(model, input, canonical_pose=False, group=None):
+def render_person_sharded(model, input, canonical_pose=False, group=None, exchange_events=None):
     """Eval-mode Multiply.forward with the persons sharded over the ranks (of `group`; None: all ranks).  Every rank returns the
     output dict for ITS ray slice [rank * ceil(R / world), ...) (use gather_rays to assemble the image).  Identical results to
     the single-process call with convergence groups that do not straddle a slice (the sampler's vote is per person and per
-    group)."""
+    group).  exchange_events (a list): (start, end) timing events around every exchange are appended (bench.py --mode person)."""
     import ctypes as C
     from . import hip
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -232,7 +232,13 @@ def render_person_sharded(model, input, canonical_pose=False, group=None):
             dense[rows, NZ + S:NZ + 4 * S] = d["rgb"][:n * S].reshape(n, 3 * S)
             dense[rows, NZ + 4 * S:NZ + 7 * S] = d["nrm"][:n * S].reshape(n, 3 * S)
             dense[rows, -1] = 1.0
+        if exchange_events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         recv.append(_exchange_by_rays(dense, world, dist.get_backend(group) == "nccl", group))      # [world, n_slice, width]
+        if exchange_events is not None:
+            e1.record()
+            exchange_events.append((e0, e1))
     # my ray slice, all persons: person p = j * world + g
     s0 = rank * n_slice
     n_my = max(0, min(R, s0 + n_slice) - s0)
@@ -297,14 +303,15 @@ def hybrid_teams(person_slots, ray_shards):
     return _TEAMS[key][rank // person_slots], rank // person_slots, rank % person_slots
 
 
-def render_hybrid(model, input, person_slots, ray_shards, group_size, groups_per_row=None, canonical_pose=False):
+def render_hybrid(model, input, person_slots, ray_shards, group_size, groups_per_row=None, canonical_pose=False,
+                  exchange_events=None):
     """Eval-mode Multiply.forward on ray_shards x person_slots ranks.  Returns (out, ray_ids): the output dict of THIS rank's
     rays and their ids in the frame's ray order (ascending).  Bit-identical to the single-process call with
     convergence_group = group_size: the shards are whole convergence groups and the person teams composite exactly the rows
     the single process composites."""
     team, shard, slot = hybrid_teams(person_slots, ray_shards)
     sub, idx = shard_input_interleaved(input, shard, ray_shards, group_size, groups_per_row)
-    out, (s0, s1) = render_person_sharded(model, sub, canonical_pose, group=team)
+    out, (s0, s1) = render_person_sharded(model, sub, canonical_pose, group=team, exchange_events=exchange_events)
     return out, idx[s0:s1]
 
 

@@ -502,7 +502,10 @@ class TrainState:
             self.tables[key] = (host.to(self.dev), len(lps), row, lps)
 
     def begin(self, keys=None):
-        """start of an iteration: effective weights of the groups in `keys` (default: all), fresh accumulators"""
+        """start of a training forward: effective weights of the groups in `keys` (default: all).  The gradient accumulators are
+        NOT part of this: they belong to a backward pass (start_backward), so that several forwards may be alive before their
+        backwards run (loss = f(A) + f(B), a forward between forward and backward, a retained graph swept twice) without one
+        graph's sweep accumulating into another's buffers."""
         L, st = hip.lib(), hip.stream()
         ptrs = []
         for ls in self.lins.values():
@@ -518,15 +521,26 @@ class TrainState:
             if keys is None or k in keys:
                 tab, n, rows, _ = self.tables[k]
                 _chk(L.mp_tr_wn_fwd_multi(_p(tab), n, rows, st), "mp_tr_wn_fwd_multi")
+        self.acc = self.gbuf = None
+        return self
+
+    def start_backward(self):
+        """start of ONE adjoint sweep: fresh flat buffers -- accumulators (one fill) and parameter gradients -- and every shared
+        layer's dW / db / gradient views re-bound to them.  Fresh per sweep on purpose: autograd takes the gradient views over as
+        param.grad without a copy, so a buffer must never be written by a later sweep."""
         self.acc = torch.zeros(self.acc_size, dtype=F32, device=self.dev)
         self.gbuf = torch.empty(self.grad_size, dtype=F32, device=self.dev)
         for ls in self.lins.values():
             for lp in ls:
                 lp.bind(self.acc, *self.layout[id(lp)][:2], self.gbuf, *self.layout[id(lp)][2:])
+        self._finished = set()
         return self
 
     def finish_group(self, key):
         """the weight-norm adjoint of one group's layers: accumulators -> parameter gradients (views of the flat buffer)"""
+        if key in self._finished:
+            raise RuntimeError(f"TrainState.finish_group({key!r}) twice in one backward sweep")
+        self._finished.add(key)
         tab, n, rows, lps = self.tables[key]
         _chk(hip.lib().mp_tr_wn_bwd_multi(_p(tab), n, rows, _p(self.acc), _p(self.gbuf), hip.stream()), "mp_tr_wn_bwd_multi")
 
@@ -601,9 +615,10 @@ class ImplicitTrainFused(ImplicitTrainRev):
     Same interface: self.out [P][257], self.grad [P][3], backward(dZ_last, dgrad) -> d cond.  The adjoint of the input points
     (pose optimisation) is not produced here: TrainGraph takes ImplicitTrainRev when it is needed."""
 
-    def __init__(self, net, x, cond_vec, lins=None, p_cap=None):
+    def __init__(self, net, x, cond_vec, lins=None, p_cap=None, cap_bytes=6 << 30):
         """p_cap: the largest P this caller can ever pass (all rays hit the body): the stash is then sized for it, i.e. the SAME
-        allocation every iteration (_big_empty)"""
+        allocation every iteration (_big_empty) -- when that is at most cap_bytes (the caller divides its arena budget by the
+        number of persons whose stashes are alive together: a crowded scene must not hold n_persons x the all-rays-hit arena)"""
         L, st = hip.lib(), hip.stream()
         assert fused_sdf_supported(net)
         self.net, self.x, self.cond = net, x, cond_vec
@@ -619,7 +634,7 @@ class ImplicitTrainFused(ImplicitTrainRev):
             capv = C.c_longlong(0)
             _chk(L.mp_tf_sdf_sizes(int(p_cap), C.byref(capv), None), "mp_tf_sdf_sizes")
             cap = int(capv.value)
-        self.arena = _big_empty(int(arena.value), dev, cap=cap)
+        self.arena = _big_empty(int(arena.value), dev, cap=cap, cap_bytes=cap_bytes)
         R1 = 256 * (P + 1)                               # every [P][256] stash tensor carries one pad row (csrc/tfuse.hip)
         self.o_dZ = lambda l: l * R1
         self.o_V = lambda l: (8 + l) * R1
@@ -888,6 +903,7 @@ class RenderTrainFused:
 # Training-mode Multiply.forward (multiply.py:174-588, `self.training` branches) as ONE autograd node
 # ======================================================================================================================
 N_EIKONAL = 512          # multiply.py:324
+ARENA_BUDGET_BYTES = int(__import__("os").environ.get("MP_TRAIN_ARENA_GB", "24")) << 30   # fixed-size SDF stashes of one iteration, all persons
 # 'fused' (ImplicitTrainFused: layer-fused kernels, default) | 'reverse' (ImplicitTrainRev, layer by layer) | 'forward'
 SDF_TRAIN_MODE = __import__("os").environ.get("MP_SDF_TRAIN_MODE", "fused")
 
@@ -955,11 +971,16 @@ class TrainGraph:
         persons = cx["persons"]
         self.fg = {}
         z_l, sdf_l, rgb_l, nrm_l, inv_l = [], [], [], [], []
+        if self.cond_zero:                                            # multiply.py:271-273
+            for p in persons:
+                cx["per"][p]["cond"] = torch.zeros_like(cx["per"][p]["cond"])
+        # the samplers of all persons advance together (Multiply._sample_persons): in ray-sharded data-parallel training the
+        # convergence vote is then ONE collective per sampler iteration for all persons
+        todo = [p for p in persons if self.draws["person"][p].get("z_given") is None]
+        sampled = m._sample_persons(cx, {p: self.draws["person"][p] for p in todo}, persons=todo) if todo else {}
         for n, p in enumerate(persons):
             pp = cx["per"][p]
             dr = self.draws["person"][p]
-            if self.cond_zero:                                        # multiply.py:271-273
-                pp["cond"] = torch.zeros_like(pp["cond"])
             Rp = max(int(cx["n_hit"][n]), 1)
             imp, ren, dfm = m.foreground_implicit_network_list[p], m.foreground_rendering_network_list[p], m.deformer_list[p]
             server = m.smpl_server_list[p]
@@ -970,7 +991,7 @@ class TrainGraph:
                 zfinal, iters, wcount = dr["z_given"].to(dev).float().contiguous(), None, None
                 assert zfinal.shape == (Rp, NZ), f"z_given of person {p}: {tuple(zfinal.shape)} != {(Rp, NZ)}"
             else:
-                zfinal, iters, wcount = m._sample_person(cx, n, p, dr)
+                zfinal, iters, wcount = sampled[p]
             npts = Rp * S
             E = N_EIKONAL
             Pt = npts + E
@@ -1005,7 +1026,9 @@ class TrainGraph:
             rev = mode != "forward"
             li, lr = self.ts.lins[id(imp)], self.ts.lins[id(ren)]
             if mode == "fused":
-                it = ImplicitTrainFused(imp, X, pp["cond"], lins=li, p_cap=R * S + E)
+                # all persons' stashes live from forward to backward: the fixed all-rays-hit size only while the sum stays in budget
+                it = ImplicitTrainFused(imp, X, pp["cond"], lins=li, p_cap=R * S + E,
+                                        cap_bytes=min(6 << 30, ARENA_BUDGET_BYTES // max(len(persons), 1)))
             else:
                 it = ImplicitTrainRev(imp, X, pp["cond"], lins=li) if rev else ImplicitTrain(imp, X, pp["cond"], fwd=True, lins=li)
             gptr = _p(it.grad) if rev else None
@@ -1151,6 +1174,7 @@ class TrainGraph:
         f32 = dict(dtype=F32, device=dev)
         persons = cx["persons"]
         all_persons = self.all_persons
+        self.ts.start_backward()                  # this sweep's own accumulators / gradient buffer (TrainState.start_backward)
         P = len(all_persons)
         S = self.NZ - 1
         t_inv, t_z, t_sdf, t_rgb, _ = self.tabs

@@ -60,17 +60,28 @@ def main():
     cxs = model._setup({**sub, "hit_index": hit_my}, -1, False)
     my = {p: {k: (v[ids.cuda()].contiguous() if k in ("t_rand", "u_final") else v) for k, v in draws["person"][p].items()}
           for p in cx["persons"]}
-    res = {}
+    import time
+    res, wall = {}, {}
+    T = model.ray_sampler.max_total_iters
     for vote in (False, True):
         model.sampler_vote_group = True if vote else None
-        zs, its = [], []
-        for n, p in enumerate(cxs["persons"]):
-            z, iters, _ = model._sample_person(cxs, n, p, my[p])
-            zs.append(z.clone())
-            its.append(int(iters.max()))
-        torch.cuda.synchronize()
+        for rep in range(3):                     # the last repetition is the timed one (same draws: same result)
+            model.vote_collectives = 0
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            out = model._sample_persons(cxs, my)      # all persons advance together: ONE vote collective per iteration
+            torch.cuda.synchronize()
+            wall[vote] = time.perf_counter() - t0
+        zs = [out[p][0].clone() for p in cxs["persons"]]
+        its = [int(out[p][1].max()) for p in cxs["persons"]]
         res[vote] = (zs, its)
+        if vote:
+            check(model.vote_collectives == T, f"{model.vote_collectives} vote collectives for {len(zs)} persons x {T} iterations: expected {T}")
     model.sampler_vote_group = None
+    print(f"[rank {rank}] sampler of {len(cxs['persons'])} persons, {T} iterations: {1e3 * wall[False]:.2f} ms without the vote, "
+          f"{1e3 * wall[True]:.2f} ms with it = {1e3 * (wall[True] - wall[False]) / T:.3f} ms per iteration for the "
+          f"{dist.get_backend()} MAX all-reduce of {len(cxs['persons'])} flags (blocking, host-visible)", flush=True)
     for n, p in enumerate(cx["persons"]):
         same_vote = torch.equal(res[True][0][n], z_full[n][ids.cuda()])
         same_novote = torch.equal(res[False][0][n], z_full[n][ids.cuda()])

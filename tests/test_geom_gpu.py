@@ -176,3 +176,37 @@ def test_hull_box_cull_hit_sets_match_the_published_algorithm():
                 print(f"[parity] person {p}: hull box {len(got)} rays (oracle {len(want)}, {len(diff)} grazing), PCA box {len(pca)} rays")
                 assert 0 < len(got) < len(pca)    # the minimum-volume box is the tighter of the two (neither contains the other)
     print(f"[parity] 20 poses x 2 persons: {n_rays} hit rays, {n_graze} grazing differences (|margin| < 1e-4)")
+
+
+def test_device_hull_give_up_path_falls_back_to_the_host_hull():
+    """The device hull's workgroups of a body spin on each other and ABANDON the wrap when they are not all resident (another
+    process, or the main stream, holding the CUs): status[3] = 1 and the setup repeats with the host-side hull, with a warning.
+    The hook mp_debug_hull_abandon starts the wraps in that state: same box, same hit sets as the undisturbed device hull."""
+    import warnings
+    import torch
+    from multiply_amd import hip
+    from tests.test_render_gpu import build
+    model, oracle, inp = build(H=24, W=24)
+    model.train()
+    gin = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inp.items()}
+    cx = model._setup(gin, -1, False)
+    assert cx["hull_status"] is not None and (cx["hull_status"][:, 3] == 0).all()
+    L = hip.lib()
+    assert L.mp_debug_hull_abandon(1) == 0
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            cx_f = model._setup(gin, -1, False)
+        torch.cuda.synchronize()
+    finally:
+        assert L.mp_debug_hull_abandon(0) == 1
+    assert any("falling back to the host-side hull" in str(x.message) for x in w), [str(x.message) for x in w]
+    assert cx_f["hull_status"] is None                      # the repeated setup took the host hull
+    for n, p in enumerate(cx["persons"]):
+        bd, bh = cx["per"][p]["obb"].cpu().numpy(), cx_f["per"][p]["obb"].cpu().numpy()
+        assert abs(np.prod(bd[12:15]) / np.prod(bh[12:15]) - 1.0) < 1e-5, (p, bd, bh)
+        a = set(cx["per"][p]["hit_index"][:cx["n_hit"][n]].tolist())
+        b = set(cx_f["per"][p]["hit_index"][:cx_f["n_hit"][n]].tolist())
+        assert len(a.symmetric_difference(b)) <= 2, (p, len(a), len(b))
+    cx2 = model._setup(gin, -1, False)                      # hook off again: the device hull is back
+    assert cx2["hull_status"] is not None and (cx2["hull_status"][:, 3] == 0).all()

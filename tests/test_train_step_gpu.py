@@ -219,6 +219,51 @@ def test_training_step_reduces_loss():
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
 
 
+def test_two_live_training_graphs_keep_their_gradients_apart():
+    """Two training forwards alive before one backward (loss = f(A) + f(B)): every sweep owns its accumulators and gradient
+    buffer (TrainState.start_backward), so the summed backward equals the sum of the two separate backwards -- and a retained
+    graph swept twice accumulates exactly twice its gradient."""
+    model, oracle, inp, gin, gt, loss_fn, train = _train_setup()
+    R = inp["uv"].shape[1]
+    hit = [torch.arange(R), torch.arange(R)]
+    in_a = {**gin, "hit_index": hit}
+    in_b = {**gin, "hit_index": hit, "uv": gin["uv"].flip(1).contiguous()}
+    gt_b = {"rgb": gt["rgb"].flip(1)}
+
+    def fwd(i, g, seed):
+        torch.manual_seed(seed)          # the draws of a forward come from torch's global generator
+        return loss_fn(model(i), g)["loss"]
+
+    def grads():
+        return {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    sep = []
+    for i, g, seed in ((in_a, gt, 11), (in_b, gt_b, 12)):
+        model.zero_grad(set_to_none=True)
+        fwd(i, g, seed).backward()
+        sep.append(grads())
+    model.zero_grad(set_to_none=True)
+    la, lb = fwd(in_a, gt, 11), fwd(in_b, gt_b, 12)          # both graphs alive
+    (la + lb).backward()
+    both = grads()
+    worst = 0.0
+    for k, g in both.items():
+        want = sep[0][k] + sep[1][k]
+        rel = float((g - want).norm() / (want.norm() + 1e-12))
+        worst = max(worst, rel)
+        assert rel < 1e-4 or float((g - want).abs().max()) < 1e-7, f"{k}: {rel:.3e}"
+    print(f"[parity] two live graphs vs separate backwards: worst relative difference {worst:.2e} over {len(both)} tensors")
+    # a retained graph swept twice: param.grad accumulates g + g
+    model.zero_grad(set_to_none=True)
+    l1 = fwd(in_a, gt, 11)
+    l1.backward(retain_graph=True)
+    l1.backward()
+    twice = grads()
+    for k, g in twice.items():
+        want = 2 * sep[0][k]
+        rel = float((g - want).norm() / (want.norm() + 1e-12))
+        assert rel < 1e-4 or float((g - want).abs().max()) < 1e-7, f"{k} (double sweep): {rel:.3e}"
+
+
 def test_eval_after_a_fused_optimizer_step_uses_the_updated_weights():
     """torch's fused Adam updates the parameters WITHOUT bumping their version counters, which the packed-weight caches of the
     f16 kernels are keyed on: the eval render after such a step must not come from the stale pack (Multiply.train() drops the

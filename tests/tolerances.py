@@ -18,7 +18,10 @@ def Dist(mean, bulk, frac, hard, p999):
 # profiles/r03_parity_16k.txt): 0.22-0.4 % of the rays above 1e-2 (99th percentile 6.6e-4, 99.9th 1.2e-2 ... 3.2e-2), worst
 # single ray 9.0e-2 (16k rays) / 1.1e-1 (the always-on 4 096-ray slice, profiles/r04_parity_4k.txt).  Round 4 (review): the fraction at 2.5x the measured one (was 9x), the worst case at 1.33x, and a bound on
 # the 99.9th percentile per quantity (2-2.5x the 16k-ray figure; on a 1 024-ray scene it is the second-worst element).
-_GRAZE = dict(bulk=1e-2, frac=0.01, hard=0.12)
+# Round 5 (advisor): `hard` had 9 % of margin over the worst single ray ever measured (1.1e-1) -- one grazing ray moving with a
+# kernel's worklist / atomics order would have made the suite flaky while saying nothing about quality.  The statistical power
+# is in `frac` and `p999`; `hard` is the gross-failure bound (a wrong pixel is O(1)), with real margin.
+_GRAZE = dict(bulk=1e-2, frac=0.01, hard=0.2)
 SMALL_SAMPLE_RAYS = 6                     # floor of the allowed number of rays above `bulk` (scenes of < 600 rays)
 P999_MIN_RAYS = 2000                      # the p99.9 bound applies to samples of at least this many rays (see within)
 EVAL = {                                   # eval-mode Multiply.forward outputs, per pixel
