@@ -60,6 +60,17 @@ typedef struct {
 int mp_pack_layer(const float* v, const float* g, const float* b, int out_dim, int in_dim, const int* rowmap,
                   int n_rows, const int* colmap, const float* colscale, int ks_in, int hoist_col0, int hoist_n,
                   const float* hoist_vec, float bias_scale, void* wpack_layer, float* bias_layer, void* stream);
+/* mp_pack_layer for ALL layers of one network in ONE launch (a training forward repacks the sampler's half-precision SDF net of
+ * every person: 9 layers x 2 launches each before).  table: n_layers (<= MP_MAX_LAYERS) DEVICE-resident records, one per layer,
+ * fields as mp_pack_layer's arguments (device pointers; hoist_vec NULL or hoist_n 0 = no hoisting; wpack_layer NULL = bias
+ * only); every layer's bias row is written for all MP_BIAS_STRIDE entries (zeros past n_rows). */
+typedef struct {
+    const void *v, *g, *b, *rowmap, *colmap, *colscale, *hoist_vec;
+    void *wpack_layer, *bias_layer;
+    int out_dim, in_dim, n_rows, hoist_col0, hoist_n;
+    float bias_scale;
+} MpPackLayer;
+int mp_pack_layers(const MpPackLayer* table, int n_layers, int ks_in, void* stream);
 
 /* ---- fused MLP evaluation -------------------------------------------------------------------
  * mp_mlp_sdf: ImplicitNet.forward restricted to the sdf column (networks.py:126-181; caller:

@@ -396,7 +396,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_grad(const NetDesc net, cons
             if constexpr (SIG8) {
                 // chunk ks: dword 2 nb + mbl = the bytes of row pairs (mbl, j = 0, 1) of column block nb -> halves 0 .. 7 in operand order
                 const u32x4 pk = *(const u32x4*)(sio.base + (size_t)7 * SIG_LAYER + ks * 1024 + lane * 16);
-                const opx8 wq = wv * (op_t)(1.0f / 255.0f);
+                const opx8 wq = wv * (op_t)SIG_QINV_F;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     const unsigned d0 = nb == 0 ? pk.x : pk.z, d1 = nb == 0 ? pk.y : pk.w;

@@ -453,6 +453,16 @@ constexpr bool SIG8 = false;
 #else
 constexpr bool SIG8 = true;
 #endif
+// -DMP_EXP_SIGBITS=4 | 6: the PRECISION of a 4- / 6-bit uniform code (levels k / 15, k / 63: exact 0 and 1 + 14 / 62 interior
+// levels) emulated inside the byte pipeline -- the same instructions, only the two scale constants change, so the normals of
+// such a code can be measured (tests/test_mlp_gpu.py, tools/sig_bits.py) before any packing code is written.  Round-5 result:
+// DESIGN.md section 3 -- the 4-bit code does not hold the asserted normal bounds.
+#ifndef MP_EXP_SIGBITS
+#define MP_EXP_SIGBITS 8
+#endif
+constexpr unsigned SIG_Q = MP_EXP_SIGBITS == 4 ? 0x4B804B80u : MP_EXP_SIGBITS == 6 ? 0x53E053E0u : 0x5BF85BF8u;      // 15.0 | 63.0 | 255.0
+constexpr unsigned SIG_QINV = MP_EXP_SIGBITS == 4 ? 0x2C442C44u : MP_EXP_SIGBITS == 6 ? 0x24102410u : 0x1C041C04u;   // 1/15 | 1/63 | 1/255
+constexpr float SIG_QINV_F = MP_EXP_SIGBITS == 4 ? 1.0f / 15.0f : MP_EXP_SIGBITS == 6 ? 1.0f / 63.0f : 1.0f / 255.0f;
 constexpr int SIG_CHUNK_BYTES = SIG8 ? 1024 : 2048;   // per wave and chunk: 64 lanes x (2 column blocks x 4 row pairs x 2 sigmoids)
 struct ActConst {
     unsigned c1, c2, c3;   // the coefficients as packed half pairs, in vector registers (gfx9 VOP3P: no literals, one SGPR)
@@ -502,7 +512,7 @@ __device__ __forceinline__ void pp_instr(ActRegs8& a, const ActConst& k, const f
         } else if constexpr (ST == 2) {
             asm volatile("v_pk_add_f16 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(a.u[q]) : "v"(k.c1024));
         } else if constexpr (ST == 3) {
-            asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(a.u[q]) : "s"(sconst(0x1C041C04u)));     // x 1/255 (0x1C04 = 0.0039215)
+            asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(a.u[q]) : "s"(sconst(SIG_QINV)));     // x 1/255 (0x1C04 = 0.0039215)
         } else {
             const h2 z = __builtin_bit_cast(h2, a.z[q]) * __builtin_bit_cast(h2, a.u[q]);
             if (c < KS_REG) Bn.put(c, nb, mbl, j, z);
@@ -559,7 +569,7 @@ __device__ __forceinline__ void pp_instr(ActRegs8& a, const ActConst& k, const f
         }
     } else if constexpr (ST == S1 + 1) {   // 8-bit: 1024 + 255 s (0x5BF8 = 255.0): the mantissa's low byte is round(255 s)
         static_assert(SIG8, "pp_instr: stage");
-        asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(a.s[q]) : "s"(sconst(0x5BF85BF8u)), "v"(k.c1024));
+        asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(a.s[q]) : "s"(sconst(SIG_Q)), "v"(k.c1024));
     } else {                               // 8-bit: the low bytes of the four halves of row pairs j = 0, 1 into one dword
         static_assert(SIG8 && ST == S1 + 2, "pp_instr: stage");
         if constexpr (j == 0) {
@@ -621,12 +631,14 @@ template <int KS_IN>
 struct DmaLanes {
     unsigned reg[4];                 // lane*16 + byte offset of this wave's four register-fed pieces
     unsigned in[(2 * KS_IN + 3) / 4 + 1];   // ... of its input-fed pieces (the last may not exist; + 1: never a zero-length array)
+    unsigned run;                    // MP_DMA_ONE_M0: lane*16 + byte offset of this wave's contiguous 4 KiB run of register-fed tiles
     unsigned wl;
 };
 template <int KS_IN>
 __device__ __forceinline__ DmaLanes<KS_IN> dma_lanes(int wl, int lane) {
     DmaLanes<KS_IN> d;
     d.wl = wl;
+    d.run = lane * 16 + (wl >> 1) * mb_bytes(KS_IN) + (wl & 1) * 4 * TILE_BYTES;
 #pragma unroll
     for (int i = 0; i < 4; ++i) d.reg[i] = lane * 16 + (i / 2) * mb_bytes(KS_IN) + (wl + 4 * (i % 2)) * TILE_BYTES;
     if constexpr (KS_IN > 0) {
@@ -652,9 +664,20 @@ __device__ __forceinline__ void pp_issue(const char* __restrict__ wpack, char* w
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_offset(wring)) + __builtin_amdgcn_readfirstlane(ring_slot) * CB;
     const unsigned wl = __builtin_amdgcn_readfirstlane(d.wl);
     if (cm.has_reg(cn_u)) {
+#ifdef MP_DMA_ONE_M0
+        // ONE M0 write per chunk: wave wl takes the register-fed tiles 4 (wl & 1) .. + 3 of row block wl >> 1 -- a contiguous
+        // 4 KiB run in the chunk (source and ring slot have the same layout), its four pieces addressed through the
+        // instruction's immediate offset, which moves the global AND the LDS address (tools/stream_model.hip: +2..5 % on
+        // the forward sweep, +1..4 % on the reverse sweep against one s_add + s_nop per piece)
+        const unsigned run = (wl >> 1) * mb_bytes(KS_IN) + (wl & 1) * 4 * TILE_BYTES;
+        asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %2, %3 offset:2048\n\tglobal_load_lds_dwordx4 %2, %3 offset:3072"
+                     ::"s"(dst), "s"(run), "v"(d.run), "s"(src) : "memory");
+#else
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             pp_dma_piece(src, d.reg[i], dst, (i / 2) * mb_bytes(KS_IN) + (wl + 4 * (i % 2)) * TILE_BYTES);
+#endif
     }
     if constexpr (KS_IN > 0) {
         if (cm.has_in(cn_u)) {

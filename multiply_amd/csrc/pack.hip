@@ -57,6 +57,59 @@ __global__ __launch_bounds__(64) void k_pack_layer(const float* __restrict__ v, 
     }
 }
 
+// All layers of one network in ONE launch (mp_pack_layers): block (r, l) packs row r of layer l (or zeroes its bias entry).
+__global__ __launch_bounds__(64) void k_pack_layers(const MpPackLayer* __restrict__ tab, int ks_in) {
+    const MpPackLayer L = tab[blockIdx.y];
+    const int r = blockIdx.x, lane = threadIdx.x;
+    float* bias_out = (float*)L.bias_layer;
+    if (r >= L.n_rows) {
+        if (bias_out && lane == 0) bias_out[r] = 0.0f;
+        return;
+    }
+    const float* v = (const float*)L.v;
+    const float* g = (const float*)L.g;
+    const float* b = (const float*)L.b;
+    const int* rowmap = (const int*)L.rowmap;
+    const int* colmap = (const int*)L.colmap;
+    const float* colscale = (const float*)L.colscale;
+    const float* hoist_vec = (const float*)L.hoist_vec;
+    _Float16* wpack = (_Float16*)L.wpack_layer;
+    const int src = rowmap[r];
+    const int n_slots = (mp::KS_REG + ks_in) * 32;
+    const int mb = r >> 4, i = r & 15;
+    float scale = 1.0f;
+    const float* row = nullptr;
+    if (src >= 0) {
+        row = v + (size_t)src * L.in_dim;
+        if (g) {
+            float ss = 0.0f;
+            for (int c = lane; c < L.in_dim; c += 64) ss += row[c] * row[c];
+            ss = wave_sum(ss);
+            scale = g[src] / sqrtf(ss);
+        }
+    }
+    if (wpack) {
+        for (int s = lane; s < n_slots; s += 64) {
+            float val = 0.0f;
+            if (src >= 0) {
+                const int col = colmap[s];
+                if (col >= 0) val = row[col] * scale * colscale[s];
+            }
+            const int ks = s >> 5, sl = s & 31, gg = sl >> 3, e = sl & 7;
+            const size_t off = ((size_t)(mb * (mp::KS_REG + ks_in) + ks) * 64 + (i + 16 * gg)) * 8 + e;
+            wpack[off] = (_Float16)val;
+        }
+    }
+    if (bias_out) {
+        float h = 0.0f;
+        if (src >= 0 && L.hoist_n > 0 && hoist_vec) {
+            for (int c = lane; c < L.hoist_n; c += 64) h += (row[L.hoist_col0 + c] * scale) * hoist_vec[c];
+            h = wave_sum(h);
+        }
+        if (lane == 0) bias_out[r] = src >= 0 ? (b[src] + h) * L.bias_scale : 0.0f;
+    }
+}
+
 __global__ void k_zero_f(float* p, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0.0f;
@@ -74,6 +127,12 @@ extern "C" int mp_pack_layer(const float* v, const float* g, const float* b, int
         hipLaunchKernelGGL(k_zero_f, dim3(1), dim3(MP_BIAS_STRIDE), 0, st, bias_layer + n_rows, MP_BIAS_STRIDE - n_rows);
     hipLaunchKernelGGL(k_pack_layer, dim3(n_rows), dim3(64), 0, st, v, g, b, out_dim, in_dim, rowmap, colmap,
                        colscale, ks_in, hoist_col0, hoist_n, hoist_vec, bias_scale, (_Float16*)wpack_layer, bias_layer);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_pack_layers(const MpPackLayer* table, int n_layers, int ks_in, void* stream) {
+    if (n_layers <= 0 || n_layers > MP_MAX_LAYERS || (ks_in != 0 && ks_in != 2 && ks_in != 3)) return -1;
+    hipLaunchKernelGGL(k_pack_layers, dim3(MP_BIAS_STRIDE, n_layers), dim3(64), 0, (hipStream_t)stream, table, ks_in);
     return (int)hipGetLastError();
 }
 

@@ -29,6 +29,13 @@ class MpNet(C.Structure):
     _fields_ = [("n_layers", C.c_int), ("total_chunks", C.c_int), ("layer", MpLayer * MAX_LAYERS)]
 
 
+class MpPackLayer(C.Structure):
+    _fields_ = [("v", C.c_void_p), ("g", C.c_void_p), ("b", C.c_void_p), ("rowmap", C.c_void_p), ("colmap", C.c_void_p),
+                ("colscale", C.c_void_p), ("hoist_vec", C.c_void_p), ("wpack_layer", C.c_void_p), ("bias_layer", C.c_void_p),
+                ("out_dim", C.c_int), ("in_dim", C.c_int), ("n_rows", C.c_int), ("hoist_col0", C.c_int), ("hoist_n", C.c_int),
+                ("bias_scale", C.c_float)]
+
+
 class MpSamplerCfg(C.Structure):
     _fields_ = [("n_samples", C.c_int), ("n_samples_eval", C.c_int), ("n_samples_extra", C.c_int),
                 ("beta_iters", C.c_int), ("max_total_iters", C.c_int), ("eps", C.c_float), ("add_tiny", C.c_float),
@@ -223,11 +230,47 @@ class PackedNet:
                     vs.append((t.data_ptr(), t._version))
         return tuple(vs)
 
+    def _table(self, weights, hoisted):
+        """device-resident MpPackLayer records of every layer (mp_pack_layers), cached per (parameter pointers, variant): the
+        hoisted vector is read from a persistent buffer of this object, so the table survives from call to call"""
+        ptrs = tuple(t.data_ptr() if t is not None else 0 for p in self.plans for t in self._params(p.lin))
+        key = (weights, hoisted)
+        cache = self.__dict__.setdefault("_tables", {})
+        if key not in cache or cache[key][0] != ptrs:
+            arr = (MpPackLayer * len(self.plans))()
+            for i, p in enumerate(self.plans):
+                v, g, b = self._params(p.lin)
+                assert v.is_contiguous() and b.is_contiguous() and v.dtype == torch.float32
+                h0, hn = p.hoist if (p.hoist is not None and hoisted) else (0, 0)
+                skip = not weights and p.hoist is None            # bias-only refresh: only the hoisted layer changes
+                arr[i] = MpPackLayer(v.data_ptr(), g.data_ptr() if g is not None else None, b.data_ptr(),
+                                     self.rowmaps[i].data_ptr(), self.colmaps[i].data_ptr(), self.colscales[i].data_ptr(),
+                                     self._hoist_buf.data_ptr() if hn else None,
+                                     (self.wpack.data_ptr() + self.offsets[i] * self.chunk_bytes) if weights else None,
+                                     None if skip else self.bias.data_ptr() + 4 * i * BIAS_STRIDE,
+                                     v.shape[0], v.shape[1], 0 if skip else len(p.rowmap), h0, hn, p.bias_scale)
+            cache[key] = (ptrs, torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device))
+        return cache[key][1]
+
     def refresh(self, hoist_vec=None, force=False):
         """(Re)packs the weights if a parameter changed (or `force`: training mode, see invalidate_packed), and the hoisted
         layer-0 bias for this call's conditioning."""
         ver = self.param_version()
         full = force or ver != self.version
+        if not any(p.transpose for p in self.plans):
+            # ONE launch for all layers (mp_pack_layers); the call's conditioning goes through a persistent buffer
+            hoisted = hoist_vec is not None and any(p.hoist is not None for p in self.plans)
+            if hoisted:
+                hn = max(p.hoist[1] for p in self.plans if p.hoist is not None)
+                if self.__dict__.get("_hoist_buf") is None or self._hoist_buf.numel() < hn:
+                    self._hoist_buf = torch.empty(hn, dtype=torch.float32, device=self.device)
+                    self.__dict__.pop("_tables", None)
+                self._hoist_buf[:hn].copy_(hoist_vec.detach().reshape(-1)[:hn].float(), non_blocking=True)
+            if full or hoisted:
+                tab = self._table(bool(full), hoisted)
+                check(lib().mp_pack_layers(ptr(tab), len(self.plans), self.ks_in, stream()), "mp_pack_layers")
+            self.version = ver
+            return
         for i, p in enumerate(self.plans):
             if full:
                 self._pack_layer(i, True, hoist_vec if p.hoist is not None else None)
@@ -366,6 +409,32 @@ def device_ints(values, dev):
     if ring is None:
         ring = _PINNED["ring"] = _PinnedInts()
     return ring.put(list(values), dev)
+
+
+class ZeroPool:
+    """Zero-initialised scratch tensors of one call / one adjoint sweep as views of a few large zero-filled blocks: ONE fill per
+    block instead of one per tensor (a training iteration asked for ~70 small zero tensors: gradient seeds, device counters,
+    adjoint accumulators -- each a launch of its own).  A block lives as long as any of its views; a new pool per call, so a
+    view handed to autograd as a gradient is never written again.  Requests above a quarter of a block get their own fill."""
+
+    def __init__(self, device, block_bytes=8 << 20):
+        self.device, self.block_bytes = torch.device(device), block_bytes
+        self.buf, self.off = None, 0
+
+    def take(self, *shape, dtype=torch.float32):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+            shape = tuple(shape[0])
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = n * torch.empty(0, dtype=dtype).element_size()
+        if nbytes > self.block_bytes // 4 or self.device.type != "cuda":
+            return torch.zeros(shape, dtype=dtype, device=self.device)
+        if self.buf is None or self.off + nbytes > self.block_bytes:
+            self.buf, self.off = torch.zeros(self.block_bytes, dtype=torch.uint8, device=self.device), 0
+        v = self.buf[self.off:self.off + nbytes].view(dtype).view(shape)
+        self.off += (nbytes + 255) // 256 * 256
+        return v
 
 
 # The packed weights are keyed on the parameters' (data_ptr, _version).  That is NOT enough for every optimizer: torch's fused

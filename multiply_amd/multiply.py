@@ -123,6 +123,7 @@ class Multiply(nn.Module):
         # ray-sharded data-parallel training: a torch.distributed process group (or True = the default group) over which the
         # sampler's per-iteration convergence vote is all-reduced (MAX) -- see _sample_person; None: the vote is per process
         self.sampler_vote_group = None
+        self.sampler_sdf_mode = os.environ.get("MP_SAMPLER_SDF", "f16")      # 'f16' (product) | 'bf16x3' (measurement: _sampler_sdf)
         self.last_stats = {}
         self.profile = False
         self.phase_events = {}
@@ -268,7 +269,8 @@ class Multiply(nn.Module):
 
         # SMPL posing, nearest-vertex structures, box cull  (multiply.py:196-214, 256-266)
         per = {}
-        counts = torch.zeros(len(persons), **i32)
+        zp = hip.ZeroPool(dev, 1 << 16)             # the setup's device counters: one fill (on the setup's stream)
+        counts = zp.take(len(persons), dtype=torch.int32)
         hull_status = None
         scan_tmp = torch.empty(R + (R + 1023) // 1024 + 8, **i32)
         verts_all = torch.empty(len(persons), NUM_VERTS, 3, **f32)
@@ -306,7 +308,7 @@ class Multiply(nn.Module):
             # the convex hulls (gift wrapping), the candidate searches and the boxes of ALL bodies in one batch on the device: no
             # host round trip; the status words are read with the hit counts below (a failure -- exactly coplanar vertices
             # tying into a non-manifold patch -- repeats the setup with the host-side hull)
-            hull_status = torch.zeros(len(persons), 8, **i32)
+            hull_status = zp.take(len(persons), 8, dtype=torch.int32)
             work = torch.empty(len(persons), int(L.mp_obb_hull_device_work_bytes()), dtype=torch.uint8, device=dev)
             obb_all = torch.empty(len(persons), 16, **f32)
             hip.check(L.mp_obb_hull_device(hip.ptr(verts_all), NUM_VERTS, len(persons), C.c_float(self.obb_inflate), hip.ptr(work),
@@ -407,8 +409,11 @@ class Multiply(nn.Module):
         nz = torch.empty(Rp, **i32); znew = torch.empty(Rp, NE, **f32); sdfnew = torch.empty(Rp, NE, **f32)
         betar = torch.empty(Rp, **f32); active = torch.empty(Rp, **i32)
         gflag = torch.empty((rs.max_total_iters + 1) * n_groups, **i32)
-        zfinal = torch.empty(Rp, NZ, **f32); iters = torch.zeros(n_groups, **i32)
-        any_active = torch.zeros(rs.max_total_iters + 1, **i32)
+        zp = cx.get("_zp_sampler")                   # the samplers' device counters of ALL persons of the call: one fill
+        if zp is None:
+            zp = cx["_zp_sampler"] = hip.ZeroPool(dev, 1 << 16)
+        zfinal = torch.empty(Rp, NZ, **f32); iters = zp.take(n_groups, dtype=torch.int32)
+        any_active = zp.take(rs.max_total_iters + 1, dtype=torch.int32)
         state = hip.MpSamplerState(zs.data_ptr(), sdfs.data_ptr(), nz.data_ptr(), znew.data_ptr(),
                                    sdfnew.data_ptr(), betar.data_ptr(), active.data_ptr(), gflag.data_ptr(),
                                    zfinal.data_ptr(), iters.data_ptr(), any_active.data_ptr())
@@ -418,7 +423,7 @@ class Multiply(nn.Module):
                                     hip.ptr(pp["count"]), Rp, group, R, t_rand, st), "mp_sampler_init")
         xc_new = torch.empty(Rp * NE, 3, **f32)
         work = torch.empty(Rp * NE, **i32)
-        wcount = torch.zeros(rs.max_total_iters + 1, **i32)
+        wcount = zp.take(rs.max_total_iters + 1, dtype=torch.int32)
         # training: the rays are random pixels -- the warp first groups a call's samples by their nearest vertex cluster
         bin_work = torch.empty(int(L.mp_warp_bin_work_bytes(Rp * NE)), dtype=torch.uint8, device=dev) if train else None
         return dict(cx=cx, p=p, pp=pp, Rp=Rp, NE=NE, cfg=cfg, state=state, train=train, draws=draws, pk_sdf=pk_sdf, n_groups=n_groups,
@@ -445,9 +450,24 @@ class Multiply(nn.Module):
                                          hip.ptr(pp["count"]), Rp, cx["group"], cx["R"], it, st), "mp_sampler_bound")
 
     def _sampler_sdf(self, s, it):
-        """the sampler's network queries of iteration `it`: the fused half-precision kernel (csrc/mlp.hip k_mlp_sdf)"""
+        """the sampler's network queries of iteration `it`: the fused half-precision kernel (csrc/mlp.hip k_mlp_sdf).
+        `self.sampler_sdf_mode = 'bf16x3'` (MP_SAMPLER_SDF; a MEASUREMENT switch, tools/sampler_precision.py) evaluates the same
+        worklist layer by layer with the training path's split-bfloat16 GEMMs (fp32 activations, ~2^-16 per product) instead --
+        what the sampler's depths would be with near-fp32 queries; it reads the worklist count on the host."""
         L, st = hip.lib(), hip.stream()
         pk_sdf, wcount = s["pk_sdf"], s["wcount"]
+        if getattr(self, "sampler_sdf_mode", "f16") != "f16":
+            from . import train as T
+            n = int(wcount[it])
+            if n > 0:
+                idx = s["work"][:n].long()
+                x = s["xc_new"][idx].contiguous()
+                imp = self.foreground_implicit_network_list[s["p"]]
+                lins = [T.LinW(l) for l in imp.layers()]
+                parts = [T.ImplicitTrain(imp, x[c0:c0 + (1 << 18)], s["pp"]["cond"], fwd=False, lins=lins).out[:, 0].clone()
+                         for c0 in range(0, n, 1 << 18)]
+                s["sdfnew"].view(-1)[idx] = torch.cat(parts)
+            return
         hip.check(L.mp_mlp_sdf(C.byref(pk_sdf.net), hip.ptr(pk_sdf.wpack), hip.ptr(pk_sdf.bias),
                                hip.ptr(s["xc_new"]), hip.ptr(s["work"]), hip.ptr(wcount[it:it + 1]), s["Rp"] * s["NE"],
                                hip.ptr(s["sdfnew"]), st), "mp_mlp_sdf")

@@ -95,6 +95,17 @@ def _big_empty(n_floats, dev, grain=1 << 26, cap=None, cap_bytes=6 << 30):
     return torch.empty((n_floats + grain - 1) // grain * grain, dtype=F32, device=dev)
 
 
+_ZP = [None]          # the running adjoint sweep's hip.ZeroPool (TrainGraph.backward); None outside a sweep
+
+
+def _zeros(*shape, device):
+    """zero-initialised fp32 tensor: a view of the sweep's zero-filled block when a sweep is running, else a fill of its own"""
+    zp = _ZP[0]
+    if zp is not None and zp.device == torch.device(device):
+        return zp.take(*shape)
+    return torch.zeros(*shape, dtype=F32, device=device)
+
+
 def off(t, n_floats):
     """device pointer `n_floats` floats into tensor t"""
     return C.c_void_p(t.data_ptr() + 4 * n_floats)
@@ -202,7 +213,7 @@ class ImplicitTrain:
                 # hoisted conditioning: dW0[:, E:] += db (x) cond ; d cond = W0[:, E:]^T db
                 _chk(L.mp_tr_hoist_bwd(_p(lw.db), out, lw.in_dim, E, net.cond_dim, _p(self.cond), _p(lw.dW), hip.stream()),
                      "mp_tr_hoist_bwd")
-                dcond = torch.zeros(net.cond_dim, dtype=F32, device=dZ.device)
+                dcond = _zeros(net.cond_dim, device=dZ.device)
                 gemm_tn(_p(lw.db), 1, off(lw.W, E), lw.in_dim, _p(dcond), net.cond_dim, 1, net.cond_dim, out)
                 if want_dx:
                     gemm_nt(_p(dZ), out, _p(lw.WT), out, _p(dIN), E, rows, E, out, accumulate=True)
@@ -696,7 +707,7 @@ class ImplicitTrainFused(ImplicitTrainRev):
         if tn_groups is None:
             self._launch(groups)
         _chk(L.mp_tr_hoist_bwd(_p(lw0.db), 256, lw0.in_dim, E, net.cond_dim, _p(self.cond), _p(lw0.dW), st), "mp_tr_hoist_bwd")
-        dcond = torch.zeros(net.cond_dim, dtype=F32, device=dev)
+        dcond = _zeros(net.cond_dim, device=dev)
         gemm_tn(_p(lw0.db), 1, off(lw0.W, E), lw0.in_dim, _p(dcond), net.cond_dim, 1, net.cond_dim, 256)
         self.dx = None
         return dcond
@@ -770,7 +781,7 @@ class RenderTrain:
         gemm_tn(_p(dZ), o0, self.feat_ptr, self.feat_ld, off(lw0.dW, self.c_feat), lw0.in_dim, o0, 256, n)
         _chk(L.mp_tr_hoist_bwd(_p(lw0.db), o0, lw0.in_dim, self.c_h0, self.n_h, _p(self.hvec), _p(lw0.dW), hip.stream()),
              "mp_tr_hoist_bwd")
-        dh = torch.zeros(self.n_h, dtype=F32, device=dev)
+        dh = _zeros(self.n_h, device=dev)
         gemm_tn(_p(lw0.db), 1, off(lw0.W, self.c_h0), lw0.in_dim, _p(dh), self.n_h, 1, self.n_h, o0)
         # data gradients
         gemm_nt(_p(dZ), o0, _p(lw0.WT), o0, _p(dXA), self.na, n, self.na, o0)
@@ -884,9 +895,9 @@ class RenderTrainFused:
         gemm_tn(_p(dz4), 3, H(3), 256, _p(lw4.dW), 256, 3, 256, n, _p(lw4.db), n)
         # the hoisted pose embedding: dW_0[:, 6:14] += db_0 (x) pose8 ; d pose8 = W_0[:, 6:14]^T db_0 ; then lin_pose's own gradients
         _chk(L.mp_tr_hoist_bwd(_p(lw0.db), 256, lw0.in_dim, 6, 8, _p(cs.pose8), _p(lw0.dW), st), "mp_tr_hoist_bwd")
-        dh = torch.zeros(8, dtype=F32, device=dev)
+        dh = _zeros(8, device=dev)
         gemm_tn(_p(lw0.db), 1, off(lw0.W, 6), lw0.in_dim, _p(dh), 8, 1, 8, 256)
-        dlp_w = torch.zeros(8, 69, dtype=F32, device=dev)
+        dlp_w = _zeros(8, 69, device=dev)
         _chk(L.mp_tr_hoist_bwd(_p(dh), 8, 69, 0, 69, _p(self.cond), _p(dlp_w), st), "mp_tr_hoist_bwd")
         self.extra_grads = [dlp_w, dh]
         self.lp_w = cs.lp_w
@@ -1178,15 +1189,16 @@ class TrainGraph:
         P = len(all_persons)
         S = self.NZ - 1
         t_inv, t_z, t_sdf, t_rgb, _ = self.tabs
-        zero = lambda t, shape: torch.zeros(shape, **f32) if t is None else t.contiguous().float()
+        zp = self.zp = _ZP[0] = hip.ZeroPool(dev)          # this sweep's zero-initialised tensors: views of one zero-filled block
+        zero = lambda t, shape: zp.take(shape) if t is None else t.contiguous().float()
         d_rgb_values = zero(d_rgb_values, (R, 3)); d_acc_map = zero(d_acc_map, (R,)); d_acc_person = zero(d_acc_person, (R, P))
         # remote persons (person-sharded mode) get scratch rows: their owners compute the same compositing adjoint
         # (a fused person's d sdf vector also covers its eikonal points, which no compositing term reaches: zeros)
-        dsdf_l = [torch.zeros((self.fg[p]["Pt"] if isinstance(self.fg[p]["it"], ImplicitTrainFused) else self.fg[p]["npts"])
-                              if p in self.fg else R * S, **f32) for p in all_persons]
-        drgb_l = [torch.zeros(self.fg[p]["npts"] if p in self.fg else R * S, 3, **f32) for p in all_persons]
-        d_bg_rgb = torch.zeros(R, 3, **f32)
-        d_beta = torch.zeros(1, **f32)
+        dsdf_l = [zp.take((self.fg[p]["Pt"] if isinstance(self.fg[p]["it"], ImplicitTrainFused) else self.fg[p]["npts"])
+                          if p in self.fg else R * S) for p in all_persons]
+        drgb_l = [zp.take(self.fg[p]["npts"] if p in self.fg else R * S, 3) for p in all_persons]
+        d_bg_rgb = zp.take(R, 3)
+        d_beta = zp.take(1)
         t_dsdf, t_drgb = _table(dsdf_l, dev), _table(drgb_l, dev)
         _chk(L.mp_tr_composite_bwd(R, P, self.NZ, _p(t_inv), _p(t_z), _p(t_sdf), _p(t_rgb), _p(beta),
                                    _p(self.bg_rgb) if self.bg_rgb is not None else None, _p(d_rgb_values), _p(d_acc_map),
@@ -1215,7 +1227,7 @@ class TrainGraph:
             it, rt, npts, Pt = f["it"], f["rt"], f["npts"], f["Pt"]
             rev = isinstance(it, ImplicitTrainRev)
             fusedp = isinstance(it, ImplicitTrainFused)
-            dgrad = torch.zeros(Pt, 3, **f32) if rev else None
+            dgrad = zp.take(Pt, 3) if rev else None
             dXA = torch.empty(npts, 6, **f32)
             if fusedp:                 # d features as their own aligned matrix, written (not accumulated) by the colour net
                 dZ8 = None
@@ -1277,7 +1289,7 @@ class TrainGraph:
             self.ts.finish_group("bg")
             collect(bit); collect(brt)
             w = m.frame_latent_encoder.weight
-            gw = torch.zeros_like(w)
+            gw = zp.take(tuple(w.shape), dtype=w.dtype)
             gw.index_copy_(0, self.frame, dcode.reshape(1, -1))
             grads[id(w)] = gw
         bp = m.density.beta
@@ -1286,6 +1298,7 @@ class TrainGraph:
             tail = [bp] + ([m.frame_latent_encoder.weight] + b["it"].params() + b["rt"].params() if self.bg is not None else [])
             sync.retire(tail, [grads[id(prm)] for prm in tail])
             grads = sync.finish(grads)
+        _ZP[0] = None
         return grads
 
 

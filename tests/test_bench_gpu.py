@@ -46,12 +46,43 @@ def test_gpus_flag_starts_the_ranks_and_reports_strong_scaling():
     d = _run(["--gpus", "2", "--res", "64", "--steps", "2", "--warmup", "1", "--train-steps", "2", "--train-warmup", "1"],
              env={"MP_BENCH_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and "cpu_baseline" not in d
-    assert d["collective_backend"] == "gloo"
+    assert d["collective_backend"] == "gloo" and d["rccl_ranks_seen"] == 2      # an all_reduce of ones over the data-path backend
+    assert d["train_iter"]["host_ms_per_iter"] > 0
     assert d["config"]["rays_per_step"] == 64 * 64 and "ray-sharded dp2" in d["config"]["parallelism"]
     assert d["weak"]["scaling"] == "weak" and d["weak"]["value"] > 0
     assert d["train_iter"]["rays_per_iter_per_gpu"] == 256 and d["train_iter"]["rays_per_iter"] == 512
     pr = d["per_rank"]       # the diagnosis of a scaling run: per-rank frame time, ray share, time inside the image all_gather
     assert len(pr["ms_per_step"]) == 2 and sum(pr["rays"]) == 64 * 64 and all(t >= 0 for t in pr["all_gather_ms_per_step"])
+
+
+@pytest.mark.parametrize("mode,ranks,persons,slots", [("person", 2, 2, 0), ("hybrid", 4, 2, 2)])
+def test_person_and_hybrid_modes_render_the_single_process_frame(mode, ranks, persons, slots):
+    """BASELINE.json configs[3]'s measurement path: `--mode person` (persons sharded, one all_to_all per person slot and chunk) and
+    `--mode hybrid` (person teams x ray shards) render ONE frame per step over the ranks (sharing this box's GPU over gloo); the
+    line carries the per-rank frame time, the exchanges' own time and the image all_gather's"""
+    d = _run(["--gpus", str(ranks), "--mode", mode, "--persons", str(persons), "--res", "64", "--steps", "2", "--warmup", "1",
+              "--train-steps", "0", "--chunk-rays", "2048"] + (["--person-slots", str(slots)] if slots else []),
+             env={"MP_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == ranks and d["value"] > 0 and d["rccl_ranks_seen"] == ranks and d["config"]["persons"] == persons
+    assert mode in d["config"]["parallelism"] and "weak" not in d
+    pr = d["per_rank"]
+    assert len(pr["ms_per_step"]) == ranks and all(x > 0 for x in pr["exchanges_per_step"]) and all(t >= 0 for t in pr["exchange_ms_per_step"])
+    assert 0 < d["roofline"]["frac"] < 1
+
+
+def test_single_gpu_line_of_the_four_person_256_sample_workload():
+    """BASELINE.json configs[3] on one GPU: `--persons 4 --samples 256` (small frame here), same fields as the headline line"""
+    d = _run(["--persons", "4", "--samples", "256", "--res", "48", "--steps", "1", "--warmup", "1", "--train-steps", "0", "--cpu-rays", "96"])
+    assert d["config"]["persons"] == 4 and "4-person" in d["config"]["workload"] and "N_samples=256" in d["config"]["workload"]
+    assert 0 < d["roofline"]["frac"] < 1 and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["parity_rgb_max_abs"] < 8e-3
+
+
+def test_cpu_oracle_leg_is_cut_by_the_wall_time_guard():
+    """a slower host must not turn the headline run into a driver timeout: with a zero budget the oracle's render sample stops after the
+    minimum number of rays (here: the whole small sample is below the 4 096-ray floor, so it completes and says how many rays it did)"""
+    d = _run(["--res", "64", "--steps", "1", "--warmup", "1", "--train-steps", "0", "--cpu-rays", "1024", "--cpu-budget-s", "0"])
+    c = d["cpu_baseline"]
+    assert c["rays"] == 1024 and c["seconds"] > 0 and "1024 rays" in c["sample"]
 
 
 def test_two_ranks_over_rccl_when_the_box_has_two_gpus():

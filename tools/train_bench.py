@@ -23,8 +23,8 @@ def barrier():
     torch.cuda.synchronize()
 
 
-dt, ph, loss, stats = bench.train_iterations(model, gin, steps, warm, False, barrier, seed=0, rays=512)
-print(json.dumps({"ms_per_iter": 1e3 * dt / steps, "gpu_ms": {"forward+loss": ph[0], "backward": ph[1], "allreduce": ph[2],
+dt, ph, loss, stats, host_ms = bench.train_iterations(model, gin, steps, warm, False, barrier, seed=0, rays=512)
+print(json.dumps({"ms_per_iter": 1e3 * dt / steps, "host_ms_per_iter": host_ms, "gpu_ms": {"forward+loss": ph[0], "backward": ph[1], "allreduce": ph[2],
                                                                "adam": ph[3]}, "hit_rays": stats["n_hit"], "loss": loss}))
 
 # ---- host-side view: how long does the HOST need to enqueue each part (it runs ahead of the GPU unless something syncs)?
