@@ -162,6 +162,23 @@ int mp_obb_hull_device(const float* verts, int n_verts, int n_bodies, float infl
  * Returns the previous setting. */
 int mp_debug_hull_abandon(int on);
 
+/* ---- training objective ---------------------------------------------------------------------
+ * The per-ray / per-point terms of Loss.forward (reference code/lib/model/loss.py:6-177) and the gradient of their weighted sum in
+ * ONE launch (csrc/loss.hip).  All pointers device fp32 unless noted:
+ *   rgb [R][3] (NaN rows are left out), rgb_gt [R][3], acc [R], accp [R][P], gth [N][3] (eikonal gradients),
+ *   sam [R][P] SAM logits or NULL (term off), in_mask [R] bytes or NULL (in-shape term off)
+ *   -> terms [8] = {total, rgb_loss, eikonal, bce, in_shape, sam_mask, 0, 0} with
+ *      total = rgb_loss + w_eik eikonal + w_bce bce + w_in in_shape + w_sam sam_mask   (the caller resolves the epoch schedules)
+ *      d_rgb [R][3], d_acc [R], d_accp [R][P], d_gth [N][3] = d total / d (rgb, acc, accp, gth). */
+typedef struct {
+    const float *rgb, *rgb_gt, *acc, *accp, *gth, *sam;
+    const unsigned char* in_mask;
+    float *d_rgb, *d_acc, *d_accp, *d_gth, *terms;
+    int n_rays, n_persons, n_eik;
+    float w_eik, w_bce, w_in, w_sam, eps;
+} MpLossArgs;
+int mp_loss_fused(const MpLossArgs* args, void* stream);
+
 /* ---- rays -------------------------------------------------------------------------------------
  * rend_util.get_camera_params (lib/utils/rend_util.py:45-87) + far sphere root (:131-147).
  *   uv [R][2], intrinsics [16], pose [16] -> dirs [R][3], far [R]; cam is pose[:3,3]. */
@@ -414,6 +431,31 @@ int mp_tf_sdf_fwd(const void* wpack, const float* bias_all, const float* w8, flo
                   void* stream);
 int mp_tf_sdf_bwd(const void* wpack, const float* w8, float* arena, int P, const float* dfeat, const float* dsdf, float* dw8,
                   float* db8, void* stream);
+/* mp_tf_sdf_val: the VALUE sweep alone, sdf column only, nothing stashed -- mp_mlp_sdf's interface (worklist of point ids or NULL,
+ * device-side count or NULL, sdf_out written at the point ids) at the training path's arithmetic: split-bfloat16 products, fp32
+ * accumulation, fp32 softplus, Fourier features from sinf / cosf.  The sampler's queries with `Multiply.sampler_sdf_mode = 'bf16x3'`
+ * (ray_sampler.py:85-88): the depths then agree with the fp32 reference to 1e-3 instead of 2e-2 (profiles/r05_sampler_precision.txt).
+ * wpack / bias_all as written by mp_tf_sdf_pack (bias row 0 with the call's conditioning hoisted in). */
+int mp_tf_sdf_val(const void* wpack, const float* bias_all, const float* xc, const int* worklist, const int* count, int max_count,
+                  float* sdf_out, void* stream);
+
+/* The NeRF++ BACKGROUND ImplicitNet (networks.py:126-208 as configured by confs/model: d_in 4, multires 10 -> 84 Fourier features,
+ * the frame code hoisted into layer 0's bias, 8 x 256 softplus, skip at layer 4 = [172 | 84] / sqrt 2, 257 outputs, no weight norm;
+ * caller multiply.py:514-541) on the same layer-fused skeleton, VALUE ONLY (its outputs feed the density and the colour net; no
+ * spatial gradient is taken): mp_tf_bg_fwd = the value sweep, mp_tf_bg_bwd = its adjoint w.r.t. the activations.
+ *   mp_tf_bg_pack : W[9] effective weights ([256][116], [256][256] x 2, [172][256], [256][256] x 4, [257][256]), B[9] (B[0] with the
+ *                   frame code hoisted in) -> wpack (mp_tf_bg_sizes' pack_bytes), bias_all [9][288]
+ *   arena         : R1 = (P + 1) 256 floats per [P][256] tensor (one pad row):  dZ(l) l = 0..7 at l R1 (bwd) | X(l) l = 1..8 at
+ *                   (7 + l) R1 (fwd: layer l's input; columns 172.. of X(4) are the caller's: the re-injected features times
+ *                   1/sqrt 2, mp_tr_copy_cols) | IN [P][84] at 16 R1 (the Fourier features: caller, before fwd)
+ *   mp_tf_bg_fwd  : feat [P+1][256], sdf [P+1] (pad rows) = the last layer's outputs, and the X stashes
+ *   mp_tf_bg_bwd  : dfeat [P][256], dsdf [P] -> the dZ stashes; dw8 [256] += the sdf row's weight gradient, db8 [1] += its bias'
+ *   weight gradients (caller, mp_gemm_tn_bf16x3[_grouped]): dW_l += dZ_l^T X_l  (l = 0: X = IN; biases = column sums of dZ_l). */
+int mp_tf_bg_sizes(int P, long long* arena_floats, long long* pack_bytes);
+int mp_tf_bg_pack(const float* const* W, const float* const* B, void* wpack, float* bias_all, void* stream);
+int mp_tf_bg_fwd(const void* wpack, const float* bias_all, float* arena, int P, float* feat, float* sdf, void* stream);
+int mp_tf_bg_bwd(const void* wpack, const float* w8, float* arena, int P, const float* dfeat, const float* dsdf, float* dw8,
+                 float* db8, void* stream);
 
 /* The foreground RenderingNet ('pose_no_view', networks.py:263-312: 270 -> 4 x 256 ReLU -> 3, sigmoid) on the same skeleton:
  *   mp_tf_col_pack : W[5] (effective weights, layer 0 = [256][270]: columns 0..5 x_c / normal, 6..13 pose embedding, 14.. features),

@@ -462,21 +462,33 @@ constexpr bool SIG8 = true;
 #endif
 constexpr unsigned SIG_Q = MP_EXP_SIGBITS == 4 ? 0x4B804B80u : MP_EXP_SIGBITS == 6 ? 0x53E053E0u : 0x5BF85BF8u;      // 15.0 | 63.0 | 255.0
 constexpr unsigned SIG_QINV = MP_EXP_SIGBITS == 4 ? 0x2C442C44u : MP_EXP_SIGBITS == 6 ? 0x24102410u : 0x1C041C04u;   // 1/15 | 1/63 | 1/255
+constexpr unsigned SIG_Q_INT = MP_EXP_SIGBITS == 4 ? 15u : MP_EXP_SIGBITS == 6 ? 63u : 255u;
 constexpr float SIG_QINV_F = MP_EXP_SIGBITS == 4 ? 1.0f / 15.0f : MP_EXP_SIGBITS == 6 ? 1.0f / 63.0f : 1.0f / 255.0f;
 constexpr int SIG_CHUNK_BYTES = SIG8 ? 1024 : 2048;   // per wave and chunk: 64 lanes x (2 column blocks x 4 row pairs x 2 sigmoids)
+// -DMP_SIG_FROM_H (round 5): the stored sigmoid as 1 - 2^(-h') instead of 2^(z' - h')  [2^h' = 1 + 2^z', so both equal
+// 2^z' / (1 + 2^z')]: the subtraction z' - h' disappears (the negation rides on the v_exp source modifier) and the "1 -" folds
+// into the byte quantisation's FMA: t = -255 e + 1279.  One VALU stage fewer per row pair in the forward sweep (11.5 instead
+// of 12.5), which is bound by exactly that program.  The difference 1 - e loses RELATIVE precision where the sigmoid is tiny
+// (absolute error <= 2^-11 from the rounding of e near 1), far below the byte's 1 / 510.
+#ifdef MP_SIG_FROM_H
+constexpr bool SIG_FROM_H = SIG8;
+#else
+constexpr bool SIG_FROM_H = false;
+#endif
 struct ActConst {
     unsigned c1, c2, c3;   // the coefficients as packed half pairs, in vector registers (gfx9 VOP3P: no literals, one SGPR)
     unsigned c1024, c64;   // 8-bit sigmoids: 1024.0 pairs; 0x64646464 (the high bytes of halves 1024 + b)
+    unsigned ctop;         // SIG_FROM_H: (1024 + Q).0 pairs, Q = 255 (the byte of sigmoid 1)
 };
 __device__ __forceinline__ ActConst act_const() {
     const h2 a = {(op_t)LOG2P_C1, (op_t)LOG2P_C1}, b = {(op_t)LOG2P_C2, (op_t)LOG2P_C2}, c = {(op_t)LOG2P_C3, (op_t)LOG2P_C3};
     const h2 k = {(op_t)1024.0f, (op_t)1024.0f};
-    return ActConst{bits(a), bits(b), bits(c), bits(k), 0x64646464u};
+    return ActConst{bits(a), bits(b), bits(c), bits(k), 0x64646464u, 0x64006400u + (SIG_Q_INT | (SIG_Q_INT << 16))};
 }
 __device__ __forceinline__ unsigned sconst(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }   // into an SGPR
 // stages of the V program per layer kind (HIDDEN = false: the linear output layers, conversion only)
 __host__ __device__ constexpr int pp_stages(int hid, bool hidden) {
-    return !hidden ? 1 : hid == HID_SOFTPLUS_SAVE ? (LOG_POLY ? 10 : 11) + (SIG8 ? 2 : 0) : hid == HID_SOFTPLUS ? (LOG_POLY ? 7 : 8)
+    return !hidden ? 1 : hid == HID_SOFTPLUS_SAVE ? (LOG_POLY ? 10 : 11) + (SIG8 ? 2 : 0) - (SIG_FROM_H ? 1 : 0) : hid == HID_SOFTPLUS ? (LOG_POLY ? 7 : 8)
                      : hid == HID_SIGMUL && SIG8 ? 5 : 2;
 }
 
@@ -491,7 +503,8 @@ __device__ __forceinline__ void pp_instr(ActRegs8& a, const ActConst& k, const f
     //   transcendental: A1 u += 1, L0 L1 lg = log2(u), RL, HH h' = r + lg
     // and for the stored sigmoids: SB d = z' - h', S0 S1 sigmoid = 2^d
     constexpr int E0 = 1, E1 = 2, P0 = LOG_POLY ? 3 : -1, P1 = LOG_POLY ? 4 : -1, A1 = LOG_POLY ? -1 : 3, L0 = LOG_POLY ? -1 : 4,
-                  L1 = LOG_POLY ? -1 : 5, RL = LOG_POLY ? 5 : 6, HH = LOG_POLY ? 6 : 7, SB = HH + 1, S0 = HH + 2, S1 = HH + 3;
+                  L1 = LOG_POLY ? -1 : 5, RL = LOG_POLY ? 5 : 6, HH = LOG_POLY ? 6 : 7, SB = SIG_FROM_H ? -1 : HH + 1,
+                  S0 = SIG_FROM_H ? HH + 1 : HH + 2, S1 = S0 + 1;
     if constexpr (ST == 0) {          // left to the compiler: it knows the MFMA -> VALU read hazard
         a.z[q] = bits(to_h2(acc[mbl][nb][2 * j], acc[mbl][nb][2 * j + 1]));
         if constexpr (!HIDDEN) {
@@ -556,10 +569,16 @@ __device__ __forceinline__ void pp_instr(ActRegs8& a, const ActConst& k, const f
         if (c < KS_REG) Bn.put(c, nb, mbl, j, __builtin_bit_cast(h2, a.h[q]));
     } else if constexpr (ST == SB) {  // z' - h'
         asm volatile("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(a.d[q]) : "v"(a.z[q]), "v"(a.h[q]));
-    } else if constexpr (ST == S0) {  // sigmoid(z') = 2^(z' - h')
-        asm volatile("v_exp_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=&v"(a.s[q]) : "v"(a.d[q]));
+    } else if constexpr (ST == S0) {  // sigmoid(z') = 2^(z' - h');  SIG_FROM_H: e = 2^(-h') = 1 - sigmoid(z')
+        if constexpr (SIG_FROM_H)
+            asm volatile("v_exp_f16_sdwa %0, -%1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=&v"(a.s[q]) : "v"(a.h[q]));
+        else
+            asm volatile("v_exp_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=&v"(a.s[q]) : "v"(a.d[q]));
     } else if constexpr (ST == S1) {
-        asm volatile("v_exp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(a.s[q]) : "v"(a.d[q]));
+        if constexpr (SIG_FROM_H)
+            asm volatile("v_exp_f16_sdwa %0, -%1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(a.s[q]) : "v"(a.h[q]));
+        else
+            asm volatile("v_exp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(a.s[q]) : "v"(a.d[q]));
         if constexpr (!SIG8) {
             constexpr int e = 2 * mbl + j;   // by name, see the note at the HID_SIGMUL read
             if constexpr (e == 0) sg[nb].x = a.s[q];
@@ -569,7 +588,10 @@ __device__ __forceinline__ void pp_instr(ActRegs8& a, const ActConst& k, const f
         }
     } else if constexpr (ST == S1 + 1) {   // 8-bit: 1024 + 255 s (0x5BF8 = 255.0): the mantissa's low byte is round(255 s)
         static_assert(SIG8, "pp_instr: stage");
-        asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(a.s[q]) : "s"(sconst(SIG_Q)), "v"(k.c1024));
+        if constexpr (SIG_FROM_H)     // 1024 + Q (1 - e) = -Q e + (1024 + Q)
+            asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(a.s[q]) : "s"(sconst(SIG_Q | 0x80008000u)), "v"(k.ctop));
+        else
+            asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(a.s[q]) : "s"(sconst(SIG_Q)), "v"(k.c1024));
     } else {                               // 8-bit: the low bytes of the four halves of row pairs j = 0, 1 into one dword
         static_assert(SIG8 && ST == S1 + 2, "pp_instr: stage");
         if constexpr (j == 0) {

@@ -582,6 +582,108 @@ __global__ __launch_bounds__(TF_THREADS) void k_tf_sdf_fwd(TfArgs a) {
     }
 }
 
+// ================================================================================================================ value only
+// The SAMPLER's network queries at the training path's arithmetic (round 5): the value sweep alone, sdf row only, nothing
+// stashed -- split-bfloat16 products with fp32 accumulation and fp32 softplus, where the inference kernel k_mlp_sdf (csrc/mlp.hip)
+// rounds inputs, weights and activations to half precision (each of the three contributes ~1e-4 to the sdf, measured).  The
+// sampler's depths are an inverse CDF of these values and a shifted sample can cross the reference's `dist > 0.1 => sdf = 4`
+// discontinuity (multiply.py:142-143): with these queries the depths agree with the fp32 oracle to 1e-3 instead of 2e-2 and the
+// opacity of the worst grazing ray to 9e-4 instead of 1.1e-1 (profiles/r05_sampler_precision.txt).  Same chunk stream as the
+// forward kernel's value sweep (chunks 0..63, then chunk 72 = the sdf row), same worklist interface as mp_mlp_sdf.
+struct TfValArgs {
+    const char* wpack;
+    const float* bias;      // [9][288], layer 0 with the call's conditioning hoisted in (FusedSDFState.refresh)
+    const float* xc;        // [*][3] canonical points
+    const int* worklist;    // point ids, or NULL = identity
+    const int* count_p;     // device-side number of work items (NULL: max_count)
+    float* sdf_out;         // [*], written at the point ids
+    int max_count;
+};
+struct EpiV {
+    static constexpr bool NEXT_FROM_MEM = false;
+    const float* bias;     // this layer's biases in pack-row order (the last layer: its single chunk's)
+    float osc;
+    bool linear;
+    float* sdf_out;
+    int id;                // this lane's point id (lanes of one column share it), -1 = none
+    f32x4 pb[2], nb[2];
+    __device__ __forceinline__ int prefetch(const Ctx& cx, int c) {
+        nb[0] = ld4g(bias + 32 * c + 4 * cx.g);
+        nb[1] = ld4g(bias + 32 * c + 16 + 4 * cx.g);
+        return 2;
+    }
+    __device__ __forceinline__ void rotate() { pb[0] = nb[0]; pb[1] = nb[1]; }
+    __device__ __forceinline__ void touch() { touch4(pb[0]); touch4(pb[1]); }
+    __device__ __forceinline__ void init(const Ctx&, int, f32x4 (&acc)[2]) {
+        acc[0] = pb[0];
+        acc[1] = pb[1];
+    }
+    __device__ __forceinline__ void run(const Ctx& cx, int c, const f32x4 (&acc)[2], BReg& Bn) {
+        if (linear) {
+            if (cx.g == 0 && id >= 0) sdf_out[id] = acc[0][0];     // row 256 of the last layer = the sdf row (chunk 72, row 0)
+            return;
+        }
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float t = acc[e >> 2][e & 3] * K2;
+            const float u = __builtin_amdgcn_exp2f(-__builtin_fabsf(t));
+            x[e] = (__builtin_fmaxf(t, 0.0f) + __builtin_amdgcn_logf(1.0f + u)) * osc;
+        }
+        if (c < 8) split8(x, Bn.h[c], Bn.l[c]);
+    }
+};
+
+__global__ __launch_bounds__(TF_THREADS) void k_tf_sdf_val(TfValArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int count = a.count_p ? min(*a.count_p, a.max_count) : a.max_count;
+    for (int tile = blockIdx.x; tile * TF_PTS < count; tile += gridDim.x) {
+        Ctx cx;
+        ctx_setup(cx, smem, a.wpack, count, 65, 64, 8, nullptr);     // stream position 64 = chunk 72
+        const int w = tile * TF_PTS + cx.wave * 16 + cx.j;
+        const int id = w < count ? (a.worklist ? a.worklist[w] : w) : -1;
+        {   // the wave's input-fed B fragments: Fourier features of its 16 points, natural slot order (39 of 64 used), as
+            // k_pe_fwd computes them (sinf / cosf of x 2^k: the training forward's encoding)
+            float px = 0.f, py = 0.f, pz = 0.f;
+            if (id >= 0) { px = a.xc[3 * (size_t)id]; py = a.xc[3 * (size_t)id + 1]; pz = a.xc[3 * (size_t)id + 2]; }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int f = 32 * ks + 8 * cx.g + e;
+                    float val = 0.0f;
+                    if (f < 3) val = f == 0 ? px : (f == 1 ? py : pz);
+                    else if (f < E_PE) {
+                        const int k = (f - 3) / 6, r = (f - 3) % 6, ax = r % 3;
+                        const float arg = (ax == 0 ? px : (ax == 1 ? py : pz)) * (float)(1 << k);
+                        val = r < 3 ? sinf(arg) : cosf(arg);
+                    }
+                    v[e] = val;
+                }
+                bf16x8 hi, lo;
+                split8(v, hi, lo);
+                *(bf16x8*)(cx.binf + (ks * 2 + 0) * TILE_B + cx.lane * 16) = hi;
+                *(bf16x8*)(cx.binf + (ks * 2 + 1) * TILE_B + cx.lane * 16) = lo;
+            }
+        }
+        tf_prologue(cx);
+        BReg Bcur, Bnext;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { Bcur.h[k] = Bcur.l[k] = Bnext.h[k] = Bnext.l[k] = zero_frag(); }
+        for (int l = 0; l <= 8; ++l) {
+            EpiV ep;
+            ep.bias = a.bias + l * BIAS_LD + (l == 8 ? 256 : 0);
+            ep.osc = (l == 3 ? R2 : 1.0f) / K2;
+            ep.linear = l == 8;
+            ep.sdf_out = a.sdf_out;
+            ep.id = id;
+            tf_layer<EpiV, 8, true>(cx, ep, l == 8 ? 1 : 8, l > 0, l == 0 || l == 4, Bcur, Bnext);
+        }
+        __syncthreads();      // the ring and the input blocks are rebuilt by the next tile
+    }
+}
+
 // ================================================================================================================ backward
 // sum over the 16 points of a wave (lanes j = 0..15 of each group g) of 8 per-lane values -> LDS column sums
 __device__ __forceinline__ void col_reduce(const Ctx& cx, int c, float (&r)[8]) {
@@ -687,7 +789,7 @@ struct EpiD {
     }
     const float* xin;      // X_l rows
     float kx;
-    const float* dsin;     // dS_{l-1} rows
+    const float* dsin;     // dS_{l-1} rows; NULL: a value-only network (no gradient sweep, hence no second-order term)
     float* dzout;          // dZ_{l-1} rows
     bool first;            // layer 8: accumulators start from w8 (x) d sdf (a rank-1 term); also sums d sdf . X_8
     const float* w8;
@@ -697,6 +799,10 @@ struct EpiD {
         const int col = 32 * c + 4 * cx.g;
         nx[0] = ld4g(xin + cx.row + col);
         nx[1] = ld4g(xin + cx.row + col + 16);
+        if (dsin == nullptr) {
+            nd[0] = nd[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            return 2;
+        }
         nd[0] = ld4g(dsin + cx.row + col);
         nd[1] = ld4g(dsin + cx.row + col + 16);
         return 4;
@@ -775,6 +881,139 @@ __global__ __launch_bounds__(TF_THREADS) void k_tf_sdf_bwd(TfArgs a) {
         ep.kx = l == 4 ? K2 / R2 : K2;
         ep.dsin = a.arena + off_dS(R1, l - 1);
         ep.dzout = a.arena + off_dZ(R1, l - 1);
+        ep.first = l == 8;
+        ep.w8 = a.w8;
+        ep.dsdf = dsdf;
+        tf_layer<EpiD, 8, false>(cx, ep, 8, true, false, Bcur, Bnext);
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) atomicAdd(a.dw8 + threadIdx.x, cx.redf[threadIdx.x]);
+    if (threadIdx.x == 256) atomicAdd(a.db8, cx.redf[256]);
+}
+
+// ================================================================================================================ background net
+// The NeRF++ background ImplicitNet (networks.py:126-208 with confs/model: d_in 4, multires 10 -> 84 Fourier features, frame code
+// (32) hoisted into layer 0's bias, 8 x 256 softplus, skip connection at layer 4 = [172 | 84] / sqrt 2, 257 outputs, no weight
+// norm; multiply.py:514-541) on the same skeleton, VALUE ONLY: the training forward reads its density (|sdf|) and features, no
+// spatial gradient, so the backward is the plain descending sweep.  Round 4 ran it layer by layer (9 GEMMs + 8 softplus passes
+// forward, 3 GEMMs + a pass per layer backward: ~45 launches, ~0.9 ms per iteration).
+// The 84 Fourier features do not fit the 64 input-fed K slots of a chunk; they ride in the REGISTER operand instead: layer 0's
+// operand is the feature row itself (K slots 0..83), and layer 4's operand is layer 3's 172 outputs followed by the 84 features
+// (times 1/sqrt 2) in slots 172..255 -- exactly 256.  No chunk of this network has an input-fed part.
+// chunk stream (40 KiB chunks as above): 0..72 value orientation W_l, l = 0..8 (layer 3: rows >= 172 zero; layer 8: 256 feature
+// rows, then the sdf row); 73..136 for the backward: W_8[1:]^T, then W_l^T for l = 7..1 (l = 4: only the 172 rows of X_4's
+// network part, times 1/sqrt 2).
+// stash (floats), P points, R1 = (P + 1) 256:  dZ(l) l = 0..7 at l R1 | X(l) l = 1..8 at (7 + l) R1 | IN [P][84] at 16 R1
+constexpr int BG_E = 84, BG_OUT3 = 172, BG_IN0 = 116, BG_FWD = 73, BG_TOTAL = 137;
+__host__ __device__ inline size_t bgoff_dZ(size_t R1, int l) { return (size_t)l * R1; }
+__host__ __device__ inline size_t bgoff_X(size_t R1, int l) { return (size_t)(7 + l) * R1; }
+__host__ __device__ inline size_t bgoff_IN(size_t R1) { return 16 * R1; }
+
+__device__ float pack_value_bg(const float* const* __restrict__ W, int chunk, int r, int f, int s) {
+    if (f < 0) return 0.f;                                // no input-fed part
+    if (chunk < BG_FWD) {                                 // value orientation
+        const int l = chunk == 72 ? 8 : chunk >> 3, R = chunk == 72 ? 256 + r : 32 * (chunk & 7) + r;
+        int o;
+        if (l < 8) { o = R; if (R >= (l == 3 ? BG_OUT3 : HID)) return 0.f; }
+        else { if (R > 256) return 0.f; o = R < 256 ? R + 1 : 0; }
+        if (l == 0) return f < BG_E ? W[0][(size_t)o * BG_IN0 + f] : 0.f;
+        return W[l][(size_t)o * HID + f];                 // (layer 4: columns 172.. multiply the re-injected features)
+    }
+    const int k = chunk - BG_FWD, l = k < 8 ? 8 : 7 - (k - 8) / 8, R = 32 * (k % 8) + r;
+    if (l == 8) return W[8][(size_t)(f + 1) * HID + R];   // W_8[1:]^T
+    if (f >= (l == 3 ? BG_OUT3 : HID)) return 0.f;        // K = the layer's outputs
+    if (l == 4) return R < BG_OUT3 ? W[4][(size_t)f * HID + R] * R2 : 0.f;
+    return W[l][(size_t)f * HID + R];
+}
+__global__ __launch_bounds__(512) void k_tf_pack_bg(const float* const* __restrict__ W, const float* const* __restrict__ B,
+                                                    __bf16* __restrict__ wpack, float* __restrict__ bias_all) {
+    pack_chunk(W, wpack, pack_value_bg);
+    const int l = blockIdx.x;
+    if (l < 9)
+        for (int r = threadIdx.x; r < BIAS_LD; r += 512) {
+            float b = 0.f;
+            if (l < 8) { if (r < (l == 3 ? BG_OUT3 : HID)) b = B[l][r]; }
+            else if (r <= 256) b = B[8][r < 256 ? r + 1 : 0];
+            bias_all[l * BIAS_LD + r] = b;
+        }
+}
+
+// this lane's eight K slots of K step ks from a row of 84 features (slot order = feature order through slot_feature), times sc;
+// slots at or beyond `from` take the feature f - from, the others keep `keep`
+__device__ __forceinline__ void bg_feature_slots(const Ctx& cx, const float* __restrict__ in_row, int ks, int from, float sc,
+                                                 BReg& B) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int f = slot_feature(ks, cx.g, e);
+        const float keep = (float)B.h[ks][e] + (float)B.l[ks][e];
+        v[e] = f >= from ? (f - from < BG_E ? in_row[f - from] * sc : 0.0f) : keep;
+    }
+    split8(v, B.h[ks], B.l[ks]);
+}
+__device__ __forceinline__ void bg_ctx(Ctx& cx) { cx.noreg_hi = 0; cx.in0_lo = cx.in0_hi = cx.in1_lo = cx.in1_hi = 0; }
+
+__global__ __launch_bounds__(TF_THREADS) void k_tf_bg_fwd(TfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Ctx cx;
+    const size_t R1 = (size_t)(a.P + 1) * HID;
+    ctx_setup(cx, smem, a.wpack, a.P, BG_FWD, BG_FWD, 0, nullptr);
+    bg_ctx(cx);
+    tf_prologue(cx);
+    BReg Bcur, Bnext;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { Bcur.h[k] = Bcur.l[k] = Bnext.h[k] = Bnext.l[k] = zero_frag(); }
+    const float* in_row = a.arena + bgoff_IN(R1) + cx.prow * BG_E;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) bg_feature_slots(cx, in_row, ks, 0, 1.0f, Bcur);        // layer 0's operand: the features
+    for (int l = 0; l <= 8; ++l) {
+        EpiA ep;
+        ep.bias = a.bias + l * BIAS_LD;
+        ep.xout = a.arena + bgoff_X(R1, l < 8 ? l + 1 : 8);
+        ep.osc = (l == 3 ? R2 : 1.0f) / K2;
+        ep.linear = l == 8;
+        ep.feat = a.feat;
+        ep.sdf = a.sdf;
+        tf_layer<EpiA, 9, false>(cx, ep, l == 8 ? 9 : 8, true, false, Bcur, Bnext);
+        if (l == 3) {                                      // the skip connection: slots 172..255 of layer 4's operand
+#pragma unroll
+            for (int ks = 5; ks < 8; ++ks) bg_feature_slots(cx, in_row, ks, BG_OUT3, R2, Bcur);
+        }
+    }
+}
+
+__global__ __launch_bounds__(TF_THREADS) void k_tf_bg_bwd(TfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Ctx cx;
+    const size_t R1 = (size_t)(a.P + 1) * HID;
+    ctx_setup(cx, smem, a.wpack, a.P, 64, 0, BG_FWD, nullptr);       // stream position k = chunk 73 + k
+    bg_ctx(cx);
+    if (threadIdx.x < 257) cx.redf[threadIdx.x] = 0.0f;
+    tf_prologue(cx);
+    BReg Bcur, Bnext;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { Bnext.h[k] = Bnext.l[k] = zero_frag(); }
+    const float dsdf = a.dsdf[cx.prow];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const f32x4 v0 = ld4g(a.dfeat + cx.row + 32 * ks + 4 * cx.g), v1 = ld4g(a.dfeat + cx.row + 32 * ks + 16 + 4 * cx.g);
+        const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        split8(v, Bcur.h[ks], Bcur.l[ks]);
+    }
+    {   // the last layer's sdf bias gradient: sum over the workgroup's points of d sdf
+        float t = (cx.valid && cx.g == 0) ? dsdf : 0.0f;
+        t += __shfl_xor(t, 1);
+        t += __shfl_xor(t, 2);
+        t += __shfl_xor(t, 4);
+        t += __shfl_xor(t, 8);
+        if (cx.lane == 0) atomicAdd(cx.redf + 256, t);
+    }
+    for (int l = 8; l >= 1; --l) {
+        EpiD ep;
+        ep.xin = a.arena + bgoff_X(R1, l);
+        ep.kx = l == 4 ? K2 / R2 : K2;
+        ep.dsin = nullptr;
+        ep.dzout = a.arena + bgoff_dZ(R1, l - 1);
         ep.first = l == 8;
         ep.w8 = a.w8;
         ep.dsdf = dsdf;
@@ -1016,12 +1255,50 @@ extern "C" int mp_tf_sdf_fwd(const void* wpack, const float* bias_all, const flo
     return (int)hipGetLastError();
 }
 
+extern "C" int mp_tf_sdf_val(const void* wpack, const float* bias_all, const float* xc, const int* worklist, const int* count,
+                             int max_count, float* sdf_out, void* stream) {
+    if (max_count <= 0) return 0;
+    MP_LDS_ATTR(k_tf_sdf_val, LDS_BYTES);
+    TfValArgs a{(const char*)wpack, bias_all, xc, worklist, count, sdf_out, max_count};
+    const int tiles = (max_count + TF_PTS - 1) / TF_PTS;
+    hipLaunchKernelGGL(k_tf_sdf_val, dim3(tiles < 256 ? tiles : 256), dim3(TF_THREADS), LDS_BYTES, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
 extern "C" int mp_tf_sdf_bwd(const void* wpack, const float* w8, float* arena, int P, const float* dfeat, const float* dsdf,
                              float* dw8, float* db8, void* stream) {
     if (P <= 0) return 0;
     MP_LDS_ATTR(k_tf_sdf_bwd, LDS_BYTES);
     TfArgs a{(const char*)wpack, nullptr, w8, arena, nullptr, nullptr, dfeat, dsdf, dw8, db8, P};
     hipLaunchKernelGGL(k_tf_sdf_bwd, dim3((P + TF_PTS - 1) / TF_PTS), dim3(TF_THREADS), LDS_BYTES, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_tf_bg_sizes(int P, long long* arena_floats, long long* pack_bytes) {
+    if (arena_floats) *arena_floats = 16LL * (P + 1) * HID + (long long)BG_E * P + 256;
+    if (pack_bytes) *pack_bytes = (long long)BG_TOTAL * CH_BYTES;
+    return 0;
+}
+
+extern "C" int mp_tf_bg_pack(const float* const* W, const float* const* B, void* wpack, float* bias_all, void* stream) {
+    hipLaunchKernelGGL(k_tf_pack_bg, dim3(BG_TOTAL), dim3(512), 0, (hipStream_t)stream, W, B, (__bf16*)wpack, bias_all);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_tf_bg_fwd(const void* wpack, const float* bias_all, float* arena, int P, float* feat, float* sdf, void* stream) {
+    if (P <= 0) return 0;
+    MP_LDS_ATTR(k_tf_bg_fwd, LDS_BYTES);
+    TfArgs a{(const char*)wpack, bias_all, nullptr, arena, feat, sdf, nullptr, nullptr, nullptr, nullptr, P};
+    hipLaunchKernelGGL(k_tf_bg_fwd, dim3((P + TF_PTS - 1) / TF_PTS), dim3(TF_THREADS), LDS_BYTES, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_tf_bg_bwd(const void* wpack, const float* w8, float* arena, int P, const float* dfeat, const float* dsdf,
+                            float* dw8, float* db8, void* stream) {
+    if (P <= 0) return 0;
+    MP_LDS_ATTR(k_tf_bg_bwd, LDS_BYTES);
+    TfArgs a{(const char*)wpack, nullptr, w8, arena, nullptr, nullptr, dfeat, dsdf, dw8, db8, P};
+    hipLaunchKernelGGL(k_tf_bg_bwd, dim3((P + TF_PTS - 1) / TF_PTS), dim3(TF_THREADS), LDS_BYTES, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

@@ -11,8 +11,52 @@ backward (multiply_amd/train.py) consumes.  Terms:
   sam_mask_loss  clipped L1 between acc_person and sigmoid(sam logits)                  (loss.py:61-78, 143-146)
   temporal/smpl_surface/zero_pose/depth_order: passed through with their schedules     (loss.py:141-158)
 """
+import ctypes as C
+import os
+
 import torch
 from torch import nn
+
+# The per-ray terms and their adjoints in ONE HIP launch (csrc/loss.hip mp_loss_fused) when the model outputs live on the GPU
+# (the training path always does); MP_FUSED_LOSS=0: the torch statement below everywhere (the cross-check, tests/test_loss_gpu.py).
+FUSED = os.environ.get("MP_FUSED_LOSS", "1") != "0"
+
+
+class MpLossArgs(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("rgb", "rgb_gt", "acc", "accp", "gth", "sam", "in_mask", "d_rgb", "d_acc", "d_accp",
+                                           "d_gth", "terms")] + \
+               [("n_rays", C.c_int), ("n_persons", C.c_int), ("n_eik", C.c_int)] + \
+               [(k, C.c_float) for k in ("w_eik", "w_bce", "w_in", "w_sam", "eps")]
+
+
+class _FusedTerms(torch.autograd.Function):
+    """(rgb_values, acc_map, acc_person_list, grad_theta) -> (total, terms): the kernel evaluates the terms AND the gradient of
+    their weighted sum; backward scales the stored gradient by d loss / d total.  `terms` (the individual losses the trainer
+    logs) is not differentiable: only `loss` is ever back-propagated (multiply_model.py:212-217)."""
+
+    @staticmethod
+    def forward(ctx, rgb, acc, accp, gth, rgb_gt, sam, in_mask, w):
+        from . import hip
+        f = lambda t: t.detach().contiguous().float()
+        rgb, acc, accp, gth, rgb_gt = f(rgb).reshape(-1, 3), f(acc).reshape(-1), f(accp), f(gth).reshape(-1, 3), f(rgb_gt).reshape(-1, 3)
+        R, P, N = rgb.shape[0], accp.reshape(R, -1).shape[1], gth.shape[0]
+        sam = None if sam is None else f(sam).reshape(R, P)
+        in_mask = None if in_mask is None else in_mask.detach().reshape(-1).to(torch.uint8).contiguous()
+        buf = torch.empty(8 + 4 * R + R * P + 3 * N, dtype=torch.float32, device=rgb.device)      # terms + the four gradients
+        terms, d_rgb, d_acc = buf[:8], buf[8:8 + 3 * R].view(R, 3), buf[8 + 3 * R:8 + 4 * R]
+        d_accp, d_gth = buf[8 + 4 * R:8 + 4 * R + R * P].view(R, P), buf[8 + 4 * R + R * P:].view(N, 3)
+        p = lambda t: None if t is None else t.data_ptr()
+        args = MpLossArgs(p(rgb), p(rgb_gt), p(acc), p(accp), p(gth), p(sam), p(in_mask), p(d_rgb), p(d_acc), p(d_accp), p(d_gth),
+                          p(terms), R, P, N, *w)
+        hip.check(hip.lib().mp_loss_fused(C.byref(args), hip.stream()), "mp_loss_fused")
+        ctx.grads = (d_rgb, d_acc, d_accp, d_gth)
+        ctx.mark_non_differentiable(terms)
+        return terms[0].reshape(1), terms
+
+    @staticmethod
+    def backward(ctx, g_total, _g_terms):
+        scaled = torch._foreach_mul(list(ctx.grads), g_total.reshape(()))       # one launch for the four gradients
+        return scaled[0], scaled[1], scaled[2], scaled[3], None, None, None, None
 
 
 def _get(opt, key, default):
@@ -96,9 +140,40 @@ class Loss(nn.Module):
         d_correct = (mean_hitted_vertex_list[correct, cols, :] - cam_loc).norm(dim=-1)
         return torch.log(1 + torch.exp(d_correct - d_front)).sum()
 
+    def _forward_fused(self, mo, ground_truth):
+        """Loss.forward with the ray / point reductions in csrc/loss.hip (same keys, same numbers to fp32 summation order)."""
+        dev = mo["acc_map"].device
+        epoch = mo["epoch"]
+        e200 = min(self.milestone, epoch)
+        use_sam = "sam_mask" in mo and epoch >= self.sam_start_epoch
+        sam_ramp = min(1.0, epoch / 100) if self.increase_sam else 1.0
+        in_mask = mo["index_in_surface"]
+        w = (float(self.eikonal_weight), float(self.bce_weight), float(self.in_shape_weight * (1 - e200 / self.milestone)),
+             float(self.sam_mask_weight * sam_ramp), float(self.eps))
+        gth = mo["grad_theta"]
+        accp = mo["acc_person_list"]
+        total, terms = _FusedTerms.apply(mo["rgb_values"], mo["acc_map"], accp.reshape(mo["acc_map"].numel(), -1), gth,
+                                         ground_truth["rgb"][0].to(dev), mo["sam_mask"] if use_sam else None, in_mask, w)
+        zero = terms[6:7]                                                  # a device zero (no fill of its own)
+        temporal_loss = mo["temporal_loss"]
+        smpl_surface_loss = mo["smpl_surface_loss"] * self.smpl_surface_weight if self.smpl_surface_weight else zero
+        zp_w = self.zero_pose_weight * (1 - min(1000, epoch) / 1000)
+        loss = total + self.temporal_loss_weight * temporal_loss
+        if self.smpl_surface_weight:
+            loss = loss + smpl_surface_loss * (1 - min(self.smpl_surface_milestone, epoch) / self.smpl_surface_milestone)
+        if zp_w:
+            loss = loss + mo["zero_pose_loss"] * zp_w
+        return {"loss": loss, "rgb_loss": terms[1], "depth_order_loss": zero, "eikonal_loss": terms[2], "bce_loss": terms[3:4],
+                "opacity_sparse_loss": zero, "in_shape_loss": terms[4:5], "temporal_loss": temporal_loss,
+                "sam_mask_loss": terms[5] if use_sam else zero, "smpl_surface_loss": smpl_surface_loss,
+                "zero_pose_loss": mo["zero_pose_loss"]}
+
     def forward(self, model_outputs, ground_truth):
         mo = model_outputs
         dev = mo["acc_map"].device
+        if (FUSED and dev.type == "cuda" and isinstance(mo["fg_rgb_values_each_person_list"], list)
+                and all(torch.is_tensor(mo[k]) and mo[k].is_cuda for k in ("rgb_values", "acc_person_list", "grad_theta"))):
+            return self._forward_fused(mo, ground_truth)
         zero = lambda: torch.zeros(1, device=dev)
         epoch = mo["epoch"]
 

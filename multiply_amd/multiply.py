@@ -451,12 +451,28 @@ class Multiply(nn.Module):
 
     def _sampler_sdf(self, s, it):
         """the sampler's network queries of iteration `it`: the fused half-precision kernel (csrc/mlp.hip k_mlp_sdf).
-        `self.sampler_sdf_mode = 'bf16x3'` (MP_SAMPLER_SDF; a MEASUREMENT switch, tools/sampler_precision.py) evaluates the same
-        worklist layer by layer with the training path's split-bfloat16 GEMMs (fp32 activations, ~2^-16 per product) instead --
-        what the sampler's depths would be with near-fp32 queries; it reads the worklist count on the host."""
+        `self.sampler_sdf_mode = 'bf16x3'` (MP_SAMPLER_SDF): the same worklist through the value sweep of the training path's
+        layer-fused kernel (mp_tf_sdf_val: split-bfloat16 products, fp32 activations, ~2^-16 per product) -- the sampler's depths
+        with near-fp32 queries, ~4x the query time; 'bf16x3-layerwise': the same arithmetic layer by layer
+        (the independent implementation tools/sampler_precision.py first measured with; reads the worklist count on the host)."""
         L, st = hip.lib(), hip.stream()
         pk_sdf, wcount = s["pk_sdf"], s["wcount"]
-        if getattr(self, "sampler_sdf_mode", "f16") != "f16":
+        mode = getattr(self, "sampler_sdf_mode", "f16")
+        if mode == "bf16x3":
+            # the value sweep of the training path's layer-fused kernel (csrc/tfuse.hip k_tf_sdf_val): same worklist, device-side count
+            fs = s.get("fs")
+            if fs is None:
+                from . import train as T
+                imp = self.foreground_implicit_network_list[s["p"]]
+                if not T.fused_sdf_supported(imp):
+                    raise NotImplementedError("sampler_sdf_mode 'bf16x3' needs the network shape csrc/tfuse.hip is specialised for")
+                # once per call and person; a training forward shares the iteration's resolved weights (TrainState.begin ran)
+                lins = T.train_state(self).lins[id(imp)] if self.training else None
+                fs = s["fs"] = T.fused_sdf_state(imp, lins).refresh(s["pp"]["cond"])
+            hip.check(L.mp_tf_sdf_val(hip.ptr(fs.wpack), hip.ptr(fs.bias_all), hip.ptr(s["xc_new"]), hip.ptr(s["work"]),
+                                      hip.ptr(wcount[it:it + 1]), s["Rp"] * s["NE"], hip.ptr(s["sdfnew"]), st), "mp_tf_sdf_val")
+            return
+        if mode == "bf16x3-layerwise":          # the measurement path of tools/sampler_precision.py (host read per iteration)
             from . import train as T
             n = int(wcount[it])
             if n > 0:

@@ -485,7 +485,7 @@ class TrainState:
         self.tables = {}
         for key, nets in self.groups:
             for net in nets:
-                fused = isinstance(net, _implicit_net_type()) and fused_sdf_supported(net)
+                fused = isinstance(net, _implicit_net_type()) and (fused_sdf_supported(net) or fused_bg_supported(net))
                 ls = []
                 for i, lin in enumerate(net.layers()):
                     lp = LinP(lin, pad_rows=256 if (fused and i == 3) else 0, need_wt=True, standalone=False)
@@ -713,6 +713,111 @@ class ImplicitTrainFused(ImplicitTrainRev):
         return dcond
 
 
+def fused_bg_supported(net):
+    """the network shape the fused background kernels (csrc/tfuse.hip k_tf_bg_*) are specialised for: the shipped NeRF++ net"""
+    return (net.d_in == 4 and net.multires == 10 and list(net.skip_in) == [4] and net.num_layers - 1 == 9 and net.cond_dim == 32
+            and list(net.dims[1:-1]) == [256] * 8 and net.dims[-1] == 257 and not hasattr(net.lin0, "weight_g"))
+
+
+class FusedBGState:
+    """chunk stream, bias table and pointer tables of the fused background kernels for one ImplicitNet (LinP layers shared with the
+    TrainState, or its own)"""
+
+    def __init__(self, net, lins=None):
+        self.net = net
+        self.shared = lins is not None
+        self.lins = lins if self.shared else [LinP(l, pad_rows=256 if i == 3 else 0) for i, l in enumerate(net.layers())]
+        dev = self.lins[0].W.device
+        arena, pack = C.c_longlong(0), C.c_longlong(0)
+        _chk(hip.lib().mp_tf_bg_sizes(1, C.byref(arena), C.byref(pack)), "mp_tf_bg_sizes")
+        self.wpack = torch.empty(int(pack.value), dtype=torch.uint8, device=dev)
+        self.bias_all = torch.empty(9 * 288, dtype=F32, device=dev)
+        self.b0 = torch.empty(256, dtype=F32, device=dev)
+        self.wtab = _table([lw.W for lw in self.lins], dev)
+        self._btab_key, self.btab = None, None
+
+    def refresh(self, code):
+        L, st = hip.lib(), hip.stream()
+        net, lins = self.net, self.lins
+        if not self.shared:
+            for lw in lins:
+                lw.refresh()
+        lw0 = lins[0]
+        _chk(L.mp_tr_hoist_fwd(_p(lw0.W), 256, lw0.in_dim, _p(lw0.b), net.embed_dim, net.cond_dim, _p(code), _p(self.b0), st),
+             "mp_tr_hoist_fwd")
+        bs = [self.b0] + [lw.b for lw in lins[1:]]
+        key = tuple(b.data_ptr() for b in bs)
+        if key != self._btab_key:
+            self._btab_key, self.btab = key, _table(bs, self.b0.device)
+        _chk(L.mp_tf_bg_pack(_p(self.wtab), _p(self.btab), _p(self.wpack), _p(self.bias_all), st), "mp_tf_bg_pack")
+        return self
+
+
+def fused_bg_state(net, lins=None):
+    key = "_mp_tfuse_shared" if lins is not None else "_mp_tfuse"
+    st = net.__dict__.get(key)
+    if st is None or (lins is not None and st.lins is not lins):
+        st = net.__dict__[key] = FusedBGState(net, lins)
+    return st
+
+
+class ImplicitTrainFusedBG:
+    """ImplicitTrain(fwd=False)'s arithmetic for the background ImplicitNet on the layer-fused kernels (csrc/tfuse.hip
+    mp_tf_bg_fwd / mp_tf_bg_bwd): the nine layers in one launch each way, the weight gradients as one contraction per layer.
+    x [P][4] (the inverted-sphere points), code (32,) the frame's latent row.  self.sdf [P+1], self.feat [P+1][256]."""
+
+    def __init__(self, net, x, code, lins=None):
+        L, st = hip.lib(), hip.stream()
+        assert fused_bg_supported(net)
+        self.net, self.x, self.cond = net, x, code
+        self.P = P = x.shape[0]
+        self.E = E = net.embed_dim                       # 84
+        dev = x.device
+        self.fs = fs = fused_bg_state(net, lins).refresh(code)
+        self.lins = fs.lins
+        arena = C.c_longlong(0)
+        _chk(L.mp_tf_bg_sizes(P, C.byref(arena), None), "mp_tf_bg_sizes")
+        self.arena = A = _big_empty(int(arena.value), dev, grain=1 << 22)
+        R1 = 256 * (P + 1)
+        self.o_dZ = lambda l: l * R1
+        self.o_X = lambda l: (7 + l) * R1
+        self.o_IN = 16 * R1
+        _chk(L.mp_tr_pe(_p(x), 4, P, net.multires, 0, C.c_float(1.0), off(A, self.o_IN), E, 0, st), "mp_tr_pe")
+        self.feat = torch.empty(P + 1, 256, dtype=F32, device=dev)
+        self.sdf = torch.empty(P + 1, dtype=F32, device=dev)
+        _chk(L.mp_tf_bg_fwd(_p(fs.wpack), _p(fs.bias_all), _p(A), P, _p(self.feat), _p(self.sdf), st), "mp_tf_bg_fwd")
+        # the skip connection re-injects the Fourier features into layer 4's input (times 1/sqrt 2): columns 172.. of X_4
+        _chk(L.mp_tr_copy_cols(off(A, self.o_IN), E, 0, off(A, self.o_X(4)), 256, 256 - E, P, E, C.c_float(1.0 / math.sqrt(2.0)), 0,
+                               st), "mp_tr_copy_cols")
+
+    def backward(self, dfeat, dsdf):
+        """dfeat [P][256], dsdf [P] -> dW / db of every layer; returns d code (the hoisted conditioning's adjoint)"""
+        L, st = hip.lib(), hip.stream()
+        net, P, E, lins, fs, A = self.net, self.P, self.E, self.lins, self.fs, self.arena
+        lw8 = lins[8]
+        _chk(L.mp_tf_bg_bwd(_p(fs.wpack), _p(lw8.W), _p(A), P, _p(dfeat), _p(dsdf), _p(lw8.dW), _p(lw8.db), st), "mp_tf_bg_bwd")
+        lw0 = lins[0]
+        gemm_tn(off(A, self.o_dZ(0)), 256, off(A, self.o_IN), E, _p(lw0.dW), lw0.in_dim, 256, E, P, _p(lw0.db), P)
+        groups = []
+        for l in range(1, 8):
+            lw = lins[l]                                # (layer 3: 172 rows contracted as 256, see LinP)
+            rows = lw.dW_full.shape[0]
+            groups.append(tn_group(off(A, self.o_dZ(l)), 256, off(A, self.o_X(l)), 256, _p(lw.dW_full), lw.in_dim, rows, lw.in_dim, P,
+                                   _p(lw.db_full), P))
+        groups.append(tn_group(_p(dfeat), 256, off(A, self.o_X(8)), 256, off(lw8.dW, 256), 256, 256, 256, P, off(lw8.db, 1), P))
+        ImplicitTrainFused._launch(groups)
+        _chk(L.mp_tr_hoist_bwd(_p(lw0.db), 256, lw0.in_dim, E, net.cond_dim, _p(self.cond), _p(lw0.dW), st), "mp_tr_hoist_bwd")
+        dcode = _zeros(net.cond_dim, device=dfeat.device)
+        gemm_tn(_p(lw0.db), 1, off(lw0.W, E), lw0.in_dim, _p(dcode), net.cond_dim, 1, net.cond_dim, 256)
+        return dcode
+
+    def params(self):
+        return [p for lw in self.lins for p in lw.params()]
+
+    def param_grads(self):
+        return [g for lw in self.lins for g in lw.param_grads()]
+
+
 class RenderTrain:
     """RenderingNet (networks.py:263-312): mode 'pose_no_view' (inputs XA = [x_c, n] (6), feat) or 'nerf_frame_encoding'
     (XA = PE_4(view) (27), feat).  feat is read in place from the SDF net's last layer (ld 257, column 1..)."""
@@ -917,6 +1022,8 @@ N_EIKONAL = 512          # multiply.py:324
 ARENA_BUDGET_BYTES = int(__import__("os").environ.get("MP_TRAIN_ARENA_GB", "24")) << 30   # fixed-size SDF stashes of one iteration, all persons
 # 'fused' (ImplicitTrainFused: layer-fused kernels, default) | 'reverse' (ImplicitTrainRev, layer by layer) | 'forward'
 SDF_TRAIN_MODE = __import__("os").environ.get("MP_SDF_TRAIN_MODE", "fused")
+# background ImplicitNet: 'fused' (ImplicitTrainFusedBG, default) | 'layerwise' (ImplicitTrain: the cross-check)
+BG_TRAIN_MODE = __import__("os").environ.get("MP_BG_TRAIN_MODE", "fused")
 
 
 def _table(ts, dev):
@@ -1139,15 +1246,25 @@ class TrainGraph:
                 cam = pose.reshape(4, 4)[:3, 3].contiguous()
                 _chk(L.mp_tr_bg_points(_p(bdirs), _p(cam), _p(zbg), Rb, NB, C.c_float(m.sdf_bounding_sphere), _p(pts), st),
                      "mp_tr_bg_points")
-                bit = ImplicitTrain(m.bg_implicit_network, pts, code, fwd=False, lins=self.ts.lins[id(m.bg_implicit_network)])
+                bgnet = m.bg_implicit_network
+                fused_bg = BG_TRAIN_MODE == "fused" and TRAIN_PRECISION == "bf16x3" and fused_bg_supported(bgnet)
+                if fused_bg:       # the nine layers in one launch (csrc/tfuse.hip k_tf_bg_fwd)
+                    bit = ImplicitTrainFusedBG(bgnet, pts, code, lins=self.ts.lins[id(bgnet)])
+                else:
+                    bit = ImplicitTrain(bgnet, pts, code, fwd=False, lins=self.ts.lins[id(bgnet)])
                 drep = bdirs[:, None, :].expand(Rb, NB, 3).reshape(-1, 3).contiguous()
                 XAb = torch.empty(Rb * NB, 27, **f32)
                 _chk(L.mp_tr_pe(_p(drep), 3, Rb * NB, 4, 0, C.c_float(1.0), _p(XAb), 27, 0, st), "mp_tr_pe")
-                brt = RenderTrain(m.bg_rendering_network, XAb, off(bit.out, 1), 257, Rb * NB, code,
-                                  lins=self.ts.lins[id(m.bg_rendering_network)])
-                sdfb = torch.empty(Rb * NB, **f32)
-                _chk(L.mp_tr_copy_cols(_p(bit.out), 257, 0, _p(sdfb), 1, 0, Rb * NB, 1, C.c_float(1.0), 0, st),
-                     "mp_tr_copy_cols")
+                if fused_bg:
+                    brt = RenderTrain(m.bg_rendering_network, XAb, _p(bit.feat), 256, Rb * NB, code,
+                                      lins=self.ts.lins[id(m.bg_rendering_network)])
+                    sdfb = bit.sdf[:Rb * NB]
+                else:
+                    brt = RenderTrain(m.bg_rendering_network, XAb, off(bit.out, 1), 257, Rb * NB, code,
+                                      lins=self.ts.lins[id(m.bg_rendering_network)])
+                    sdfb = torch.empty(Rb * NB, **f32)
+                    _chk(L.mp_tr_copy_cols(_p(bit.out), 257, 0, _p(sdfb), 1, 0, Rb * NB, 1, C.c_float(1.0), 0, st),
+                         "mp_tr_copy_cols")
                 bg_slice = torch.empty(Rb, 3, **f32)
                 _chk(L.mp_tr_bg_comp_fwd(_p(sdfb), _p(brt.rgb), _p(zbg), Rb, NB, _p(bg_slice), st), "mp_tr_bg_comp_fwd")
                 bg_rgb[s0:s1] = bg_slice
@@ -1281,11 +1398,16 @@ class TrainGraph:
             dsdfb = torch.empty(rows, **f32); drgbb = torch.empty(rows, 3, **f32)
             _chk(L.mp_tr_bg_comp_bwd(_p(b["sdfb"]), _p(brt.rgb), _p(b["zbg"]), Rb, NB, _p(d_bg_slice), _p(dsdfb), _p(drgbb),
                                      st), "mp_tr_bg_comp_bwd")
-            dZ8b = torch.zeros(rows, 257, **f32)
             dXAb = torch.empty(rows, 27, **f32)
-            dcode = brt.backward(drgbb, dXAb, off(dZ8b, 1), 257)
-            _chk(L.mp_tr_copy_cols(_p(dsdfb), 1, 0, _p(dZ8b), 257, 0, rows, 1, C.c_float(1.0), 0, st), "mp_tr_copy_cols")
-            dcode = dcode + bit.backward(dZ8b)
+            if isinstance(bit, ImplicitTrainFusedBG):
+                dfeatb = torch.empty(rows, 256, **f32)         # written (not accumulated) by the colour net
+                dcode = brt.backward(drgbb, dXAb, _p(dfeatb), 256, feat_accumulate=False)
+                dcode = dcode + bit.backward(dfeatb, dsdfb)
+            else:
+                dZ8b = torch.zeros(rows, 257, **f32)
+                dcode = brt.backward(drgbb, dXAb, off(dZ8b, 1), 257)
+                _chk(L.mp_tr_copy_cols(_p(dsdfb), 1, 0, _p(dZ8b), 257, 0, rows, 1, C.c_float(1.0), 0, st), "mp_tr_copy_cols")
+                dcode = dcode + bit.backward(dZ8b)
             self.ts.finish_group("bg")
             collect(bit); collect(brt)
             w = m.frame_latent_encoder.weight

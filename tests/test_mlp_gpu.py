@@ -49,6 +49,43 @@ def test_implicit_full_and_sdf(nets_gpu):
     assert report("bg implicit feat", got[:, 1:], want[:, 1:]) < TOL.MLP["bg_feat"]
 
 
+def test_precise_sdf_value_kernel(nets_gpu):
+    """mp_tf_sdf_val (csrc/tfuse.hip): the sampler's queries at the training path's arithmetic -- split-bfloat16 products, fp32
+    activations -- through mp_mlp_sdf's worklist interface: against the fp32 oracle (two orders of magnitude below the f16 kernel's
+    1e-3) and, for the worklist / device-count handling, untouched entries stay untouched"""
+    from multiply_amd import hip, train as T
+    m, sd = nets_gpu
+    rng = np.random.RandomState(11)
+    n = 5000                                                     # not a multiple of the 128-point tile
+    x = torch.tensor(rng.uniform(-0.9, 0.9, (n, 3)), dtype=torch.float32)
+    cond = torch.tensor(rng.normal(0, 0.1, 69), dtype=torch.float32)
+    want = O.implicit_forward(sd, "foreground_implicit_network_list.1.", x, cond, multires=6)[:, 0]
+    net = m.foreground_implicit_network_list[1]
+    fs = T.fused_sdf_state(net).refresh(cond.cuda())
+    L = hip.lib()
+    xd = x.cuda()
+    out = torch.full((n,), -7.0, device="cuda")
+    hip.check(L.mp_tf_sdf_val(hip.ptr(fs.wpack), hip.ptr(fs.bias_all), hip.ptr(xd), None, None, n, hip.ptr(out), hip.stream()), "val")
+    torch.cuda.synchronize()
+    assert report("precise sdf kernel (all points)", out, want) < 2e-5
+    f16 = hip.implicit_sdf(net, xd, cond.cuda())
+    assert report("f16 sdf kernel, same points", f16, want) > 10 * float((out.cpu() - want).abs().max())
+    # worklist of every third point in shuffled order, device-side count smaller than the launch's upper bound
+    ids = torch.tensor(rng.permutation(np.arange(0, n, 3)), dtype=torch.int32).cuda()
+    k = 1000
+    work = torch.cat([ids[:k], torch.zeros(300, dtype=torch.int32, device="cuda")])
+    cnt = torch.tensor([k], dtype=torch.int32, device="cuda")
+    out2 = torch.full((n,), -7.0, device="cuda")
+    hip.check(L.mp_tf_sdf_val(hip.ptr(fs.wpack), hip.ptr(fs.bias_all), hip.ptr(xd), hip.ptr(work), hip.ptr(cnt), k + 300, hip.ptr(out2),
+                              hip.stream()), "val")
+    torch.cuda.synchronize()
+    sel = ids[:k].long()
+    assert torch.equal(out2[sel], out[sel])
+    rest = torch.ones(n, dtype=torch.bool, device="cuda")
+    rest[sel] = False
+    assert bool((out2[rest] == -7.0).all())
+
+
 def test_rendering_net_standalone_forward(nets_gpu):
     """RenderingNet.forward (networks.py:263-312, mode pose_no_view) called like the reference does -- points, normals, view
     dirs, body pose, fp32 feature vectors -- through the fragment packer + mp_mlp_color"""

@@ -285,6 +285,48 @@ def test_background_branch_backward():
     assert max(errs.values()) < 1e-2, errs
 
 
+@pytest.mark.parametrize("P", [3000, 129, 5])
+def test_fused_background_kernels_against_autograd(P, monkeypatch):
+    """The layer-fused kernels of the background ImplicitNet (csrc/tfuse.hip k_tf_bg_fwd / k_tf_bg_bwd: the 84 Fourier features
+    in the register operand, the skip connection patched into layer 4's operand, value sweep only; split-bf16 products) against
+    torch autograd on the oracle's formula and against the layer-wise path: outputs, every parameter gradient, the frame code's
+    adjoint.  Weights perturbed so that hidden units sit in the softplus transition."""
+    from multiply_amd import train as T
+    monkeypatch.setattr(T, "TRAIN_PRECISION", "bf16x3")       # the fused kernels' arithmetic (their weight gradients included)
+    m, _ = seeded_networks(1, 0)
+    m = m.cuda()
+    net = m.bg_implicit_network
+    torch.manual_seed(13)
+    with torch.no_grad():
+        for prm in net.parameters():
+            prm.add_(torch.randn_like(prm) * 0.05 * prm.abs().mean().clamp_min(1e-2))
+    assert T.fused_bg_supported(net)
+    x = torch.cat([torch.nn.functional.normalize(torch.randn(P, 3, device="cuda"), dim=1), torch.rand(P, 1, device="cuda") / 3], 1).contiguous()
+    code = torch.randn(32, device="cuda") * 0.3
+    fus = T.ImplicitTrainFusedBG(net, x, code)
+    ref = T.ImplicitTrain(net, x, code, fwd=False)
+    sd = {k: v for k, v in m.named_parameters()}
+    codeg = code.clone().requires_grad_(True)
+    out = O.implicit_forward(sd, "bg_implicit_network.", x, codeg, multires=10)
+    got_out = torch.cat([fus.sdf[:P, None], fus.feat[:P]], 1)
+    assert rel("fused bg sdf+feat vs autograd", got_out, out.detach()) < 3e-5
+    assert rel("fused bg sdf+feat vs layer-wise", got_out, ref.out) < 3e-5
+    a_out = torch.randn(P, 257, device="cuda")
+    names = [n for n, p in m.named_parameters() if n.startswith("bg_implicit_network.")]
+    plist = [p for n, p in m.named_parameters() if n.startswith("bg_implicit_network.")]
+    want = torch.autograd.grad((out * a_out).sum(), plist + [codeg])
+    dc_f = fus.backward(a_out[:, 1:].contiguous(), a_out[:, 0].contiguous())
+    dc_r = ref.backward(a_out.clone())
+    assert rel("d frame code, fused vs layer-wise", dc_f, dc_r) < 2e-4
+    assert rel("d frame code vs autograd", dc_f, want[-1]) < 5e-4
+    got = dict(zip([id(p) for p in fus.params()], fus.param_grads()))
+    gref = dict(zip([id(p) for p in ref.params()], ref.param_grads()))
+    assert len(got) == len(names)
+    for n, p, ww in zip(names, plist, want):
+        assert rel(n + " vs layer-wise", got[id(p)].reshape(ww.shape), gref[id(p)].reshape(ww.shape)) < 2e-4, n
+        assert rel(n + " vs autograd", got[id(p)].reshape(ww.shape), ww) < 5e-4, n
+
+
 def test_composite_backward():
     """mp_composite / mp_tr_composite_bwd vs the oracle's packed compositing under autograd (two persons, rays hit by
     both, one or none; includes the exclusive background transmittance and d beta)."""

@@ -34,6 +34,11 @@ EVAL = {                                   # eval-mode Multiply.forward outputs,
     "normal_values": Dist(8e-4, p999=0.04, **_GRAZE),  # mean 3.2e-4; 3 of 1024 rays above 1e-2, worst 3.9e-2; 16k: p99.9 1.2e-2
     "bg_rgb": (1.5e-4, 2.5e-5),             # 2.7e-5, 5.4e-6
 }
+# eval outputs with the sampler's network queries at near-fp32 precision (Multiply.sampler_sdf_mode = 'bf16x3'; shading still f16):
+# plain max bounds, <= 5x the largest error measured on the 4 096-ray headline slice (profiles/r05_sampler_precision.txt:
+# acc 9.0e-4, normals 1.2e-3, rgb 3.0e-5, depths 5.0e-4) -- the f16 sampler's grazing-ray tail (0.11) does not exist here
+EVAL_PRECISE = {"rgb_values": 1.5e-4, "acc_map": 4.5e-3, "acc_person_list": 4.5e-3, "normal_values": 6e-3, "fg_rgb_values": 4.5e-3}
+Z_VALS_PRECISE = (2.5e-3, 2.5e-5)
 Z_VALS = (5e-2, 3e-4)                       # sampler depths (inverse CDF of f16 sdf queries); measured 1.4e-2, 6.7e-5
 TRAIN_Z_VALS = (0.15, 1e-3)                 # training-mode depths (stratified / random draws); measured 3e-2, 2e-4
 MLP = {                                     # the fused MLP kernels on random points vs the fp32 oracle: max |err|

@@ -5,7 +5,8 @@ reference's `dist > 0.1 => sdf = 4` discontinuity (multiply.py:142-143) and a gr
 tool renders the always-on 4 096-ray slice of the headline frame (tests/test_headline_slow_gpu.py: 8 convergence groups spread
 over the 512x512 two-person frame, N_samples 128) once per sampler arithmetic --
     f16     the fused kernel k_mlp_sdf (product)
-    bf16x3  the same worklists through the training path's split-bfloat16 GEMMs, fp32 activations (Multiply.sampler_sdf_mode)
+    bf16x3  the same worklists through mp_tf_sdf_val: the value sweep of the training path's layer-fused kernel (split-bfloat16
+            products, fp32 activations; Multiply.sampler_sdf_mode); `bf16x3-layerwise`: the same arithmetic layer by layer
 -- and compares depths and pixels with the fp32 oracle on the same hit sets.  Shading stays on the product's f16 kernels in
 both runs, so the difference between the rows is the sampler's arithmetic alone.
     python tools/sampler_precision.py [n_groups]  ->  gpurun_out/sampler_precision.txt
@@ -50,7 +51,7 @@ def main():
              f"N_samples 128), fp32 oracle {t_or:.0f} s; shading on the product's f16 kernels in every row",
              f"{'sampler sdf':10s} {'z max':>9s} {'z mean':>9s} | {'acc max':>9s} {'acc>1e-2':>8s} {'acc>3e-3':>8s} | {'nrm max':>9s} {'nrm>1e-2':>8s} | "
              f"{'rgb max':>9s} | sampler-sdf ms (these rays)"]
-    for mode in ("f16", "bf16x3"):
+    for mode in ("f16", "bf16x3", "bf16x3-layerwise"):
         model.sampler_sdf_mode = mode
         zerr, err = [], {k: [] for k in keys}
         model.profile = True
@@ -68,12 +69,12 @@ def main():
         model.profile = False
         z = torch.cat(zerr)
         e = {k: torch.cat(v) for k, v in err.items()}
-        lines.append(f"{mode:10s} {float(z.max()):9.2e} {float(z.mean()):9.2e} | {float(e['acc_map'].max()):9.2e} "
+        lines.append(f"{mode[:10]:10s} {float(z.max()):9.2e} {float(z.mean()):9.2e} | {float(e['acc_map'].max()):9.2e} "
                      f"{int((e['acc_map'] > 1e-2).sum()):8d} {int((e['acc_map'] > 3e-3).sum()):8d} | {float(e['normal_values'].max()):9.2e} "
                      f"{int((e['normal_values'] > 1e-2).sum()):8d} | {float(e['rgb_values'].max()):9.2e} | {ph.get('sampler_mlp_sdf', (0, 0.0))[1]:.2f}")
     model.sampler_sdf_mode = "f16"
-    lines.append("(the bf16x3 row's time is the layer-wise measurement path incl. a host read per iteration, not a candidate kernel's: a "
-                 "fused split-bf16 value kernel costs ~3 MFMAs per product + fp32 activations, i.e. >= 4x the f16 kernel's time)")
+    lines.append("(third row: bf16x3-layerwise = the same arithmetic through the layer-wise GEMMs with a host read per iteration -- the "
+                 "independent implementation the fused kernel of row 2 is checked against)")
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/sampler_precision.txt", "w") as f:
         f.write("\n".join(lines) + "\n")
