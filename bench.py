@@ -415,6 +415,9 @@ def main():
                          "sharded, one all_to_all (configs[3] on <= P ranks); hybrid: person teams x ray shards (configs[3] on 8 ranks)")
     ap.add_argument("--person-slots", type=int, default=0, help="--mode hybrid: ranks per team (default: min(persons, world))")
     ap.add_argument("--chunk-rays", type=int, default=16384, help="--mode person / hybrid: rays per exchange (whole convergence groups)")
+    ap.add_argument("--sampler-sdf", choices=("f16", "bf16x3"), default=os.environ.get("MP_SAMPLER_SDF", "f16"),
+                    help="arithmetic of the sampler's network queries: f16 (fused half-precision kernel, default) | bf16x3 (near-fp32: "
+                         "mp_tf_sdf_val; depths within 1e-3 of the fp32 reference instead of 2e-2, ~5 ms per frame)")
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the frame-per-rank weak-scaling leg")
     ap.add_argument("--breakdown", action="store_true", help="print per-phase GPU times to stderr")
     args = ap.parse_args()
@@ -469,6 +472,7 @@ def main():
     # strong scaling: every rank holds the SAME frame (seed 0) and renders its round-robin share of the convergence groups
     model, inp, tables, sc = build_model(args.samples, seed=0, H=args.res, W=args.res, P=args.persons, tile=args.tile)
     model.convergence_group = GROUP
+    model.sampler_sdf_mode = args.sampler_sdf
     R = inp["uv"].shape[1]
     exchange_evs, frame_fn = None, None
     if dist and args.mode != "ray":
@@ -659,7 +663,7 @@ def main():
                                    f"person), N_samples_eval={max(128, args.samples)}, 32 background samples, "
                                    f"convergence groups of 512 rays (reference pixel_per_batch), geometric-init weights",
                        "rays_per_step": R, "frames": args.steps,
-                       "persons": args.persons,
+                       "persons": args.persons, "sampler_sdf": args.sampler_sdf,
                        "parallelism": ("single GPU" if not dist else
                                        f"ray-sharded dp{world}: one frame per step, convergence groups dealt on a diagonal lattice, "
                                        f"all_gather of the image on every rank" if args.mode == "ray" else

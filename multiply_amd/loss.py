@@ -37,9 +37,12 @@ class _FusedTerms(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rgb, acc, accp, gth, rgb_gt, sam, in_mask, w):
         from . import hip
+        ctx.shapes = (rgb.shape, acc.shape, accp.shape, gth.shape)
         f = lambda t: t.detach().contiguous().float()
         rgb, acc, accp, gth, rgb_gt = f(rgb).reshape(-1, 3), f(acc).reshape(-1), f(accp), f(gth).reshape(-1, 3), f(rgb_gt).reshape(-1, 3)
-        R, P, N = rgb.shape[0], accp.reshape(R, -1).shape[1], gth.shape[0]
+        R, N = rgb.shape[0], gth.shape[0]
+        accp = accp.reshape(R, -1)
+        P = accp.shape[1]
         sam = None if sam is None else f(sam).reshape(R, P)
         in_mask = None if in_mask is None else in_mask.detach().reshape(-1).to(torch.uint8).contiguous()
         buf = torch.empty(8 + 4 * R + R * P + 3 * N, dtype=torch.float32, device=rgb.device)      # terms + the four gradients
@@ -56,7 +59,7 @@ class _FusedTerms(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, _g_terms):
         scaled = torch._foreach_mul(list(ctx.grads), g_total.reshape(()))       # one launch for the four gradients
-        return scaled[0], scaled[1], scaled[2], scaled[3], None, None, None, None
+        return tuple(g.reshape(sh) for g, sh in zip(scaled, ctx.shapes)) + (None, None, None, None)
 
 
 def _get(opt, key, default):

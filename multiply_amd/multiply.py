@@ -43,6 +43,14 @@ class Multiply(nn.Module):
         self.using_nerfacc = True
         self.smpl_surface_weight = opt.loss.get("smpl_surface_weight", 0)
         self.zero_pose_weight = opt.loss.get("zero_pose_weight", 0)
+        self.smpl_vertex_part = None
+        if self.smpl_surface_weight > 0:      # multiply.py:112-113 (the reference's asset ./outputs/smpl_vert_segmentation.json)
+            import json
+            seg = os.path.abspath(opt.get("smpl_vert_segmentation_path", "./outputs/smpl_vert_segmentation.json"))
+            if os.path.exists(seg):
+                with open(seg) as f:
+                    self.smpl_vertex_part = json.load(f)
+            # (absent: train.surface_sampling_weights raises at the first training forward unless model.smpl_vertex_part is assigned)
         self.use_person_encoder = opt.get("use_person_encoder", False)
         if self.use_person_encoder:
             raise NotImplementedError("use_person_encoder (shared triplane networks) is outside the hot-path scope")

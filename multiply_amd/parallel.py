@@ -128,6 +128,8 @@ class GradientAllReduce:
     def __call__(self):
         """gradients -> flat buffer (one concat) -> all_reduce -> averaged gradients written back (one foreach copy)"""
         world = dist.get_world_size() if dist.is_initialized() else 1
+        if world == 1:          # nothing to average: no flat copy either (it cost ~40 zero fills of never-touched gradients + a 9 MB
+            return self.flat    # concat per iteration in the single-GPU bench line)
         for p in self.params:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)

@@ -207,14 +207,21 @@ class ImplicitTrain:
             if TRAIN_PRECISION == "bf16x3" and l > 0 and out == 256 and kin == 256 and Xl.shape[1] == 256:
                 groups.append(tn_group(_p(dZ), out, _p(Xl), 256, _p(lw.dW), lw.in_dim, out, kin, rows, _p(lw.db), P))
                 held.append(dZ)
+            elif l == 0:
+                # layer 0's bias gradient of THIS evaluation on its own (db0), then added to the accumulator: the hoisted
+                # conditioning's adjoint below must not see what other evaluations of the same network left in lw.db
+                # (the zero-pose regulariser evaluates a network under two conditionings in one sweep)
+                db0 = _zeros(out, device=dZ.device)
+                gemm_tn(_p(dZ), out, _p(Xl), Xl.shape[1], _p(lw.dW), lw.in_dim, out, kin, rows, _p(db0), P)
+                lw.db.add_(db0)
             else:
                 gemm_tn(_p(dZ), out, _p(Xl), Xl.shape[1], _p(lw.dW), lw.in_dim, out, kin, rows, _p(lw.db), P)
             if l == 0:
                 # hoisted conditioning: dW0[:, E:] += db (x) cond ; d cond = W0[:, E:]^T db
-                _chk(L.mp_tr_hoist_bwd(_p(lw.db), out, lw.in_dim, E, net.cond_dim, _p(self.cond), _p(lw.dW), hip.stream()),
+                _chk(L.mp_tr_hoist_bwd(_p(db0), out, lw.in_dim, E, net.cond_dim, _p(self.cond), _p(lw.dW), hip.stream()),
                      "mp_tr_hoist_bwd")
                 dcond = _zeros(net.cond_dim, device=dZ.device)
-                gemm_tn(_p(lw.db), 1, off(lw.W, E), lw.in_dim, _p(dcond), net.cond_dim, 1, net.cond_dim, out)
+                gemm_tn(_p(db0), 1, off(lw.W, E), lw.in_dim, _p(dcond), net.cond_dim, 1, net.cond_dim, out)
                 if want_dx:
                     gemm_nt(_p(dZ), out, _p(lw.WT), out, _p(dIN), E, rows, E, out, accumulate=True)
                     self.dx = torch.zeros(P, net.d_in, dtype=F32, device=dZ.device)
@@ -370,11 +377,16 @@ class ImplicitTrainRev:
             lw, Xl = lins[l], self.X[l]
             out = lw.out_dim
             kin = E if l == 0 else lw.in_dim
-            gemm_tn(_p(dZ), out, _p(Xl), Xl.shape[1], _p(lw.dW), lw.in_dim, out, kin, P, _p(lw.db), P)
+            if l == 0:           # (this evaluation's own bias gradient: see ImplicitTrain.backward)
+                db0 = _zeros(out, device=dZ.device)
+                gemm_tn(_p(dZ), out, _p(Xl), Xl.shape[1], _p(lw.dW), lw.in_dim, out, kin, P, _p(db0), P)
+                lw.db.add_(db0)
+            else:
+                gemm_tn(_p(dZ), out, _p(Xl), Xl.shape[1], _p(lw.dW), lw.in_dim, out, kin, P, _p(lw.db), P)
             if l == 0:
-                _chk(L.mp_tr_hoist_bwd(_p(lw.db), out, lw.in_dim, E, net.cond_dim, _p(self.cond), _p(lw.dW), st), "mp_tr_hoist_bwd")
+                _chk(L.mp_tr_hoist_bwd(_p(db0), out, lw.in_dim, E, net.cond_dim, _p(self.cond), _p(lw.dW), st), "mp_tr_hoist_bwd")
                 dcond = torch.zeros(net.cond_dim, **f32)
-                gemm_tn(_p(lw.db), 1, off(lw.W, E), lw.in_dim, _p(dcond), net.cond_dim, 1, net.cond_dim, out)
+                gemm_tn(_p(db0), 1, off(lw.W, E), lw.in_dim, _p(dcond), net.cond_dim, 1, net.cond_dim, out)
                 if want_dx:
                     gemm_nt(_p(dZ), out, _p(lw.WT), out, _p(dIN), E, P, E, out, accumulate=True)
                     _chk(L.mp_tr_pe_bwd(_p(self.x), 3, P, net.multires, 0, _p(dIN), E, _p(self.dx), st), "mp_tr_pe_bwd")
@@ -694,7 +706,9 @@ class ImplicitTrainFused(ImplicitTrainRev):
         _chk(L.mp_tr_copy_cols(dG, E, 0, off(A, self.o_dT(4)), 256, 256 - E, P, E, C.c_float(r2), 0, st), "mp_tr_copy_cols")
         # weight gradients  dW_l += dZ_l^T X_l (value sweep; bias gradient = its column sums) + V_l^T dT_l (gradient sweep)
         lw0 = lins[0]
-        gemm_tn(off(A, self.o_dZ(0)), 256, off(A, self.o_IN), E, _p(lw0.dW), lw0.in_dim, 256, E, P, _p(lw0.db), P)
+        db0 = _zeros(256, device=dev)        # layer 0's bias gradient of THIS evaluation (see ImplicitTrain.backward)
+        gemm_tn(off(A, self.o_dZ(0)), 256, off(A, self.o_IN), E, _p(lw0.dW), lw0.in_dim, 256, E, P, _p(db0), P)
+        lw0.db.add_(db0)
         gemm_tn(off(A, self.o_V(0)), 256, dG, E, _p(lw0.dW), lw0.in_dim, 256, E, P)
         groups = tn_groups if tn_groups is not None else []
         for l in range(1, 8):
@@ -706,9 +720,9 @@ class ImplicitTrainFused(ImplicitTrainRev):
         groups.append(tn_group(_p(dfeat), 256, off(A, self.o_X(8)), 256, off(lw8.dW, 256), 256, 256, 256, P, off(lw8.db, 1), P))
         if tn_groups is None:
             self._launch(groups)
-        _chk(L.mp_tr_hoist_bwd(_p(lw0.db), 256, lw0.in_dim, E, net.cond_dim, _p(self.cond), _p(lw0.dW), st), "mp_tr_hoist_bwd")
+        _chk(L.mp_tr_hoist_bwd(_p(db0), 256, lw0.in_dim, E, net.cond_dim, _p(self.cond), _p(lw0.dW), st), "mp_tr_hoist_bwd")
         dcond = _zeros(net.cond_dim, device=dev)
-        gemm_tn(_p(lw0.db), 1, off(lw0.W, E), lw0.in_dim, _p(dcond), net.cond_dim, 1, net.cond_dim, 256)
+        gemm_tn(_p(db0), 1, off(lw0.W, E), lw0.in_dim, _p(dcond), net.cond_dim, 1, net.cond_dim, 256)
         self.dx = None
         return dcond
 
@@ -1026,8 +1040,28 @@ SDF_TRAIN_MODE = __import__("os").environ.get("MP_SDF_TRAIN_MODE", "fused")
 BG_TRAIN_MODE = __import__("os").environ.get("MP_BG_TRAIN_MODE", "fused")
 
 
+ZERO_POSE_SAMPLES = 2000          # multiply.py:363
+SMPL_SURFACE_THRESHOLD = 0.02     # multiply.py:358
+SURFACE_EXCLUDED_PARTS = ("head", "rightHand", "leftHand", "rightFoot", "leftFoot", "leftHandIndex1", "rightHandIndex1")   # multiply.py:340-343
+
+
 def _table(ts, dev):
     return hip.device_ints([t.data_ptr() for t in ts], dev)      # (no host wait: hip._PinnedInts)
+
+
+def surface_sampling_weights(model, n_verts, dev):
+    """multiply.py:339-345: SMPL vertices the surface regulariser samples from -- all but head, hands and feet (cached)"""
+    w = model.__dict__.get("_mp_surface_weights")
+    if w is None or w.shape[0] != n_verts or w.device != torch.device(dev):
+        part = getattr(model, "smpl_vertex_part", None)
+        if part is None:
+            raise FileNotFoundError("smpl_surface_weight > 0 needs the SMPL vertex segmentation (the reference reads "
+                                    "./outputs/smpl_vert_segmentation.json, multiply.py:113, an asset it does not ship): set "
+                                    "opt.smpl_vert_segmentation_path or assign model.smpl_vertex_part = {part name: [vertex ids]}")
+        w = torch.ones(n_verts)
+        w[[i for k in SURFACE_EXCLUDED_PARTS for i in part[k]]] = 0
+        w = model.__dict__["_mp_surface_weights"] = w.to(dev)
+    return w
 
 
 def _random_prefixes(sizes, k, dev, gen):
@@ -1063,6 +1097,15 @@ def make_draws(model, cx, gen=None):
             t_rand=torch.rand(Rp, NE, **kw), u_final=torch.rand(Rp, NS, **kw), extra_idx=extra[n].contiguous(),
             eik_idx=eik[n], eik_noise=torch.randn(N_EIKONAL, 3, **kw))
     draws["bg_rand"] = torch.rand(cx["R"], rs.N_samples_inverse_sphere, **kw)
+    # the two regularisers of multiply.py:336-394 (weight 0 in the shipped configs): their vertex draws
+    if model.smpl_surface_weight > 0:
+        for n, p in enumerate(persons):                               # idx_weight.multinomial(num_pixels, replacement=True)
+            draws["person"][p]["surf_idx"] = torch.multinomial(surface_sampling_weights(model, nvs[n], dev), cx["R"],
+                                                               replacement=True, generator=gen)
+    if model.zero_pose_weight > 0:
+        nv_all = [v.shape[1] for v in model.mesh_v_cano_list]
+        zp = _random_prefixes(nv_all * len(persons), min(ZERO_POSE_SAMPLES, min(nv_all)), dev, gen).reshape(len(persons), len(nv_all), -1)
+        draws["zp_idx"] = {(q, p): zp[n, p] for n, q in enumerate(persons) for p in range(len(nv_all))}
     return draws
 
 
@@ -1168,6 +1211,9 @@ class TrainGraph:
                               nn_cano=nn_cano)
             z_l.append(zfinal); sdf_l.append(sdf); rgb_l.append(rt.rgb); nrm_l.append(nrm); inv_l.append(pp["inv_index"])
 
+        self.reg_items, self.reg_losses = [], (None, None)
+        if m.smpl_surface_weight > 0 or m.zero_pose_weight > 0:
+            self._regularisers_forward()
         all_persons = list(persons)
         self.remote = {}
         s0, s1 = 0, R
@@ -1235,12 +1281,20 @@ class TrainGraph:
             NB = rs.N_samples_inverse_sphere
             Rb = s1 - s0                                              # this rank's rays of the background branch
             bdirs = dirs[s0:s1].contiguous()
-            t = torch.linspace(0.0, 1.0, NB, device=dev)[None].expand(Rb, NB)
-            mids = 0.5 * (t[:, 1:] + t[:, :-1])
-            upper = torch.cat([mids, t[:, -1:]], -1); lower = torch.cat([t[:, :1], mids], -1)
-            zb = lower + (upper - lower) * self.draws["bg_rand"][s0:s1]
-            zbg = torch.flip(zb * (1.0 / rs.scene_bounding_sphere), dims=[-1]).contiguous()
-            bg_rgb = torch.zeros(R, 3, **f32)
+            # stratified depths (ray_sampler.py:32-40): the bin edges are constants of (NB, bounding sphere) -- built once per model,
+            # already flipped and scaled, so that the iteration pays one fused multiply-add instead of ten small launches
+            strata = m.__dict__.get("_mp_bg_strata")
+            if strata is None or strata[0] != (NB, float(rs.scene_bounding_sphere), str(dev)):
+                t = torch.linspace(0.0, 1.0, NB, device=dev)[None]
+                mids = 0.5 * (t[:, 1:] + t[:, :-1])
+                upper = torch.cat([mids, t[:, -1:]], -1); lower = torch.cat([t[:, :1], mids], -1)
+                c = 1.0 / rs.scene_bounding_sphere
+                strata = m.__dict__["_mp_bg_strata"] = ((NB, float(rs.scene_bounding_sphere), str(dev)),
+                                                        torch.flip(lower * c, dims=[-1]).contiguous(),
+                                                        torch.flip((upper - lower) * c, dims=[-1]).contiguous())
+            # zbg = flip((lower + (upper - lower) u) / r) = flip(lower / r) + flip((upper - lower) / r) flip(u)
+            zbg = torch.addcmul(strata[1], strata[2], torch.flip(self.draws["bg_rand"][s0:s1], dims=[-1])).contiguous()
+            bg_rgb = torch.zeros(R, 3, **f32) if Rb != R else None
             if Rb > 0:
                 pts = torch.empty(Rb * NB, 4, **f32)
                 cam = pose.reshape(4, 4)[:3, 3].contiguous()
@@ -1267,7 +1321,10 @@ class TrainGraph:
                          "mp_tr_copy_cols")
                 bg_slice = torch.empty(Rb, 3, **f32)
                 _chk(L.mp_tr_bg_comp_fwd(_p(sdfb), _p(brt.rgb), _p(zbg), Rb, NB, _p(bg_slice), st), "mp_tr_bg_comp_fwd")
-                bg_rgb[s0:s1] = bg_slice
+                if bg_rgb is None:
+                    bg_rgb = bg_slice                                 # the whole call's rays: no scatter into a zero image
+                else:
+                    bg_rgb[s0:s1] = bg_slice
                 self.bg = dict(it=bit, rt=brt, zbg=zbg, sdfb=sdfb, XAb=XAb, NB=NB, code=code, pts=pts, Rb=Rb)
             if self.shard is not None:                                # every rank composites all rays
                 pad = torch.zeros(self.n_slice, 3, **f32)
@@ -1291,10 +1348,76 @@ class TrainGraph:
                                0)[None]                                            # multiply.py:565
         self.bg_T = bg_T
         self.NZ = NZ
+        if self.reg_items:
+            return (rgb_values, normal_values, acc_map, acc_person, grad_theta) + self.reg_losses
         return rgb_values, normal_values, acc_map, acc_person, grad_theta
 
+    # ---- the two optional regularisers (multiply.py:336-394) -----------------------------------------------------------------
+    def _regularisers_forward(self):
+        """smpl_surface: the SDF at `num_pixels` posed SMPL vertices (head / hands / feet left out), warped to canonical space, must not
+        exceed 0.02 -- mean of (sdf - 0.02) over the offenders, per rendered person.  zero_pose: for every rendered person q and every
+        network p, the network's outputs at 2 000 vertices of p's canonical mesh under q's pose conditioning vs under a zero
+        conditioning -- L1 of the sdf + L1 of the features (the reference pairs q's conditioning with network p exactly like this).
+        Value-only passes of the SDF net, layer by layer (ImplicitTrain) on the iteration's shared weights; their adjoints run at the
+        head of the backward sweep, before any person's weight-norm adjoint retires its accumulators."""
+        m, cx, L, st = self.model, self.cx, hip.lib(), hip.stream()
+        dev = cx["dev"]
+        if self.pose_grad:
+            raise NotImplementedError("smpl_surface / zero_pose with body-model inputs under optimisation: their pose adjoints are not built")
+        ssl = torch.zeros(1, dtype=F32, device=dev)
+        zpl = torch.zeros(1, dtype=F32, device=dev)
+        for q in cx["persons"]:
+            pp = cx["per"][q]
+            cond = pp["cond"]
+            if m.smpl_surface_weight > 0:
+                imp = m.foreground_implicit_network_list[q]
+                idx = self.draws["person"][q]["surf_idx"].to(dev).long()
+                pts = pp["verts"].index_select(0, idx).contiguous()
+                n = pts.shape[0]
+                xc = torch.empty(n, 3, dtype=F32, device=dev)
+                _chk(L.mp_warp_inverse(_p(pts), None, None, None, None, None, 0, 1, n, _p(pp["vsorted"]), _p(pp["cbound"]),
+                                       _p(pp["btab"]), 0, None, None, _p(xc), None, None, None, None, None, st), "mp_warp_inverse")
+                it = ImplicitTrain(imp, xc, cond, fwd=False, lins=self.ts.lins[id(imp)])
+                sdf = it.out[:, 0]
+                mask = sdf > SMPL_SURFACE_THRESHOLD
+                cnt = mask.sum().clamp(min=1).to(F32)
+                ssl = ssl + torch.where(mask, sdf - SMPL_SURFACE_THRESHOLD, torch.zeros_like(sdf)).sum() / cnt      # 0 when none offends
+                self.reg_items.append(("surf", it, mask, cnt))
+            if m.zero_pose_weight > 0:
+                for p, vcano in enumerate(m.mesh_v_cano_list):
+                    net = m.foreground_implicit_network_list[p]
+                    pts = vcano.reshape(-1, 3).to(dev).float().index_select(0, self.draws["zp_idx"][(q, p)].to(dev).long()).contiguous()
+                    lins = self.ts.lins[id(net)]
+                    it1 = ImplicitTrain(net, pts, cond, fwd=False, lins=lins)
+                    it0 = ImplicitTrain(net, pts, torch.zeros_like(cond), fwd=False, lins=lins)
+                    d = it1.out - it0.out
+                    zpl = zpl + d[:, 0].abs().mean() + d[:, 1:].abs().mean()
+                    self.reg_items.append(("zero", it1, it0, torch.sign(d)))
+        self.reg_losses = (ssl, zpl)
+
+    def _regularisers_backward(self, d_ssl, d_zpl):
+        dev = self.cx["dev"]
+        for item in self.reg_items:
+            if item[0] == "surf":
+                _, it, mask, cnt = item
+                if d_ssl is None:
+                    continue
+                dZ = torch.zeros(it.P, 257, dtype=F32, device=dev)
+                dZ[:, 0] = d_ssl.reshape(()) * mask.to(F32) / cnt
+                it.backward(dZ)
+            else:
+                _, it1, it0, sg = item
+                if d_zpl is None:
+                    continue
+                n = sg.shape[0]
+                dZ = torch.empty(n, 257, dtype=F32, device=dev)
+                dZ[:, 0] = sg[:, 0] * (d_zpl.reshape(()) / n)
+                dZ[:, 1:] = sg[:, 1:] * (d_zpl.reshape(()) / (n * 256))
+                it1.backward(dZ)
+                it0.backward(-dZ)
+
     # ---- backward -----------------------------------------------------------------------------------------------
-    def backward(self, d_rgb_values, d_acc_map, d_acc_person, d_grad_theta):
+    def backward(self, d_rgb_values, d_acc_map, d_acc_person, d_grad_theta, d_ssl=None, d_zpl=None):
         """-> {id(parameter): gradient}"""
         m, cx, L = self.model, self.cx, hip.lib()
         dev, R, beta = cx["dev"], cx["R"], cx["beta"]
@@ -1303,6 +1426,8 @@ class TrainGraph:
         persons = cx["persons"]
         all_persons = self.all_persons
         self.ts.start_backward()                  # this sweep's own accumulators / gradient buffer (TrainState.start_backward)
+        if self.reg_items:
+            self._regularisers_backward(d_ssl, d_zpl)
         P = len(all_persons)
         S = self.NZ - 1
         t_inv, t_z, t_sdf, t_rgb, _ = self.tabs
@@ -1434,9 +1559,9 @@ class _TrainFn(torch.autograd.Function):
         return outs
 
     @staticmethod
-    def backward(ctx, d_rgb, d_nrm, d_acc, d_accp, d_gth):
+    def backward(ctx, d_rgb, d_nrm, d_acc, d_accp, d_gth, d_ssl=None, d_zpl=None):
         graph = ctx.graph
-        g = graph.backward(d_rgb, d_acc, d_accp, d_gth)
+        g = graph.backward(d_rgb, d_acc, d_accp, d_gth, d_ssl, d_zpl)
         body = [None, None, None]
         if graph.pose_grad:
             sl = ((4, 76), (1, 4), (76, 86))
@@ -1454,9 +1579,8 @@ def forward_train(model, input, id=-1, cond_zero_shit=False, canonical_pose=Fals
     tensors rgb_values / acc_map / acc_person_list / grad_theta (/ normal_values, not differentiable) hang off ONE autograd
     node whose backward is the hand-written adjoint sweep."""
     epoch = int(input["current_epoch"])
-    if model.smpl_surface_weight > 0 or model.zero_pose_weight > 0:
-        raise NotImplementedError("the smpl_surface / zero_pose regularisers (multiply.py:336-394, weight 0 in the shipped "
-                                  "configs) are not built; set their weights to 0")
+    if (model.smpl_surface_weight > 0 or model.zero_pose_weight > 0) and shard is not None:
+        raise NotImplementedError("the smpl_surface / zero_pose regularisers (multiply.py:336-394) are not built for person-sharded training")
     if shard is not None:                   # person-sharded: this rank evaluates persons {p : p % world == rank}
         assert id == -1, "person-sharded training renders all persons"
         id = [p for p in range(int(input["smpl_trans"].shape[1])) if p % shard[0] == shard[1]]
@@ -1472,7 +1596,9 @@ def forward_train(model, input, id=-1, cond_zero_shit=False, canonical_pose=Fals
     graph = TrainGraph(model, cx, input, cond_zero, draws, surface_flags=epoch < 250, pose_grad=pose_grad, shard=shard)
     params = [p for p in model.parameters() if p.requires_grad]
     with torch.enable_grad():                                                       # multiply.py:176
-        rgb_values, normal_values, acc_map, acc_person, grad_theta = _TrainFn.apply(graph, *body, *params)
+        outs = _TrainFn.apply(graph, *body, *params)
+        rgb_values, normal_values, acc_map, acc_person, grad_theta = outs[:5]
+        smpl_surface_loss, zero_pose_loss = (outs[5], outs[6]) if len(outs) == 7 else (None, None)
         temporal_loss = torch.zeros(1, device=dev)
         if epoch > 250:                                                             # multiply.py:242-243
             temporal_loss = torch.mean(torch.square(input["smpl_pose_last"].to(dev) - input["smpl_pose"].to(dev)))
@@ -1488,7 +1614,9 @@ def forward_train(model, input, id=-1, cond_zero_shit=False, canonical_pose=Fals
         if hit.numel() == 0:
             hit = torch.zeros(1, dtype=torch.long, device=dev)      # the reference's empty-hit fallback, multiply.py:262-263
         points = cam[None, None, :] + rl["z"][hit][:, :-1, None] * cx["dirs"][hit][:, None, :]
-    zeros1 = lambda: torch.zeros(1, device=dev)
+    _z3 = torch.zeros(3, device=dev)            # the dict's constant zero entries: one fill
+    _zi = iter(range(3))
+    zeros1 = lambda: _z3[next(_zi):][:1]
     index_off_surface = index_in_surface = None
     if epoch < 250:                                                                 # multiply.py:549-557
         P = len(graph.all_persons)
@@ -1506,13 +1634,14 @@ def forward_train(model, input, id=-1, cond_zero_shit=False, canonical_pose=Fals
                 in_all[:, n] = torch.where(r["hit"], r["inn"], in_all[:, n])
         index_off_surface, index_in_surface = off_all.all(dim=1), in_all.any(dim=1)
     out = {
-        "zero_pose_loss": zeros1(), "t_list": [], "fg_rgb_values_each_person_list": [],
+        "zero_pose_loss": zero_pose_loss if zero_pose_loss is not None else zeros1(), "t_list": [], "fg_rgb_values_each_person_list": [],
         "cam_loc": cam[None].expand(cx["R"], 3), "hitted_mask_idx": [], "mean_hitted_vertex_list": [],
         "points": points, "rgb_values": rgb_values, "normal_values": normal_values,
         "index_outside": input.get("index_outside"), "index_off_surface": index_off_surface,
         "index_in_surface": index_in_surface,
         "acc_map": acc_map, "grad_theta": grad_theta, "interpenetration_loss": zeros1(), "temporal_loss": temporal_loss,
-        "acc_person_list": acc_person, "smpl_surface_loss": zeros1(), "epoch": input["current_epoch"],
+        "acc_person_list": acc_person, "smpl_surface_loss": smpl_surface_loss if smpl_surface_loss is not None else zeros1(),
+        "epoch": input["current_epoch"],
     }
     if "sam_mask" in input:
         out["sam_mask"] = input["sam_mask"].squeeze()

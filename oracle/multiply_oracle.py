@@ -653,6 +653,23 @@ class MultiplyOracle:
             with torch.no_grad():
                 sdf, x_c, _ = person.sdf_func(pts, cond, tfs, pv, eval_mode=True)
             rgb, nrm, _ = self.shade(person, x_c, cond, tfs)
+            # the two optional regularisers (multiply.py:336-394; weight 0 in the shipped configs), when their draws are handed in
+            if dr.get("surf_idx") is not None:
+                # SDF at posed SMPL vertices (head / hands / feet excluded by the draw), warped to canonical space: above 0.02 is implausible
+                sample = pv.reshape(-1, 3)[dr["surf_idx"].long()]
+                xs, _ = deform_inverse(sample, tfs, pv, person.server.weights)
+                ss = person.implicit(xs, cond)[:, 0]
+                bad = ss > 0.02
+                if bool(bad.any()):
+                    smpl_surface_loss = smpl_surface_loss + F.l1_loss(ss[bad], torch.full_like(ss[bad], 0.02), reduction="mean")
+            if draws.get("zp_idx") is not None:
+                # network q under THIS person's conditioning vs under a zero conditioning, at vertices of q's canonical mesh
+                for q in range(self.P):
+                    vq = self.persons[q].server.verts_c[draws["zp_idx"][(p, q)].long()]
+                    o_pred = self.persons[q].implicit(vq, cond)
+                    o_zero = self.persons[q].implicit(vq, cond * 0.0)
+                    zero_pose_loss = zero_pose_loss + F.l1_loss(o_pred[:, :1], o_zero[:, :1], reduction="mean") + \
+                        F.l1_loss(o_pred[:, 1:], o_zero[:, 1:], reduction="mean")
             S = z.shape[1]
             z_l.append(z); zmax_l.append(zmax); sdf_l.append(sdf.reshape(-1, S)); hit_l.append(idx)
             rgb_l.append(rgb.detach().reshape(-1, S, 3)); nrm_l.append(nrm.detach().reshape(-1, S, 3))
@@ -699,6 +716,7 @@ class MultiplyOracle:
         persons = list(range(self.P)) if person_list is None else person_list
         z_l, zmax_l, sdf_l, rgb_l, nrm_l, hit_l, gth_l = [], [], [], [], [], [], []
         body_grad = any(inp[k].requires_grad for k in ("smpl_pose", "smpl_trans", "smpl_shape"))
+        smpl_surface_loss, zero_pose_loss = torch.zeros(1), torch.zeros(1)
         for k, p in enumerate(persons):
             with torch.set_grad_enabled(body_grad):
                 so = self.servers[p].forward(scale[p], inp["smpl_trans"][0, p], inp["smpl_pose"][0, p],
@@ -721,6 +739,23 @@ class MultiplyOracle:
             xe = (person.server.verts_c[dr["eik_idx"]] + dr["eik_noise"] * 0.01).detach().requires_grad_(True)
             se = person.implicit(xe, cond)[:, :1]
             gth = torch.autograd.grad(se, xe, torch.ones_like(se), create_graph=True)[0]
+            # the two optional regularisers (multiply.py:336-394; weight 0 in the shipped configs), when their draws are handed in
+            if dr.get("surf_idx") is not None:
+                # SDF at posed SMPL vertices (head / hands / feet excluded by the draw), warped to canonical space: above 0.02 is implausible
+                sample = pv.reshape(-1, 3)[dr["surf_idx"].long()]
+                xs, _ = deform_inverse(sample, tfs, pv, person.server.weights)
+                ss = person.implicit(xs, cond)[:, 0]
+                bad = ss > 0.02
+                if bool(bad.any()):
+                    smpl_surface_loss = smpl_surface_loss + F.l1_loss(ss[bad], torch.full_like(ss[bad], 0.02), reduction="mean")
+            if draws.get("zp_idx") is not None:
+                # network q under THIS person's conditioning vs under a zero conditioning, at vertices of q's canonical mesh
+                for q in range(self.P):
+                    vq = self.persons[q].server.verts_c[draws["zp_idx"][(p, q)].long()]
+                    o_pred = self.persons[q].implicit(vq, cond)
+                    o_zero = self.persons[q].implicit(vq, cond * 0.0)
+                    zero_pose_loss = zero_pose_loss + F.l1_loss(o_pred[:, :1], o_zero[:, :1], reduction="mean") + \
+                        F.l1_loss(o_pred[:, 1:], o_zero[:, 1:], reduction="mean")
             S = z.shape[1]
             z_l.append(z); zmax_l.append(zmax); sdf_l.append(sdf.reshape(-1, S)); hit_l.append(idx)
             rgb_l.append(rgb.reshape(-1, S, 3)); nrm_l.append(nrm.reshape(-1, S, 3)); gth_l.append(gth)
@@ -733,4 +768,4 @@ class MultiplyOracle:
         rgb_values = fg_rgb + bg_T[:, None] * bg_rgb
         return dict(rgb_values=rgb_values, normal_values=nrm, acc_map=acc, acc_person_list=acc_person,
                     grad_theta=torch.cat(gth_l, 0)[None], bg_transmittance=bg_T, bg_rgb=bg_rgb, sdf=sdf_l,
-                    rgb_samples=rgb_l)
+                    rgb_samples=rgb_l, smpl_surface_loss=smpl_surface_loss, zero_pose_loss=zero_pose_loss)

@@ -264,6 +264,67 @@ def test_two_live_training_graphs_keep_their_gradients_apart():
         assert rel < 1e-4 or float((g - want).abs().max()) < 1e-7, f"{k} (double sweep): {rel:.3e}"
 
 
+def test_smpl_surface_and_zero_pose_regularisers_match_the_oracle():
+    """The two optional regularisers of the training forward (multiply.py:336-394; weight 0 in the shipped configs, so a reachable
+    branch rather than a used one): value, and the gradient of every parameter through loss terms that are ONLY these two (all
+    other weights irrelevant: the loss here is their weighted sum + the render loss), against the oracle's restatement under torch
+    autograd on the same vertex draws.  The vertex segmentation the reference reads from an asset it does not ship
+    (outputs/smpl_vert_segmentation.json) is a synthetic one here; parity of these two terms with the reference itself is unpinned."""
+    model, oracle, inp, gin, gt, loss_fn, train = _train_setup()
+    model.smpl_surface_weight, model.zero_pose_weight = 1.0, 0.5
+    loss_fn.smpl_surface_weight, loss_fn.zero_pose_weight = 1.0, 0.5
+    nv = model.smpl_server_list[0].verts_c.reshape(-1, 3).shape[0]
+    ids = list(range(nv))
+    model.smpl_vertex_part = {"head": ids[:300], "rightHand": ids[300:400], "leftHand": ids[400:500], "rightFoot": ids[500:560],
+                              "leftFoot": ids[560:620], "leftHandIndex1": ids[620:640], "rightHandIndex1": ids[640:660]}
+    torch.manual_seed(21)
+    with torch.no_grad():         # the geometric initialisation zeroes layer 0's conditioning columns (the outputs would not depend on
+        for net in model.foreground_implicit_network_list:     # the pose at all: zero_pose_loss == 0): perturb them
+            net.lin0.weight_v[:, 39:] += 0.05 * torch.randn_like(net.lin0.weight_v[:, 39:])
+            net.lin8.bias[0] += 0.03
+    oracle.sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    for pp in oracle.persons:
+        pp.sd = oracle.sd
+    R = inp["uv"].shape[1]
+    hit = [torch.arange(R), torch.arange(R)]
+    out = model({**gin, "hit_index": hit, "current_epoch": 30})       # epoch 30: both schedules are on, the pose conditioning too
+    lo = loss_fn(out, gt)
+    model.zero_grad()
+    lo["loss"].backward()
+    torch.cuda.synchronize()
+    graph = model._last_train
+    assert float(out["smpl_surface_loss"]) > 0 and float(out["zero_pose_loss"]) > 0
+    for v in oracle.sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    draws = _cpu(graph.draws)
+    assert draws["person"][0]["surf_idx"].min() >= 660            # the excluded parts are never drawn
+    z_given = [graph.fg[p]["zfinal"].cpu() for p in range(2)]
+    want = oracle.forward_train(inp, hit, z_given, draws)
+    for k in ("smpl_surface_loss", "zero_pose_loss"):
+        a, b = float(out[k]), float(want[k])
+        print(f"[parity] {k}: gpu {a:.6f} oracle {b:.6f}")
+        assert abs(a - b) < 2e-5 * max(1.0, abs(b)), k
+    tl = torch.mean(torch.square((inp["smpl_pose"] + 0.01) - inp["smpl_pose"]))
+    want.update(fg_rgb_values_each_person_list=[], index_in_surface=graph_index_in_surface(out), epoch=30,
+                temporal_loss=tl.reshape(()), sam_mask=gin["sam_mask"].squeeze().cpu())
+    lw = loss_fn(want, gt)
+    for k in ("loss", "rgb_loss", "eikonal_loss", "bce_loss", "in_shape_loss", "sam_mask_loss", "smpl_surface_loss", "zero_pose_loss"):
+        print(f"[parity] loss term {k}: gpu {float(lo[k]):.6f} oracle {float(lw[k]):.6f}")
+    # (the perturbed conditioning columns make the network rougher than the geometric initialisation: 3e-4 instead of the 1e-4 of
+    # the other training tests; the terms under test agree to 1e-6 above)
+    assert abs(float(lo["loss"]) - float(lw["loss"])) < 3e-4 * max(1.0, abs(float(lw["loss"])))
+    names = [k for k, v in oracle.sd.items() if v.requires_grad]
+    gw = torch.autograd.grad(lw["loss"], [oracle.sd[k] for k in names], allow_unused=True)
+    worst = _compare_parameter_gradients(model, oracle, names, gw)
+    print(f"[parity] with the two regularisers on: worst relative parameter-gradient error {worst:.3e}")
+
+
+def graph_index_in_surface(out):
+    v = out["index_in_surface"]
+    return None if v is None else v.cpu()
+
+
 def test_eval_after_a_fused_optimizer_step_uses_the_updated_weights():
     """torch's fused Adam updates the parameters WITHOUT bumping their version counters, which the packed-weight caches of the
     f16 kernels are keyed on: the eval render after such a step must not come from the stale pack (Multiply.train() drops the
