@@ -9,7 +9,11 @@ over the 512x512 two-person frame, N_samples 128) once per sampler arithmetic --
             products, fp32 activations; Multiply.sampler_sdf_mode); `bf16x3-layerwise`: the same arithmetic layer by layer
 -- and compares depths and pixels with the fp32 oracle on the same hit sets.  Shading stays on the product's f16 kernels in
 both runs, so the difference between the rows is the sampler's arithmetic alone.
-    python tools/sampler_precision.py [n_groups]  ->  gpurun_out/sampler_precision.txt
+    python tools/sampler_precision.py [n_groups] [beta]  ->  gpurun_out/sampler_precision[_beta<b>].txt
+beta (default: the initial 0.1 of confs/model.yaml): the Laplace density's scale.  At the initial 0.1 the density at the outlier
+boundary (distance 0.1 from the body, where the reference switches to sdf = 4, multiply.py:142-143) is still 1.8 per unit length, so
+a sample the f16 sampler shifts across that boundary moves a grazing ray's opacity; a trained model's beta (~0.01) makes the
+density there e^-10 of its surface value.
 """
 import os
 import sys
@@ -25,7 +29,11 @@ from oracle import multiply_oracle as O         # noqa: E402
 
 def main():
     n_groups = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    beta = float(sys.argv[2]) if len(sys.argv) > 2 else None
     model, inp, tables, sc = bench.build_model(128)
+    if beta is not None:
+        with torch.no_grad():
+            model.density.beta.fill_(beta)
     model.convergence_group = 512
     R = inp["uv"].shape[1]
     gin = bench.to_dev(inp)
@@ -48,7 +56,7 @@ def main():
         subs.append((sub, hg))
     t_or = time.time() - t0
     lines = [f"sampler precision: {512 * len(groups)} rays = {len(groups)} convergence groups of the headline frame (2 persons, 512x512, "
-             f"N_samples 128), fp32 oracle {t_or:.0f} s; shading on the product's f16 kernels in every row",
+             f"N_samples 128), density beta {float(model.density.beta):.3g}, fp32 oracle {t_or:.0f} s; shading on the product's f16 kernels in every row",
              f"{'sampler sdf':10s} {'z max':>9s} {'z mean':>9s} | {'acc max':>9s} {'acc>1e-2':>8s} {'acc>3e-3':>8s} | {'nrm max':>9s} {'nrm>1e-2':>8s} | "
              f"{'rgb max':>9s} | sampler-sdf ms (these rays)"]
     for mode in ("f16", "bf16x3", "bf16x3-layerwise"):
@@ -76,7 +84,7 @@ def main():
     lines.append("(third row: bf16x3-layerwise = the same arithmetic through the layer-wise GEMMs with a host read per iteration -- the "
                  "independent implementation the fused kernel of row 2 is checked against)")
     os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/sampler_precision.txt", "w") as f:
+    with open("gpurun_out/sampler_precision.txt" if beta is None else f"gpurun_out/sampler_precision_beta{beta:g}.txt", "w") as f:
         f.write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
