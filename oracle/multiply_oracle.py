@@ -653,23 +653,6 @@ class MultiplyOracle:
             with torch.no_grad():
                 sdf, x_c, _ = person.sdf_func(pts, cond, tfs, pv, eval_mode=True)
             rgb, nrm, _ = self.shade(person, x_c, cond, tfs)
-            # the two optional regularisers (multiply.py:336-394; weight 0 in the shipped configs), when their draws are handed in
-            if dr.get("surf_idx") is not None:
-                # SDF at posed SMPL vertices (head / hands / feet excluded by the draw), warped to canonical space: above 0.02 is implausible
-                sample = pv.reshape(-1, 3)[dr["surf_idx"].long()]
-                xs, _ = deform_inverse(sample, tfs, pv, person.server.weights)
-                ss = person.implicit(xs, cond)[:, 0]
-                bad = ss > 0.02
-                if bool(bad.any()):
-                    smpl_surface_loss = smpl_surface_loss + F.l1_loss(ss[bad], torch.full_like(ss[bad], 0.02), reduction="mean")
-            if draws.get("zp_idx") is not None:
-                # network q under THIS person's conditioning vs under a zero conditioning, at vertices of q's canonical mesh
-                for q in range(self.P):
-                    vq = self.persons[q].server.verts_c[draws["zp_idx"][(p, q)].long()]
-                    o_pred = self.persons[q].implicit(vq, cond)
-                    o_zero = self.persons[q].implicit(vq, cond * 0.0)
-                    zero_pose_loss = zero_pose_loss + F.l1_loss(o_pred[:, :1], o_zero[:, :1], reduction="mean") + \
-                        F.l1_loss(o_pred[:, 1:], o_zero[:, 1:], reduction="mean")
             S = z.shape[1]
             z_l.append(z); zmax_l.append(zmax); sdf_l.append(sdf.reshape(-1, S)); hit_l.append(idx)
             rgb_l.append(rgb.detach().reshape(-1, S, 3)); nrm_l.append(nrm.detach().reshape(-1, S, 3))
