@@ -316,6 +316,21 @@ def train_cpu_baseline(model, gin, inp, tables, sc, n_samples, rays=512, iters=3
                     smpl_surface_loss=torch.zeros(1), zero_pose_loss=torch.zeros(1))
         with contextlib.redirect_stdout(sys.stderr):
             lo = loss_fn(want, gt)
+        # The reference replaces a NaN bce term by zero (loss.py:124-128): log(1 - acc + 1e-6) is NaN as soon as ONE opacity exceeds
+        # 1 + 1e-6 -- a rounding-level event (the device's and the oracle's acc_map agree to ~7e-6, and a ray through several opaque
+        # bodies sums to 1 within that).  When the guard fires on one side only, the two iterations differ by the whole bce term and
+        # no gradient is comparable: the oracle's loss is then taken without the term as well (and the event is recorded).
+        guard_gpu, guard_or = float(lo_gpu["bce_loss"]) == 0.0, float(lo["bce_loss"]) == 0.0
+        bce_note = None
+        if guard_gpu and not guard_or:
+            lo = dict(lo)
+            lo["loss"] = lo["loss"] - loss_fn.bce_weight * lo["bce_loss"]
+            bce_note = (f"the reference's NaN guard on bce_loss (loss.py:124-128) fired on the device (acc_map max "
+                        f"{float(out['acc_map'].max()):.8f} > 1 + 1e-6) and not on the oracle (max {float(want['acc_map'].max()):.8f}): "
+                        f"the oracle's loss is compared without the bce term too")
+        elif guard_or and not guard_gpu:
+            bce_note = ("the reference's NaN guard on bce_loss fired on the oracle and not on the device: the parity figures of this "
+                        "iteration include the whole bce term")
         gw = torch.autograd.grad(lo["loss"], [sd[k] for k in names], allow_unused=True)
         times.append(time.time() - t0)
         if i == 0:
@@ -339,7 +354,7 @@ def train_cpu_baseline(model, gin, inp, tables, sc, n_samples, rays=512, iters=3
             parity = {"parity_loss_abs": abs(float(lo_gpu["loss"]) - float(lo["loss"])), "loss_gpu": float(lo_gpu["loss"]),
                       "loss_oracle": float(lo["loss"]), "parity_grad_rel_worst": worst, "parity_grad_worst_tensor": worst_name,
                       "parity_grad_tensors": n_cmp, "parity_grad_tensors_below_1e-7": n_tiny,
-                      "parity_state_entries_without_gradient": n_nograd, "parity_forward_max_abs": fwd}
+                      "parity_state_entries_without_gradient": n_nograd, "parity_forward_max_abs": fwd, "parity_note": bce_note}
         del gw
     dt = float(np.mean(times[1:]))
     threads, phys, name = host_cpu()
