@@ -474,8 +474,9 @@ class Multiply(nn.Module):
                 imp = self.foreground_implicit_network_list[s["p"]]
                 if not T.fused_sdf_supported(imp):
                     raise NotImplementedError("sampler_sdf_mode 'bf16x3' needs the network shape csrc/tfuse.hip is specialised for")
-                # once per call and person; a training forward shares the iteration's resolved weights (TrainState.begin ran)
-                lins = T.train_state(self).lins[id(imp)] if self.training else None
+                # once per call and person; inside a training forward (TrainGraph.run: TrainState.begin has just resolved the
+                # iteration's weights) the shared layers are used, anywhere else the state resolves the weights itself
+                lins = T.train_state(self).lins[id(imp)] if self.__dict__.get("_mp_in_train_graph") else None
                 fs = s["fs"] = T.fused_sdf_state(imp, lins).refresh(s["pp"]["cond"])
             hip.check(L.mp_tf_sdf_val(hip.ptr(fs.wpack), hip.ptr(fs.bias_all), hip.ptr(s["xc_new"]), hip.ptr(s["work"]),
                                       hip.ptr(wcount[it:it + 1]), s["Rp"] * s["NE"], hip.ptr(s["sdfnew"]), st), "mp_tf_sdf_val")

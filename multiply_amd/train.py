@@ -1138,7 +1138,11 @@ class TrainGraph:
         # the samplers of all persons advance together (Multiply._sample_persons): in ray-sharded data-parallel training the
         # convergence vote is then ONE collective per sampler iteration for all persons
         todo = [p for p in persons if self.draws["person"][p].get("z_given") is None]
-        sampled = m._sample_persons(cx, {p: self.draws["person"][p] for p in todo}, persons=todo) if todo else {}
+        m.__dict__["_mp_in_train_graph"] = True       # (the near-fp32 sampler mode may share this iteration's resolved weights)
+        try:
+            sampled = m._sample_persons(cx, {p: self.draws["person"][p] for p in todo}, persons=todo) if todo else {}
+        finally:
+            m.__dict__["_mp_in_train_graph"] = False
         for n, p in enumerate(persons):
             pp = cx["per"][p]
             dr = self.draws["person"][p]

@@ -62,6 +62,12 @@ def test_training_sampler_matches_oracle_with_same_draws():
                                        dict(t_rand=d["t_rand"], u_final=d["u_final"], extra_idx=d["extra_idx"].long()))
         print("[info] iterations oracle", it_o, "gpu", iters.tolist())
         assert TOL.within(report(f"train z_vals person {p}", zfinal, z), TOL.TRAIN_Z_VALS)
+        # the near-fp32 sampler mode (mp_tf_sdf_val), same draws: an order of magnitude closer
+        model.sampler_sdf_mode = "bf16x3"
+        zp, it_p, _ = model._sample_person(cx, n, p, draws["person"][p])
+        model.sampler_sdf_mode = "f16"
+        torch.cuda.synchronize()
+        assert TOL.within(report(f"train z_vals person {p}, sampler_sdf_mode bf16x3", zp, z), TOL.TRAIN_Z_VALS_PRECISE)
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "f32"])
@@ -200,6 +206,28 @@ def test_training_parity_at_the_benchmarked_workload():
         # measured at this workload: rgb 1.3e-6, acc 2.9e-6, normals 1.2e-4 (82 k shaded samples per person: the worst one
         # sits where |grad sdf| is small and the normalisation amplifies the fp32 summation-order difference)
         assert v < (6e-4 if k == "normal_values" else 3 * TOL.train_fwd().get(k, 8e-6)), (k, v)
+
+
+def test_training_step_with_the_near_fp32_sampler_mode():
+    """sampler_sdf_mode = 'bf16x3' inside a training forward (the sampler's queries on the iteration's shared, already resolved
+    weights): the step runs, and its depths differ from the f16 sampler's by no more than the f16 tolerance"""
+    model, oracle, inp, gin, gt, loss_fn, train = _train_setup()
+    R = inp["uv"].shape[1]
+    hit = [torch.arange(R), torch.arange(R)]
+    zs = {}
+    for mode in ("f16", "bf16x3"):
+        model.sampler_sdf_mode = mode
+        torch.manual_seed(9)
+        out = model({**gin, "hit_index": hit})
+        lo = loss_fn(out, gt)
+        model.zero_grad()
+        lo["loss"].backward()
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(lo["loss"]).all())
+        zs[mode] = [model._last_train.fg[p]["zfinal"].clone() for p in range(2)]
+    model.sampler_sdf_mode = "f16"
+    for p in range(2):
+        assert TOL.within(report(f"train z_vals person {p}: bf16x3 vs f16 sampler", zs["bf16x3"][p], zs["f16"][p].cpu()), TOL.TRAIN_Z_VALS)
 
 
 def test_training_step_reduces_loss():

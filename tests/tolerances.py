@@ -40,6 +40,7 @@ EVAL = {                                   # eval-mode Multiply.forward outputs,
 EVAL_PRECISE = {"rgb_values": 1.5e-4, "acc_map": 4.5e-3, "acc_person_list": 4.5e-3, "normal_values": 6e-3, "fg_rgb_values": 4.5e-3}
 Z_VALS_PRECISE = (2.5e-3, 2.5e-5)
 Z_VALS = (5e-2, 3e-4)                       # sampler depths (inverse CDF of f16 sdf queries); measured 1.4e-2, 6.7e-5
+TRAIN_Z_VALS_PRECISE = (6e-3, 3.5e-5)       # the same with sampler_sdf_mode = 'bf16x3'; measured 1.2e-3, 6.5e-6
 TRAIN_Z_VALS = (0.15, 1e-3)                 # training-mode depths (stratified / random draws); measured 3e-2, 2e-4
 MLP = {                                     # the fused MLP kernels on random points vs the fp32 oracle: max |err|
     "fg_sdf": 5e-3, "fg_feat": 7e-3,        # 9.8e-4, 1.4e-3
