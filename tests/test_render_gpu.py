@@ -95,18 +95,40 @@ def test_forward_eval_two_persons_128_samples_headline_config():
     # the oracle's convergence vote is per call: feed it the same 512-ray chunks
     R = inp["uv"].shape[1]
     parts = {k: [] for k in ("rgb_values", "acc_map", "acc_person_list", "normal_values", "fg_rgb_values")}
+    z_or = [[], []]
     for c0 in range(0, R, 512):
         sub = dict(inp)
         sub["uv"] = inp["uv"][:, c0:c0 + 512]
         hg = [h[(h >= c0) & (h < c0 + 512)] - c0 for h in hit]
+        empty = [len(h) == 0 for h in hg]
         hg = [h if len(h) else torch.zeros(1, dtype=torch.long) for h in hg]
         w = oracle.forward_eval(sub, hg)
         for k in parts:
             parts[k].append(w[k])
+        for p in range(2):
+            if not empty[p]:
+                z_or[p].append(torch.cat([w["z_vals"][p], w["z_max"][p][:, None]], 1))
     print("[info] hit rays per person", n_hit, "of", R)
     for k, tol in TOL.EVAL.items():
         if k in parts:
             assert TOL.within(report("headline N=128 " + k, got[k], torch.cat(parts[k], 0)), tol), k
+    # round 5: the same render with the sampler's queries at near-fp32 precision (sampler_sdf_mode = 'bf16x3', mp_tf_sdf_val):
+    # depths and outputs against the same oracle, PLAIN maxima (tests/tolerances.py EVAL_PRECISE / Z_VALS_PRECISE)
+    z_f16 = [model._last["per"][p]["zfinal"][:n_hit[p]].clone() for p in range(2)]
+    model.sampler_sdf_mode = "bf16x3"
+    got_p = model(_gpu(inp))
+    torch.cuda.synchronize()
+    model.sampler_sdf_mode = "f16"
+    assert list(model.last_stats["n_hit"]) == list(n_hit)
+    for p in range(2):
+        zo = torch.cat(z_or[p], 0)
+        report(f"headline N=128 z_vals person {p}, f16 sampler", z_f16[p], zo)
+        st = report(f"headline N=128 z_vals person {p}, bf16x3 sampler", model._last["per"][p]["zfinal"][:n_hit[p]], zo)
+        zt = TOL.Z_VALS_PRECISE
+        ray_err = (model._last["per"][p]["zfinal"][:n_hit[p]].cpu() - zo).abs().max(1).values
+        assert st[1] < zt["mean"] and int((ray_err > zt["bulk"]).sum()) <= max(2, int(zt["frac"] * len(ray_err))), (st[0], st[1])
+    for k, tol in TOL.EVAL_PRECISE.items():
+        assert report("headline N=128, bf16x3 sampler: " + k, got_p[k], torch.cat(parts[k], 0))[0] < tol, k
 
 
 def test_forward_eval_box_cull_is_conservative():
