@@ -607,7 +607,9 @@ def main():
                               "achieved": tflop / (tdt / args.train_steps) / 1e12,
                               "frac": tflop / (tdt / args.train_steps) / 1e12 / train_peak,
                               "note": "algorithmic GEMM FLOP of the differentiable path (the f16 sampler queries are not counted) "
-                                      "over the whole iteration's wall time; peak = " + train_peak_note}}
+                                      "over the whole iteration's wall time; peak = " + train_peak_note + ".  The iteration is not "
+                                      "matrix-bound: its three dominant kernels (k_tf_sdf_fwd / _bwd, k_gemm_tn_b3w: 5.1 of 9.4 ms) move "
+                                      "the SDF net's per-point stash at 2.8-4.3 TB/s (profiles/r05_train_pmc_traffic.txt)"}}
 
     n_shaded = float(sum(int(w.sum()) for s_ in shaded for w in s_)) / args.steps          # per frame (this rank's share)
     n_sdf = float(sum(int(w[:-1].sum()) for s_ in sdf_evals for w in s_)) / args.steps
