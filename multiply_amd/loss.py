@@ -58,7 +58,10 @@ class _FusedTerms(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_total, _g_terms):
-        scaled = torch._foreach_mul(list(ctx.grads), g_total.reshape(()))       # one launch for the four gradients
+        try:
+            scaled = torch._foreach_mul(list(ctx.grads), g_total.reshape(()))   # one launch for the four gradients
+        except (AttributeError, TypeError, RuntimeError):                        # (a torch without the list x tensor overload)
+            scaled = [g * g_total.reshape(()) for g in ctx.grads]
         return tuple(g.reshape(sh) for g, sh in zip(scaled, ctx.shapes)) + (None, None, None, None)
 
 
