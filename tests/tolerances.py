@@ -34,10 +34,24 @@ EVAL = {                                   # eval-mode Multiply.forward outputs,
     "normal_values": Dist(8e-4, p999=0.04, **_GRAZE),  # mean 3.2e-4; 3 of 1024 rays above 1e-2, worst 3.9e-2; 16k: p99.9 1.2e-2
     "bg_rgb": (1.5e-4, 2.5e-5),             # 2.7e-5, 5.4e-6
 }
-# eval outputs with the sampler's network queries at near-fp32 precision (Multiply.sampler_sdf_mode = 'bf16x3'; shading still f16):
-# plain max bounds, <= 5x the largest error measured on the 4 096-ray headline slice (profiles/r05_sampler_precision.txt:
-# acc 9.0e-4, normals 1.2e-3, rgb 3.0e-5, depths 5.0e-4) -- the f16 sampler's grazing-ray tail (0.11) does not exist here
-EVAL_PRECISE = {"rgb_values": 1.5e-4, "acc_map": 4.5e-3, "acc_person_list": 4.5e-3, "normal_values": 6e-3, "fg_rgb_values": 4.5e-3}
+# eval outputs with the sampler's network queries at near-fp32 precision (Multiply.sampler_sdf_mode = 'bf16x3'; shading still f16).
+# Measured (profiles/r05_parity_16k.txt, 16 384 rays of the headline frame): acc_map 1 ray of 16 384 above 3e-3 (1.1e-2; the f16
+# sampler: 36 rays above 1e-2, worst 9.0e-2), normals 3 elements above 3e-3 (worst 9.7e-3), pixels 3.5e-4; on the always-on 4 096- and
+# 1 024-ray slices nothing above 1.2e-3.  Bounds: `hard` <= 5x the 16k maxima, and at most max(1, frac x rays) rays with an element
+# above `bulk` -- 5e-4 of the rays where the f16 sampler's distribution bound allows 1e-2 of them above 1e-2.
+EVAL_PRECISE = {"rgb_values": dict(hard=1.5e-3, bulk=3e-3, frac=5e-4), "acc_map": dict(hard=5e-2, bulk=3e-3, frac=5e-4),
+                "acc_person_list": dict(hard=5e-2, bulk=3e-3, frac=5e-4), "normal_values": dict(hard=5e-2, bulk=3e-3, frac=5e-4),
+                "fg_rgb_values": dict(hard=2.5e-2, bulk=3e-3, frac=5e-4)}
+
+
+def within_precise(err, tol):
+    """err: |got - want| per element, rows = rays (NaNs already zeroed); tol: an EVAL_PRECISE entry"""
+    import torch
+    e = torch.as_tensor(err).double()
+    ray = e.reshape(e.shape[0], -1).max(dim=1).values if e.dim() > 1 else e
+    return float(e.max()) < tol["hard"] and int((ray > tol["bulk"]).sum()) <= max(1, int(tol["frac"] * ray.numel()))
+
+
 # depths in that mode: mean, and the fraction of the RAYS with a depth off by more than 3e-3 -- not a maximum: where the CDF is flat (no
 # weight) an inverse-CDF depth moves by centimetres with the last bit of an sdf (measured on the 1 024-ray headline scene: mean
 # 3.9e-7 / 2.6e-5, one ray of 479 at 4.0e-2; with the f16 sampler 4.8e-5 / 3.0e-4, 12 / 101 rays above 3e-3, worst 0.22)
