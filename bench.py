@@ -696,6 +696,7 @@ def main():
                          "algorithmic_flop_per_launch": flops[dom] / launches_per_frame,
                          "note": "rank 0's share of the frame" if dist else None},
             "phases_ms_per_step": {k: v[1] / args.steps for k, v in phases.items()},
+            "lib_source_sha16": __import__("multiply_amd.hip", fromlist=["x"]).lib_source_sha16(),     # content hash of csrc/* + headers + flags the loaded library was built from
         }
         if per_rank is not None:
             out["per_rank"] = per_rank

@@ -58,9 +58,22 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                                f"g.build()'` (hipcc --offload-arch=gfx950). The MultiPly hot path has no fallback.")
+        if "MP_LIB_PATH" not in os.environ:
+            # the library must be what THIS tree's sources produce (multiply_amd/build.py stamps it with a content hash)
+            from . import build as B
+            have, want = B.library_hash(), B.source_hash()
+            if have is not None and have != want:
+                raise RuntimeError(f"{LIB_PATH} was built from sources {have}, this tree is {want}: rebuild it with "
+                                   f"`python -m multiply_amd.build` (a stale library is never loaded)")
         _lib = C.CDLL(LIB_PATH)
         _declare_prototypes(_lib)
     return _lib
+
+
+def lib_source_sha16():
+    """content hash of the sources the loaded library was built from (multiply_amd/build.py)"""
+    from . import build as B
+    return B.library_hash()
 
 
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "multiply_hip.h")
