@@ -430,9 +430,10 @@ def main():
                          "sharded, one all_to_all (configs[3] on <= P ranks); hybrid: person teams x ray shards (configs[3] on 8 ranks)")
     ap.add_argument("--person-slots", type=int, default=0, help="--mode hybrid: ranks per team (default: min(persons, world))")
     ap.add_argument("--chunk-rays", type=int, default=16384, help="--mode person / hybrid: rays per exchange (whole convergence groups)")
-    ap.add_argument("--sampler-sdf", choices=("f16", "bf16x3"), default=os.environ.get("MP_SAMPLER_SDF", "f16"),
-                    help="arithmetic of the sampler's network queries: f16 (fused half-precision kernel, default) | bf16x3 (near-fp32: "
-                         "mp_tf_sdf_val; depths within 1e-3 of the fp32 reference instead of 2e-2, ~5 ms per frame)")
+    ap.add_argument("--sampler-sdf", choices=("auto", "f16", "f16x2", "bf16x3"), default=os.environ.get("MP_SAMPLER_SDF", "auto"),
+                    help="arithmetic of the sampler's network queries: auto (default) = bf16x3 (near-fp32: mp_tf_sdf_val; depths within "
+                         "1e-3 of the fp32 reference instead of 2e-2) | f16x2 (split activations) | f16 (fused half-precision kernel, "
+                         "the round 1-5 default: ~5 ms per frame less)")
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the frame-per-rank weak-scaling leg")
     ap.add_argument("--breakdown", action="store_true", help="print per-phase GPU times to stderr")
     args = ap.parse_args()
@@ -680,7 +681,7 @@ def main():
                                    f"person), N_samples_eval={max(128, args.samples)}, 32 background samples, "
                                    f"convergence groups of 512 rays (reference pixel_per_batch), geometric-init weights",
                        "rays_per_step": R, "frames": args.steps,
-                       "persons": args.persons, "sampler_sdf": args.sampler_sdf,
+                       "persons": args.persons, "sampler_sdf": model.resolved_sampler_sdf_mode(0),
                        "parallelism": ("single GPU" if not dist else
                                        f"ray-sharded dp{world}: one frame per step, convergence groups dealt on a diagonal lattice, "
                                        f"all_gather of the image on every rank" if args.mode == "ray" else

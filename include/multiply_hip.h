@@ -80,6 +80,14 @@ int mp_pack_layers(const MpPackLayer* table, int n_layers, int ks_in, void* stre
 int mp_mlp_sdf(const MpNet* net, const void* wpack, const float* bias, const float* xc, const int* worklist,
                const int* count, int max_count, float* sdf_out, void* stream);
 
+/* mp_mlp_sdf_x2: the same queries with SPLIT ACTIVATIONS (round 6; the sampler's default, `Multiply.sampler_sdf_mode = 'f16x2'`):
+ * same arguments, same packed half-precision weights and bias table, but every activation travels as two halves x = hi + lo
+ * (22 mantissa bits) and a product is two MFMAs, W_h x_h + W_h x_l, with fp32 accumulation and an fp32 softplus.  The error
+ * against the fp32 reference network drops from ~1e-3 to ~1e-4 (what is left is the rounding of the weights), the depths the
+ * reference's sampler derives from these values (ray_sampler.py:85-94, multiply.py:137-151) agree accordingly. */
+int mp_mlp_sdf_x2(const MpNet* net, const void* wpack, const float* bias, const float* xc, const int* worklist,
+                  const int* count, int max_count, float* sdf_out, void* stream);
+
 /* mp_mlp_full: ImplicitNet.forward, all 1+256 outputs, for callers outside the fused renderer
  * (multiply_model.py:941-945 query_oc).  d_in = 3 (multires 6) or 4 (multires 10). out [n][257]. */
 int mp_mlp_full(const MpNet* net, const void* wpack, const float* bias, const float* x, int d_in, int n,

@@ -127,6 +127,61 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_sdf(const NetDesc net, const
     }
 }
 
+// ------------------------------------------------------------------------------------------------ sdf only, split activations
+// The sampler's queries at an order of magnitude below the half-precision kernel's error, for twice its time (round 6; DESIGN.md
+// section 4): the SAME packed half-precision weights and bias table as k_mlp_sdf, but a wave carries 16 points whose activations
+// travel as two halves, x = hi + lo, in its two column blocks (mlp_core.hpp HID_SOFTPLUS_X2): W_h x_h + W_h x_l, fp32 softplus.
+// Fourier features from sincosf per octave in fp32 (the half-precision kernel doubles the angle), split like the activations.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_mlp_sdf_x2(const NetDesc net, const char* __restrict__ wpack,
+                                                           const float* __restrict__ bias, const float* __restrict__ xc,
+                                                           const int* __restrict__ worklist,
+                                                           const int* __restrict__ count_p, int max_count,
+                                                           float* __restrict__ sdf_out) {
+    constexpr int KS_IN = 2, NB = 2, WPTS = 16, TILE = WPTS * WAVES;
+    using L = Lds<KS_IN, NB, WAVES>;               // 32 staging rows per wave: rows 0..15 = hi, 16..31 = lo of its 16 points
+    constexpr int NF = 39, STR = in_stride(KS_IN);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int count = count_p ? min(*count_p, max_count) : max_count;
+    float* bias_lds = (float*)(smem + L::bias0);
+    op_t* stage = (op_t*)(smem + L::stage) + wave * L::PTS * STR;
+    load_bias(net, bias, bias_lds);
+    for (int t = blockIdx.x; t * TILE < count; t += gridDim.x) {
+        const int w = t * TILE + wave * WPTS + j;
+        const int id = w < count ? (worklist ? worklist[w] : w) : -1;    // every lane knows the id of point lane & 15
+        {
+            op_t* rh = stage + j * STR;
+            op_t* rl = stage + (16 + j) * STR;
+            auto put = [&](int f, float v) {
+                const op_t hi = (op_t)v;
+                rh[f] = hi;
+                rl[f] = (op_t)(v - (float)hi);
+            };
+            if (g < 3) {             // lanes of group g: axis g of point j -- x, then sin / cos of x 2^k (embedders.py layout)
+                const float x = id >= 0 ? xc[3 * (size_t)id + g] : 0.0f;
+                put(g, x);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    float sn, cs;
+                    sincosf(x * (float)(1 << k), &sn, &cs);
+                    put(3 + 6 * k + g, sn);
+                    put(3 + 6 * k + 3 + g, cs);
+                }
+            } else {
+#pragma unroll
+                for (int f = NF; f < KS_IN * 32; ++f) { rh[f] = (op_t)0.0f; rl[f] = (op_t)0.0f; }
+            }
+        }
+        opx8 Bcur[KS_REG][NB];
+        f32x4 out[NB];
+        zero_b<NB>(Bcur);
+        prologue<KS_IN, WAVES>(net, wpack, smem + L::ring, wave, lane);  // barrier inside: staging rows visible
+        run_net<NB, false, KS_IN, HID_SOFTPLUS_X2, WAVES>(net, wpack, bias_lds, smem + L::ring, Bcur, stage, out, wave, lane);
+        if (lane < 16 && id >= 0) sdf_out[id] = out[0][0] + out[1][0];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ all outputs
 template <int D_IN, int LFREQ, int KS_IN, int NB, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_mlp_full(const NetDesc net, const char* __restrict__ wpack,
@@ -472,6 +527,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_color(const NetDesc net, con
     op_t* stage = (op_t*)(smem + L::stage) + wave * L::PTS * in_stride(KS_IN);
     load_bias(net, bias, bias_lds);
     for (int t = blockIdx.x; t * L::TILE < count; t += gridDim.x) {
+        MP_STAMP_AT(HID_RELU, 120, 0);
         const int w0 = t * L::TILE + wave * L::PTS;   // first work item of this wave
         const int tile = w0 / 64, nb0 = (w0 % 64) / 16;
         const int w = w0 + lane;
@@ -488,6 +544,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_color(const NetDesc net, con
                 }
             }
         }
+        MP_STAMP_AT(HID_RELU, 120, 1);
         opx8 Bcur[KS_REG][NB];
         f32x4 out[NB];
         const bool live = w0 < count;
@@ -509,6 +566,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_color(const NetDesc net, con
                 for (int c = 0; c < 3; ++c) rgb_out[3 * (size_t)pid + c] = 1.0f / (1.0f + __expf(-out[nb][c]));
             }
         }
+        MP_STAMP_AT(HID_RELU, 121, 0);
     }
 }
 
@@ -660,6 +718,20 @@ extern "C" int mp_mlp_sdf(const MpNet* net, const void* wpack, const float* bias
     hipLaunchKernelGGL((k_mlp_sdf<PNB, PWAVES>), dim3(grid_for((max_count + L::TILE - 1) / L::TILE, 1)),
                        dim3(PWAVES * 64), L::total, st, d, (const char*)wpack, bias, xc, worklist, count, max_count,
                        sdf_out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mp_mlp_sdf_x2(const MpNet* net, const void* wpack, const float* bias, const float* xc,
+                             const int* worklist, const int* count, int max_count, float* sdf_out, void* stream) {
+    if (max_count <= 0) return 0;
+    if (!net_ok(net)) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    using L = Lds<2, PNB, PWAVES>;
+    constexpr int TILE = 16 * PWAVES;
+    MP_LDS_ATTR((k_mlp_sdf_x2<PWAVES>), L::total);
+    const NetDesc d = as_desc(net);
+    hipLaunchKernelGGL((k_mlp_sdf_x2<PWAVES>), dim3(grid_for((max_count + TILE - 1) / TILE, 1)), dim3(PWAVES * 64), L::total, st,
+                       d, (const char*)wpack, bias, xc, worklist, count, max_count, sdf_out);
     return (int)hipGetLastError();
 }
 

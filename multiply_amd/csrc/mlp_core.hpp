@@ -114,6 +114,17 @@ __device__ __forceinline__ void issue_chunk(const char* __restrict__ wpack, char
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// Weight DMA of the phase-separated stream: issued by the EARLY waves at the tail of their V phase (round 6, default) or -- -DMP_DMA_LATE,
+// rounds 2-5 -- by the late waves at the head of theirs.  Same-box A/B (profiles/r06_early_dma_ab.txt): sampler SDF -2.6 %, forward
+// sweep -2 %, colour -1 %, reverse sweep 0, mp_tf_sdf_val -3...5 %.
+#if !defined(MP_DMA_LATE) && !defined(MP_DMA_EARLY)
+#define MP_DMA_EARLY 1
+#endif
+#ifdef MP_EXP_NOMFMA   // ablation (timing only, results are wrong): no matrix instructions
+#define MP_MFMA_F16(a, b, c, x, y, z) (c)
+#else
+#define MP_MFMA_F16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z)
+#endif
 
 #ifdef MP_EXP_STAMP   // ablation tooling: shader-clock stamps of workgroup 0 at every chunk boundary (mp_debug_stamps)
 __device__ unsigned long long mp_stamps[8 * 128 * 4];
@@ -189,7 +200,12 @@ struct NextB {
 //   [layer][K step][column block][lane][8 halves]  (one 16 B store per lane when a K step's operand is complete)
 // HID_SIGMUL: the "activation" is a multiplication by such a stored sigmoid: the reverse sweep of reverse-mode
 //   differentiation runs through the same core with the transposed weights.
-enum Hidden : int { HID_SOFTPLUS = 0, HID_RELU = 1, HID_SOFTPLUS_SAVE = 2, HID_SIGMUL = 3 };
+// HID_SOFTPLUS_X2 (round 6): "split activations" -- the wave's two column blocks are the HIGH and the LOW half-precision part of
+//   the SAME 16 points' activations (x = hi + lo, |lo| <= 2^-11 |x|: 22 mantissa bits), both multiplied by the same half-precision
+//   weight tile: W_h x_h + W_h x_l, two MFMAs per product, accumulated in fp32; the softplus runs in fp32 on the sum of the two
+//   accumulators and is split again.  What is left of the half-precision kernel's error is the rounding of the WEIGHTS, a tenth of
+//   it (tools/sdf_split_study.py: the activation rounding is coherent from layer to layer, the weight rounding averages out).
+enum Hidden : int { HID_SOFTPLUS = 0, HID_RELU = 1, HID_SOFTPLUS_SAVE = 2, HID_SIGMUL = 3, HID_SOFTPLUS_X2 = 4 };
 struct SigIO {
     char* base;       // this wave's sigmoid block of the current tile
     int layer_bytes;  // bytes per layer in it (= 8 * NB * 1024)
@@ -615,6 +631,29 @@ __device__ __forceinline__ void pp_program(ActRegs8& a, const ActConst& k, const
     }
 }
 
+// V phase of HID_SOFTPLUS_X2: fp32 softplus (scaled units, base 2) of the chunk's 8 rows per lane, z' = (W_h x_h) + (W_h x_l), and the
+// split of the result into the next layer's two operand blocks: hi = half(h'), lo = half(h' - hi).  Plain C++ between the two
+// scheduling barriers of the V phase: eight independent chains, the compiler interleaves them and knows the transcendental hazards.
+template <typename NB_T>
+__device__ __forceinline__ void x2_program(const f32x4 (&acc)[CHUNK_MB][2], NB_T& Bn, int c) {
+    float h[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float z = acc[q >> 2][0][q & 3] + acc[q >> 2][1][q & 3];
+        const float u = __builtin_amdgcn_exp2f(-__builtin_fabsf(z));
+        h[q] = __builtin_fmaxf(z, 0.0f) + __builtin_amdgcn_logf(1.0f + u);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {          // row pair j = p & 1 of 16-row block mbl = p >> 1
+        const h2 hi = to_h2(h[2 * p], h[2 * p + 1]);
+        const h2 lo = to_h2(h[2 * p] - (float)hi[0], h[2 * p + 1] - (float)hi[1]);
+        if (c < KS_REG) {
+            Bn.put(c, 0, p >> 1, p & 1, hi);
+            Bn.put(c, 1, p >> 1, p & 1, lo);
+        }
+    }
+}
+
 // Which weight chunks have register-fed / input-fed K steps (a chunk's unused tiles are never fetched): bit ci of the
 // two masks, built once per network from the layer table.
 struct ChunkMasks {
@@ -779,7 +818,7 @@ __device__ __forceinline__ void run_layer_pp(const NetDesc& net, const LayerDesc
                 f32x4 bv = (f32x4){0, 0, 0, 0};
                 if constexpr (BIAS) bv = *(const f32x4*)(bl + (2 * c + mbl) * 16);
                 acc[mbl][0] = bv;
-                acc[mbl][1] = bv;
+                acc[mbl][1] = HID == HID_SOFTPLUS_X2 ? (f32x4){0, 0, 0, 0} : bv;   // X2: both blocks are the same points (hi | lo)
             }
             if (L.use_reg) {   // tiles 0 .. PF-1 are in the queue already (loaded at the end of the previous chunk)
 #pragma unroll
@@ -797,7 +836,7 @@ __device__ __forceinline__ void run_layer_pp(const NetDesc& net, const LayerDesc
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb)
-                        acc[mbl][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, Bcur[ks][nb], acc[mbl][nb], 0, 0, 0);
+                        acc[mbl][nb] = MP_MFMA_F16(a, Bcur[ks][nb], acc[mbl][nb], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -814,7 +853,7 @@ __device__ __forceinline__ void run_layer_pp(const NetDesc& net, const LayerDesc
                             const opx8 a = *(const opx8*)(slot + mbl * mb_bytes(KS_IN) + (KS_REG + ks) * TILE_BYTES);
 #pragma unroll
                             for (int nb = 0; nb < 2; ++nb)
-                                acc[mbl][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bi[nb], acc[mbl][nb], 0, 0, 0);
+                                acc[mbl][nb] = MP_MFMA_F16(a, bi[nb], acc[mbl][nb], 0, 0, 0);
                         }
                     }
                 }
@@ -845,12 +884,16 @@ __device__ __forceinline__ void run_layer_pp(const NetDesc& net, const LayerDesc
                 else dma_wait_all();
             }
             if (late) {
+#ifdef MP_DMA_EARLY
+                __syncthreads();   // the late waves issue no DMA in this variant: nothing of theirs to wait for
+#else
                 // every DMA piece this wave issued (one whole M phase ago) has landed; every wave is done with chunk ci:
                 // its ring slot is free for chunk ci + 3
                 if constexpr (!REV) dma_wait_all();
                 __syncthreads();
 #ifndef MP_EXP_NOLOAD
                 if (ci + 3 <= pp_last) pp_issue<KS_IN>(wpack, wring, ci + 3, ring_pos, cm, dl);   // (ci + 3) % 3 == ring_pos
+#endif
 #endif
                 MP_STAMP(2);
             }
@@ -861,7 +904,11 @@ __device__ __forceinline__ void run_layer_pp(const NetDesc& net, const LayerDesc
 #ifdef MP_EXP_NOV   // ablation: no V phase (accumulators kept alive)
                 asm volatile("" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1]));
 #else
-                pp_program<HID, HIDDEN, 0>(a, kact, acc, Bn, c, sg);
+                if constexpr (HID == HID_SOFTPLUS_X2) {
+                    if constexpr (HIDDEN) x2_program(acc, Bn, c);   // the linear output layer: `out` holds the two partial sums
+                } else {
+                    pp_program<HID, HIDDEN, 0>(a, kact, acc, Bn, c, sg);
+                }
 #endif
                 if constexpr (HID == HID_SOFTPLUS_SAVE && HIDDEN) {
 #pragma unroll
@@ -878,7 +925,21 @@ __device__ __forceinline__ void run_layer_pp(const NetDesc& net, const LayerDesc
             }
             if (!late) {
                 MP_STAMP(2);
-                __syncthreads();   // the early waves issue no DMA: nothing to wait for (their stores need no wait)
+#ifdef MP_DMA_EARLY
+                // Variant (round 6): the EARLY waves issue the weight DMA, at the tail of their V phase -- where they otherwise
+                // wait at the barrier for the late waves, whose [barrier, DMA issue, V, M] chain is the chunk's critical path.
+                // Behind the barrier of chunk ci - 1 (passed at the tail of the previous iteration) slot (ci - 1) % 3 is free:
+                // chunk ci + 2 goes there; it is first read behind the barrier of chunk ci + 1, before which this wave waits
+                // for it (the wait below, one iteration from now).  The forward sweep's sigmoid stores of THIS V phase are the
+                // youngest operations in flight: the wait is counted so that it does not include them.
+                if constexpr (HID == HID_SOFTPLUS_SAVE && HIDDEN) __builtin_amdgcn_s_waitcnt(0x0F70 | (SIG8 ? 1 : 2));
+                else if constexpr (!REV) dma_wait_all();
+#ifndef MP_EXP_NOLOAD
+                if (ci >= 1 && ci + 2 <= pp_last)
+                    pp_issue<KS_IN>(wpack, wring, ci + 2, ring_pos == 0 ? RING_SLOTS - 1 : ring_pos - 1, cm, dl);
+#endif
+#endif
+                __syncthreads();   // default: the early waves issue no DMA: nothing to wait for (their stores need no wait)
             }
             MP_STAMP(3);
             // the next chunk's first tiles (complete in the ring: both kinds of wave are past the barrier behind M(c))
@@ -1002,7 +1063,7 @@ __device__ __forceinline__ void run_layer(const NetDesc& net, const LayerDesc L,
             MP_LDS_STMT                                                                                               \
         }                                                                                                             \
         _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                             \
-            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, Bcur[KS][nb], acc[nb], 0, 0, 0);                     \
+            acc[nb] = MP_MFMA_F16(a, Bcur[KS][nb], acc[nb], 0, 0, 0);                     \
         MP_ACT_STMT(KS)                                                                                               \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                            \
         _Pragma("unroll") for (int q = 0; q < NB; ++q) {                                                              \
@@ -1033,7 +1094,7 @@ __device__ __forceinline__ void run_layer(const NetDesc& net, const LayerDesc L,
                         for (int nb = 0; nb < NB; ++nb) {
                             const opx8 bi = *(const opx8*)(stage_wave + (nb * 16 + (lane & 15)) * in_stride(KS_IN) +
                                                                ks * 32 + g * 8);
-                            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bi, acc[nb], 0, 0, 0);
+                            acc[nb] = MP_MFMA_F16(a, bi, acc[nb], 0, 0, 0);
                         }
                     }
                 }

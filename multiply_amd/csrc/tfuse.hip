@@ -316,7 +316,11 @@ __device__ __forceinline__ void wait_vm_rt(int n) {
 }
 __device__ __forceinline__ void touch4(const f32x4& v) { asm volatile("" ::"v"(v)); }
 
-template <class Epi, int MAXC, bool HAS_IN>
+// EARLY_DMA (round 6; the value-only kernel -- its activation code issues no stores; -DMP_DMA_LATE: the round-5 schedule): the weight DMA is issued by the EARLY waves
+// at the tail of their activation code -- where they otherwise wait at the barrier for the late waves, whose [barrier, DMA issue,
+// activation, products] chain is the chunk's critical path.  Behind barrier(ci - 1) slot (ci - 1) % 3 is free: chunk ci + 2 goes
+// there, and the issuing wave waits for it one iteration later (counted: everything but the prefetch loads just issued).
+template <class Epi, int MAXC, bool HAS_IN, bool EARLY_DMA = false>
 __device__ __forceinline__ void tf_layer(Ctx& cx, Epi& ep, int n_chunk, bool use_reg, bool use_in, BReg& Bcur, BReg& Bnext) {
     int npref = ep.prefetch(cx, 0);
     ep.rotate();
@@ -328,13 +332,22 @@ __device__ __forceinline__ void tf_layer(Ctx& cx, Epi& ep, int n_chunk, bool use
             tf_mma<HAS_IN>(cx, use_reg, use_in, Bcur, acc);
             ep.touch();
             if (cx.late) {
-                wait_vm_rt(npref);
+                if constexpr (!EARLY_DMA) wait_vm_rt(npref);
                 __syncthreads();
-                if (cx.ci + RING < cx.n_total) tf_issue<4>(cx, cx.ci + RING, cx.ring_pos, cx.wave - 4);
+                if constexpr (!EARLY_DMA) {
+                    if (cx.ci + RING < cx.n_total) tf_issue<4>(cx, cx.ci + RING, cx.ring_pos, cx.wave - 4);
+                }
             }
             npref = c + 1 < n_chunk ? ep.prefetch(cx, c + 1) : 0;
             ep.run(cx, c, acc, Bnext);
             ep.rotate();
+            if constexpr (EARLY_DMA) {
+                if (!cx.late) {
+                    wait_vm_rt(npref);
+                    if (cx.ci >= 1 && cx.ci + RING - 1 < cx.n_total)
+                        tf_issue<4>(cx, cx.ci + RING - 1, cx.ring_pos == 0 ? RING - 1 : cx.ring_pos - 1, cx.wave);
+                }
+            }
             if (!cx.late) __syncthreads();
             ++cx.ci;
             cx.ring_pos = cx.ring_pos + 1 == RING ? 0 : cx.ring_pos + 1;
@@ -678,7 +691,11 @@ __global__ __launch_bounds__(TF_THREADS) void k_tf_sdf_val(TfValArgs a) {
             ep.linear = l == 8;
             ep.sdf_out = a.sdf_out;
             ep.id = id;
+#ifndef MP_DMA_LATE
+            tf_layer<EpiV, 8, true, true>(cx, ep, l == 8 ? 1 : 8, l > 0, l == 0 || l == 4, Bcur, Bnext);
+#else
             tf_layer<EpiV, 8, true>(cx, ep, l == 8 ? 1 : 8, l > 0, l == 0 || l == 4, Bcur, Bnext);
+#endif
         }
         __syncthreads();      // the ring and the input blocks are rebuilt by the next tile
     }

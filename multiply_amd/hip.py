@@ -513,15 +513,17 @@ def implicit_forward(net, x, cond_vec):
     return out
 
 
-def implicit_sdf(net, x_c, cond_vec):
-    """sdf column of the foreground ImplicitNet at canonical points (N,3) -> (N,)."""
+def implicit_sdf(net, x_c, cond_vec, mode="f16"):
+    """sdf column of the foreground ImplicitNet at canonical points (N,3) -> (N,).  mode 'f16' (mp_mlp_sdf) | 'f16x2' (split
+    activations on the same packed weights, mp_mlp_sdf_x2)."""
     require_device()
     x_c = x_c.detach().float().contiguous()
     pk = packed(net, "sdf", 2)
     pk.refresh(cond_vec.detach().float().contiguous())
     out = torch.empty(x_c.shape[0], dtype=torch.float32, device=x_c.device)
-    check(lib().mp_mlp_sdf(C.byref(pk.net), ptr(pk.wpack), ptr(pk.bias), ptr(x_c), None, None, x_c.shape[0],
-                           ptr(out), stream()), "mp_mlp_sdf")
+    fn = {"f16": lib().mp_mlp_sdf, "f16x2": lib().mp_mlp_sdf_x2}[mode]
+    check(fn(C.byref(pk.net), ptr(pk.wpack), ptr(pk.bias), ptr(x_c), None, None, x_c.shape[0], ptr(out), stream()),
+          "mp_mlp_sdf" + ("_x2" if mode == "f16x2" else ""))
     return out
 
 

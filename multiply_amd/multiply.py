@@ -131,7 +131,11 @@ class Multiply(nn.Module):
         # ray-sharded data-parallel training: a torch.distributed process group (or True = the default group) over which the
         # sampler's per-iteration convergence vote is all-reduced (MAX) -- see _sample_person; None: the vote is per process
         self.sampler_vote_group = None
-        self.sampler_sdf_mode = os.environ.get("MP_SAMPLER_SDF", "f16")      # 'f16' (product) | 'bf16x3' (measurement: _sampler_sdf)
+        # arithmetic of the sampler's network queries (_sampler_sdf): 'auto' (default, round 6) = 'bf16x3' -- near-fp32: the depths
+        # then agree with the fp32 reference to 1e-3 instead of 2e-2 and the grazing-ray tail of the render disappears -- for the
+        # network shape csrc/tfuse.hip is specialised for (the shipped configs), 'f16x2' (split activations, any shape) otherwise;
+        # 'f16': the fused half-precision kernel (the round 1-5 default), a third of the query time
+        self.sampler_sdf_mode = os.environ.get("MP_SAMPLER_SDF", "auto")
         self.last_stats = {}
         self.profile = False
         self.phase_events = {}
@@ -457,15 +461,25 @@ class Multiply(nn.Module):
             hip.check(L.mp_sampler_bound(C.byref(s["cfg"]), C.byref(s["state"]), hip.ptr(cx["beta"]), hip.ptr(pp["hit_index"]),
                                          hip.ptr(pp["count"]), Rp, cx["group"], cx["R"], it, st), "mp_sampler_bound")
 
+    def resolved_sampler_sdf_mode(self, p=0):
+        """`sampler_sdf_mode` with 'auto' resolved for person p's network (see __init__)"""
+        mode = getattr(self, "sampler_sdf_mode", "auto")
+        if mode != "auto":
+            return mode
+        from . import train as T
+        return "bf16x3" if T.fused_sdf_supported(self.foreground_implicit_network_list[p]) else "f16x2"
+
     def _sampler_sdf(self, s, it):
-        """the sampler's network queries of iteration `it`: the fused half-precision kernel (csrc/mlp.hip k_mlp_sdf).
-        `self.sampler_sdf_mode = 'bf16x3'` (MP_SAMPLER_SDF): the same worklist through the value sweep of the training path's
-        layer-fused kernel (mp_tf_sdf_val: split-bfloat16 products, fp32 activations, ~2^-16 per product) -- the sampler's depths
-        with near-fp32 queries, ~4x the query time; 'bf16x3-layerwise': the same arithmetic layer by layer
-        (the independent implementation tools/sampler_precision.py first measured with; reads the worklist count on the host)."""
+        """the sampler's network queries of iteration `it` (`self.sampler_sdf_mode`, MP_SAMPLER_SDF):
+        'bf16x3' (what 'auto' resolves to for the shipped network shape): the value sweep of the training path's layer-fused
+        kernel (mp_tf_sdf_val: split-bfloat16 products, fp32 activations, ~2^-16 per product) -- near-fp32 queries, 3x the time
+        of the half-precision kernel; 'f16x2': split activations on the half-precision weights (mp_mlp_sdf_x2, 2x the time, a
+        quarter of the mean depth error, any network shape); 'f16': the fused half-precision kernel (csrc/mlp.hip k_mlp_sdf);
+        'bf16x3-layerwise': the bf16x3 arithmetic layer by layer (the independent implementation tools/sampler_precision.py
+        first measured with; reads the worklist count on the host)."""
         L, st = hip.lib(), hip.stream()
         pk_sdf, wcount = s["pk_sdf"], s["wcount"]
-        mode = getattr(self, "sampler_sdf_mode", "f16")
+        mode = self.resolved_sampler_sdf_mode(s["p"])
         if mode == "bf16x3":
             # the value sweep of the training path's layer-fused kernel (csrc/tfuse.hip k_tf_sdf_val): same worklist, device-side count
             fs = s.get("fs")
@@ -493,9 +507,13 @@ class Multiply(nn.Module):
                          for c0 in range(0, n, 1 << 18)]
                 s["sdfnew"].view(-1)[idx] = torch.cat(parts)
             return
-        hip.check(L.mp_mlp_sdf(C.byref(pk_sdf.net), hip.ptr(pk_sdf.wpack), hip.ptr(pk_sdf.bias),
-                               hip.ptr(s["xc_new"]), hip.ptr(s["work"]), hip.ptr(wcount[it:it + 1]), s["Rp"] * s["NE"],
-                               hip.ptr(s["sdfnew"]), st), "mp_mlp_sdf")
+        if mode not in ("f16", "f16x2"):
+            raise ValueError(f"sampler_sdf_mode {mode!r}: expected 'f16x2', 'f16', 'bf16x3' or 'bf16x3-layerwise'")
+        # 'f16x2': split activations on the same packed half-precision weights (csrc/mlp.hip k_mlp_sdf_x2)
+        fn = L.mp_mlp_sdf_x2 if mode == "f16x2" else L.mp_mlp_sdf
+        hip.check(fn(C.byref(pk_sdf.net), hip.ptr(pk_sdf.wpack), hip.ptr(pk_sdf.bias),
+                     hip.ptr(s["xc_new"]), hip.ptr(s["work"]), hip.ptr(wcount[it:it + 1]), s["Rp"] * s["NE"],
+                     hip.ptr(s["sdfnew"]), st), "mp_mlp_sdf_x2" if mode == "f16x2" else "mp_mlp_sdf")
 
     def _sampler_resample(self, s, it):
         """iteration `it`, second half: new samples where the bound is not met (or, converged, the final inverse-CDF draw)"""

@@ -24,8 +24,11 @@ def _run(args, env=None):
 
 
 def test_single_gpu_line_has_roofline_and_cpu_baseline():
+    # --cpu-budget-s 0: the wall-time guard of the CPU oracle's render leg at its tightest (a slower host must not turn the headline run
+    # into a driver timeout): the sample stops after the minimum number of rays -- here the whole small sample is below the 4 096-ray
+    # floor, so it completes and says how many rays it did (round 6: checked in THIS run instead of a second 70 s bench run)
     d = _run(["--res", "64", "--steps", "2", "--warmup", "1", "--train-steps", "2", "--train-warmup", "1", "--cpu-rays", "128",
-              "--cpu-train-iters", "1"])
+              "--cpu-train-iters", "1", "--cpu-budget-s", "0"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -33,7 +36,9 @@ def test_single_gpu_line_has_roofline_and_cpu_baseline():
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c and c["parity_rgb_max_abs"] < 8e-3
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c and c["parity_rgb_max_abs"] < 5e-4
+    assert c["rays"] == 128 and c["seconds"] > 0 and "128 rays" in c["sample"]
+    assert d["config"]["sampler_sdf"] == "bf16x3" and len(d["lib_source_sha16"]) == 16
     t = d["train_iter"]
     assert t["ms_per_iter"] > 0 and t["rays_per_iter"] == 512 and t["cpu_baseline"]["value"] > 0 and 0 < t["roofline"]["frac"] < 1
     assert t["dtype"] == "bf16x3" and "dtype_note" in d and t["cpu_baseline"]["parity_grad_rel_worst"] < 2e-2
@@ -74,15 +79,7 @@ def test_single_gpu_line_of_the_four_person_256_sample_workload():
     """BASELINE.json configs[3] on one GPU: `--persons 4 --samples 256` (small frame here), same fields as the headline line"""
     d = _run(["--persons", "4", "--samples", "256", "--res", "48", "--steps", "1", "--warmup", "1", "--train-steps", "0", "--cpu-rays", "96"])
     assert d["config"]["persons"] == 4 and "4-person" in d["config"]["workload"] and "N_samples=256" in d["config"]["workload"]
-    assert 0 < d["roofline"]["frac"] < 1 and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["parity_rgb_max_abs"] < 8e-3
-
-
-def test_cpu_oracle_leg_is_cut_by_the_wall_time_guard():
-    """a slower host must not turn the headline run into a driver timeout: with a zero budget the oracle's render sample stops after the
-    minimum number of rays (here: the whole small sample is below the 4 096-ray floor, so it completes and says how many rays it did)"""
-    d = _run(["--res", "64", "--steps", "1", "--warmup", "1", "--train-steps", "0", "--cpu-rays", "1024", "--cpu-budget-s", "0"])
-    c = d["cpu_baseline"]
-    assert c["rays"] == 1024 and c["seconds"] > 0 and "1024 rays" in c["sample"]
+    assert 0 < d["roofline"]["frac"] < 1 and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["parity_rgb_max_abs"] < 5e-4
 
 
 def test_two_ranks_over_rccl_when_the_box_has_two_gpus():

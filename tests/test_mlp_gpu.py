@@ -2,6 +2,8 @@
 
 Arithmetic: f16 MFMA operands (fp32 accumulation, half-precision activations); the reference is fp32 end to end, so the
 tolerances are the stated half-precision tolerances of tests/tolerances.py: <= 5x the errors measured on MI355X."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -78,6 +80,40 @@ def test_precise_sdf_value_kernel(nets_gpu):
     out2 = torch.full((n,), -7.0, device="cuda")
     hip.check(L.mp_tf_sdf_val(hip.ptr(fs.wpack), hip.ptr(fs.bias_all), hip.ptr(xd), hip.ptr(work), hip.ptr(cnt), k + 300, hip.ptr(out2),
                               hip.stream()), "val")
+    torch.cuda.synchronize()
+    sel = ids[:k].long()
+    assert torch.equal(out2[sel], out[sel])
+    rest = torch.ones(n, dtype=torch.bool, device="cuda")
+    rest[sel] = False
+    assert bool((out2[rest] == -7.0).all())
+
+
+def test_split_activation_sdf_kernel(nets_gpu):
+    """mp_mlp_sdf_x2 (csrc/mlp.hip k_mlp_sdf_x2, round 6): the sampler's default queries -- the half-precision kernel's packed weights,
+    activations as two halves, fp32 softplus -- against the fp32 oracle: an order of magnitude below the f16 kernel's error on the
+    same points; worklist / device-count handling like mp_mlp_sdf (untouched entries stay untouched)"""
+    from multiply_amd import hip
+    m, sd = nets_gpu
+    rng = np.random.RandomState(12)
+    n = 5003                                                     # not a multiple of the 128-point tile
+    x = torch.tensor(rng.uniform(-0.9, 0.9, (n, 3)), dtype=torch.float32)
+    cond = torch.tensor(rng.normal(0, 0.1, 69), dtype=torch.float32)
+    want = O.implicit_forward(sd, "foreground_implicit_network_list.1.", x, cond, multires=6)[:, 0]
+    net = m.foreground_implicit_network_list[1]
+    xd = x.cuda()
+    out = hip.implicit_sdf(net, xd, cond.cuda(), mode="f16x2")
+    f16 = hip.implicit_sdf(net, xd, cond.cuda())
+    torch.cuda.synchronize()
+    e2, e1 = report("split-activation sdf kernel", out, want), report("f16 sdf kernel, same points", f16, want)
+    assert e2 < TOL.MLP["fg_sdf_x2"] and e1 > 2.5 * e2
+    L, pk = hip.lib(), hip.packed(net, "sdf", 2)
+    ids = torch.tensor(rng.permutation(np.arange(0, n, 3)), dtype=torch.int32).cuda()
+    k = 1000
+    work = torch.cat([ids[:k], torch.zeros(300, dtype=torch.int32, device="cuda")])
+    cnt = torch.tensor([k], dtype=torch.int32, device="cuda")
+    out2 = torch.full((n,), -7.0, device="cuda")
+    hip.check(L.mp_mlp_sdf_x2(C.byref(pk.net), hip.ptr(pk.wpack), hip.ptr(pk.bias), hip.ptr(xd), hip.ptr(work), hip.ptr(cnt), k + 300,
+                              hip.ptr(out2), hip.stream()), "mp_mlp_sdf_x2")
     torch.cuda.synchronize()
     sel = ids[:k].long()
     assert torch.equal(out2[sel], out[sel])

@@ -109,28 +109,32 @@ def test_forward_eval_two_persons_128_samples_headline_config():
             if not empty[p]:
                 z_or[p].append(torch.cat([w["z_vals"][p], w["z_max"][p][:, None]], 1))
     print("[info] hit rays per person", n_hit, "of", R)
+    # the DEFAULT path (round 6): sampler queries at near-fp32 precision (sampler_sdf_mode 'auto' -> 'bf16x3', mp_tf_sdf_val)
+    assert model.resolved_sampler_sdf_mode(0) == "bf16x3"
     for k, tol in TOL.EVAL.items():
         if k in parts:
             assert TOL.within(report("headline N=128 " + k, got[k], torch.cat(parts[k], 0)), tol), k
-    # round 5: the same render with the sampler's queries at near-fp32 precision (sampler_sdf_mode = 'bf16x3', mp_tf_sdf_val):
-    # depths and outputs against the same oracle (tests/tolerances.py EVAL_PRECISE / Z_VALS_PRECISE)
-    z_f16 = [model._last["per"][p]["zfinal"][:n_hit[p]].clone() for p in range(2)]
-    model.sampler_sdf_mode = "bf16x3"
-    got_p = model(_gpu(inp))
-    torch.cuda.synchronize()
-    model.sampler_sdf_mode = "f16"
-    assert list(model.last_stats["n_hit"]) == list(n_hit)
     for p in range(2):
         zo = torch.cat(z_or[p], 0)
-        report(f"headline N=128 z_vals person {p}, f16 sampler", z_f16[p], zo)
-        st = report(f"headline N=128 z_vals person {p}, bf16x3 sampler", model._last["per"][p]["zfinal"][:n_hit[p]], zo)
+        st = report(f"headline N=128 z_vals person {p}", model._last["per"][p]["zfinal"][:n_hit[p]], zo)
         zt = TOL.Z_VALS_PRECISE
         ray_err = (model._last["per"][p]["zfinal"][:n_hit[p]].cpu() - zo).abs().max(1).values
         assert st[1] < zt["mean"] and int((ray_err > zt["bulk"]).sum()) <= max(2, int(zt["frac"] * len(ray_err))), (st[0], st[1])
     for k, tol in TOL.EVAL_PRECISE.items():
-        st = report("headline N=128, bf16x3 sampler: " + k, got_p[k], torch.cat(parts[k], 0))
-        err = (got_p[k].double().cpu() - torch.cat(parts[k], 0).double()).abs().nan_to_num()
+        st = report("headline N=128, maxima: " + k, got[k], torch.cat(parts[k], 0))
+        err = (got[k].double().cpu() - torch.cat(parts[k], 0).double()).abs().nan_to_num()
         assert TOL.within_precise(err, tol), (k, st[0])
+    # the opt-out: the half-precision sampler kernel (the round 1-5 default), against its own distribution bounds
+    model.sampler_sdf_mode = "f16"
+    got_h = model(_gpu(inp))
+    torch.cuda.synchronize()
+    model.sampler_sdf_mode = "auto"
+    assert list(model.last_stats["n_hit"]) == list(n_hit)
+    for p in range(2):
+        report(f"headline N=128 z_vals person {p}, f16 sampler", model._last["per"][p]["zfinal"][:n_hit[p]], torch.cat(z_or[p], 0))
+    for k, tol in TOL.EVAL_F16.items():
+        if k in parts:
+            assert TOL.within(report("headline N=128, f16 sampler: " + k, got_h[k], torch.cat(parts[k], 0)), tol), k
 
 
 def test_forward_eval_box_cull_is_conservative():
@@ -165,14 +169,15 @@ def test_forward_eval_box_cull_is_conservative():
 
 def test_forward_eval_four_persons_256_samples():
     """BASELINE.json configs[3] as a parity case: 4-person synthetic scene, N_samples = 256 (289 composited samples per ray
-    and person), own box cull, 32 x 32 = 1 024 rays (round 5; 81 before).  Same tolerances as the 2-person test."""
+    and person), own box cull, 26 x 26 = 676 rays (round 5: 1 024; round 6: the suite's time budget -- the oracle needs 75 ms per
+    ray here; 81 before round 5).  Same tolerances as the 2-person test."""
     import warnings
     warnings.filterwarnings("ignore")
     from multiply_amd.config import load_config
     from multiply_amd.multiply import Multiply
     from multiply_amd.synthetic import make_scene, make_smpl_tables
     tables = make_smpl_tables(0)
-    sc = make_scene(4, seed=1, H=32, W=32)
+    sc = make_scene(4, seed=1, H=26, W=26)
     opt = load_config()
     opt.ray_sampler.N_samples = 256
     opt.ray_sampler.N_samples_eval = 256
@@ -188,8 +193,8 @@ def test_forward_eval_four_persons_256_samples():
     oracle = O.MultiplyOracle(sd, tables, sc["smpl_params"][0, :, 76:], O.SamplerCfg(N_samples=256, N_samples_eval=256))
     want = oracle.forward_eval(inp, hit)
     print("[info] hit rays per person", model.last_stats["n_hit"], "iterations", want["iters"])
-    assert got["acc_person_list"].shape == (1024, 4)
-    assert all(n > 100 for n in model.last_stats["n_hit"]), model.last_stats["n_hit"]      # every person is actually rendered
+    assert got["acc_person_list"].shape == (676, 4)
+    assert all(n > 60 for n in model.last_stats["n_hit"]), model.last_stats["n_hit"]      # every person is actually rendered
     assert TOL.within(report("4p rgb_values", got["rgb_values"], want["rgb_values"]), TOL.EVAL["rgb_values"])
     assert TOL.within(report("4p acc_map", got["acc_map"], want["acc_map"]), TOL.EVAL["acc_map"])
     assert TOL.within(report("4p acc_person_list", got["acc_person_list"], want["acc_person_list"]), TOL.EVAL["acc_person_list"])

@@ -37,6 +37,18 @@ if which in ("all", "shade"):
 if which in ("all", "sdf"):
     t = timeit(lambda: hip.implicit_sdf(imp, x, cond))
     print(f"sdf only   : {n / t / 1e6:.1f} Mpts/s, algorithmic {2 * M_IMP * n / t / 1e12:.0f} TFLOP/s  ({t * 1e3:.1f} ms)")
+if which in ("all", "sdf", "sdf_x2"):
+    t = timeit(lambda: hip.implicit_sdf(imp, x, cond, mode="f16x2"))
+    print(f"sdf, split activations (mp_mlp_sdf_x2): {n / t / 1e6:.1f} Mpts/s, algorithmic {2 * M_IMP * n / t / 1e12:.0f} TFLOP/s, "
+          f"executed {4 * M_IMP * n / t / 1e12:.0f}  ({t * 1e3:.1f} ms)")
+if which in ("all", "sdf", "sdf_b3"):
+    from multiply_amd import train as T
+    fs = T.fused_sdf_state(imp).refresh(cond)
+    outb = torch.empty(n, device="cuda")
+    t = timeit(lambda: hip.check(hip.lib().mp_tf_sdf_val(hip.ptr(fs.wpack), hip.ptr(fs.bias_all), hip.ptr(x), None, None, n, hip.ptr(outb),
+                                                          hip.stream()), "val"))
+    print(f"sdf, split bf16 x3 (mp_tf_sdf_val): {n / t / 1e6:.1f} Mpts/s, algorithmic {2 * M_IMP * n / t / 1e12:.0f} TFLOP/s, "
+          f"executed {6 * M_IMP * n / t / 1e12:.0f}  ({t * 1e3:.1f} ms)")
 if which in ("all", "shade_forward"):
     t = timeit(lambda: hip.shade_points(imp, ren, x, jinv, cond, mode="forward"))
     print(f"shade+color (forward-mode kernel): {n / t / 1e6:.1f} Mpts/s  ({t * 1e3:.1f} ms)")

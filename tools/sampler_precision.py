@@ -59,7 +59,7 @@ def main():
              f"N_samples 128), density beta {float(model.density.beta):.3g}, fp32 oracle {t_or:.0f} s; shading on the product's f16 kernels in every row",
              f"{'sampler sdf':10s} {'z max':>9s} {'z mean':>9s} | {'acc max':>9s} {'acc>1e-2':>8s} {'acc>3e-3':>8s} | {'nrm max':>9s} {'nrm>1e-2':>8s} | "
              f"{'rgb max':>9s} | sampler-sdf ms (these rays)"]
-    for mode in ("f16", "bf16x3", "bf16x3-layerwise"):
+    for mode in (sys.argv[3].split(",") if len(sys.argv) > 3 else ("f16", "f16x2", "bf16x3")):
         model.sampler_sdf_mode = mode
         zerr, err = [], {k: [] for k in keys}
         model.profile = True
@@ -81,8 +81,8 @@ def main():
                      f"{int((e['acc_map'] > 1e-2).sum()):8d} {int((e['acc_map'] > 3e-3).sum()):8d} | {float(e['normal_values'].max()):9.2e} "
                      f"{int((e['normal_values'] > 1e-2).sum()):8d} | {float(e['rgb_values'].max()):9.2e} | {ph.get('sampler_mlp_sdf', (0, 0.0))[1]:.2f}")
     model.sampler_sdf_mode = "f16"
-    lines.append("(third row: bf16x3-layerwise = the same arithmetic through the layer-wise GEMMs with a host read per iteration -- the "
-                 "independent implementation the fused kernel of row 2 is checked against)")
+    lines.append("(f16x2: split activations on the half-precision weights, mp_mlp_sdf_x2; bf16x3: mp_tf_sdf_val; bf16x3-layerwise: the same "
+                 "arithmetic through the layer-wise GEMMs with a host read per iteration)")
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/sampler_precision.txt" if beta is None else f"gpurun_out/sampler_precision_beta{beta:g}.txt", "w") as f:
         f.write("\n".join(lines) + "\n")

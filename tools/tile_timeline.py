@@ -48,5 +48,6 @@ for c in range(nch):
     for w in (0, 4):
         r.append((int(s[w, c, 0] - t0), int(s[w, c, 1] - s[w, c, 0]), int(s[w, c, 2] - s[w, c, 1]), int(s[w, c, 3] - s[w, c, 2])))
     print(f"  chunk {c:2d}: wave0 @{r[0][0]:7d} {r[0][1:]}   wave4 @{r[1][0]:7d} {r[1][1:]}")
+print("  next tile start ", "(stamps of the LAST tile: its start relative to the previous tile is not recorded)")
 tot = max(s[:, 121, 0].max(), s[:, 120, 3].max()) - t0
 print("tile total", tot, "cycles")
