@@ -89,7 +89,11 @@ __device__ __forceinline__ void lds_dma_16(const void* gsrc_uniform, unsigned la
 // s_waitcnt vmcnt(0) (gfx9 encoding: expcnt 7 and lgkmcnt 15 = "do not wait").  The builtin, not asm text: hipcc's wait
 // insertion pass reads it and learns that ITS OWN global loads (inputs, stored sigmoids) are complete as well, so it
 // does not re-wait for them (with vmcnt(0), i.e. also for the weight stream) inside the next chunk.
+#ifdef MP_EXP_NOWAIT   // ablation (timing only, results are wrong): nobody waits for the weight DMA
+__device__ __forceinline__ void dma_wait_all() {}
+#else
 __device__ __forceinline__ void dma_wait_all() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+#endif
 __device__ __forceinline__ unsigned lds_offset(const void* p) { return (unsigned)(size_t)p; }   // low half of the flat address
 __device__ __forceinline__ const char* uniform_ptr(const char* p) {
     const size_t v = (size_t)p;

@@ -93,9 +93,10 @@ MLP = {                                     # the fused MLP kernels on random po
 # acc_person 5.2e-5 (the 512-ray bench workload after ten Adam steps), grad_theta 1.2e-5)
 TRAIN_FWD_BY_PRECISION = {
     # acc_person_list, round 6: two persons' samples at (nearly) equal depth may be merged in either order -- the per-person opacities then
-    # move by the product of two alphas while their sum does not (measured 4.0e-5 on one ray of 121, acc_map 2.0e-6 on the same run)
-    "f32": {"rgb_values": 8e-6, "acc_map": 8e-6, "acc_person_list": 2e-4, "grad_theta": 5e-6, "normal_values": 8e-6},
-    "bf16x3": {"rgb_values": 8e-6, "acc_map": 5e-5, "acc_person_list": 2e-4, "grad_theta": 5e-5, "normal_values": 5e-5},
+    # move by the product of two alphas while their sum does not, and the composited normal by that product times the difference of the two
+    # normals (measured 4.0e-5 / 4.1e-5 on one ray of 121, acc_map 2.0e-6 on the same run)
+    "f32": {"rgb_values": 8e-6, "acc_map": 8e-6, "acc_person_list": 2e-4, "grad_theta": 5e-6, "normal_values": 2e-4},
+    "bf16x3": {"rgb_values": 8e-6, "acc_map": 5e-5, "acc_person_list": 2e-4, "grad_theta": 5e-5, "normal_values": 2e-4},
 }
 
 
