@@ -103,6 +103,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_sdf(const NetDesc net, const
     load_bias(net, bias, bias_lds);
     for (int t = blockIdx.x; t * L::TILE < count; t += gridDim.x) {
         MP_STAMP_AT(HID_SOFTPLUS, 120, 0);
+        prologue_issue<KS_IN, WAVES>(net, wpack, smem + L::ring, wave, lane);
         const int w = t * L::TILE + wave * L::PTS + lane;
         const int id = (lane < L::PTS && w < count) ? (worklist ? worklist[w] : w) : -1;
         if (lane < L::PTS) {
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_sdf(const NetDesc net, const
         opx8 Bcur[KS_REG][NB];
         f32x4 out[NB];
         zero_b<NB>(Bcur);
-        prologue<KS_IN, WAVES>(net, wpack, smem + L::ring, wave, lane);  // barrier inside: staging rows visible
+        prologue_wait();  // barrier inside: staging rows visible
         MP_STAMP_AT(HID_SOFTPLUS, 120, 2);
         run_net<NB, false, KS_IN, HID_SOFTPLUS, WAVES>(net, wpack, bias_lds, smem + L::ring, Bcur, stage, out, wave, lane);
         MP_STAMP_AT(HID_SOFTPLUS, 120, 3);
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_sdf_x2(const NetDesc net, co
     op_t* stage = (op_t*)(smem + L::stage) + wave * L::PTS * STR;
     load_bias(net, bias, bias_lds);
     for (int t = blockIdx.x; t * TILE < count; t += gridDim.x) {
+        prologue_issue<KS_IN, WAVES>(net, wpack, smem + L::ring, wave, lane);
         const int w = t * TILE + wave * WPTS + j;
         const int id = w < count ? (worklist ? worklist[w] : w) : -1;    // every lane knows the id of point lane & 15
         {
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_sdf_x2(const NetDesc net, co
         opx8 Bcur[KS_REG][NB];
         f32x4 out[NB];
         zero_b<NB>(Bcur);
-        prologue<KS_IN, WAVES>(net, wpack, smem + L::ring, wave, lane);  // barrier inside: staging rows visible
+        prologue_wait();  // barrier inside: staging rows visible
         run_net<NB, false, KS_IN, HID_SOFTPLUS_X2, WAVES>(net, wpack, bias_lds, smem + L::ring, Bcur, stage, out, wave, lane);
         if (lane < 16 && id >= 0) sdf_out[id] = out[0][0] + out[1][0];
     }
@@ -360,6 +362,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_fwdsave(const NetDesc net, c
     load_bias(net, bias, bias_lds);
     constexpr int SIG_LAYER = KS_REG * SIG_CHUNK_BYTES;   // one wave's sigmoids of one layer: 8 (UNORM8) or 16 KiB
     for (int t = blockIdx.x; offset + t * L::TILE < count; t += gridDim.x) {
+        prologue_issue<KS_IN, WAVES>(net, wpack, smem + L::ring, wave, lane);
         const int w = offset + t * L::TILE + wave * L::PTS + lane;
         const int id = (lane < L::PTS && w < count) ? (worklist ? worklist[w] : w) : -1;
         if (lane < L::PTS) {
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_fwdsave(const NetDesc net, c
         opx8 Bcur[KS_REG][NB];
         f32x4 out[NB];
         zero_b<NB>(Bcur);
-        prologue<KS_IN, WAVES>(net, wpack, smem + L::ring, wave, lane);
+        prologue_wait();
         MP_STAMP_AT(HID_SOFTPLUS_SAVE, 120, 2);
         #ifdef MP_EXP_SIGCACHED   // ablation: every tile uses the first workgroup-slots of the buffer (cache resident)
         const SigIO sio = {sigbuf + ((size_t)(blockIdx.x) * WAVES + wave) * (size_t)(8 * SIG_LAYER), SIG_LAYER};
@@ -531,7 +534,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_color(const NetDesc net, con
         const int w0 = t * L::TILE + wave * L::PTS;   // first work item of this wave
         const int tile = w0 / 64, nb0 = (w0 % 64) / 16;
         const int w = w0 + lane;
+        // Order of the tile's memory requests (round 6): the work item's id first (one small load), then the first weight chunks
+        // and the 16 KiB of feature fragments of this wave -- none of them depends on the id -- and only then the id -> position /
+        // normal chain, whose two dependent latencies now run beside the big transfers instead of in front of them.
         const int id = (lane < L::PTS && w < count) ? (worklist ? worklist[w] : w) : -1;
+        prologue_issue<KS_IN, WAVES>(net, wpack, smem + L::ring, wave, lane);
+        opx8 Bcur[KS_REG][NB];
+        const bool live = w0 < count;
+#pragma unroll
+        for (int ks = 0; ks < KS_REG; ++ks)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                Bcur[ks][nb] = live ? *(const opx8*)(feat_frag + (((size_t)tile * KS_REG + ks) * 4 + nb0 + nb) * 1024 + lane * 16)
+                                    : (opx8)(op_t)0.0f;
         if (lane < L::PTS) {
             op_t* row = stage + lane * in_stride(KS_IN);
 #pragma unroll
@@ -545,16 +560,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_mlp_color(const NetDesc net, con
             }
         }
         MP_STAMP_AT(HID_RELU, 120, 1);
-        opx8 Bcur[KS_REG][NB];
         f32x4 out[NB];
-        const bool live = w0 < count;
-#pragma unroll
-        for (int ks = 0; ks < KS_REG; ++ks)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-                Bcur[ks][nb] = live ? *(const opx8*)(feat_frag + (((size_t)tile * KS_REG + ks) * 4 + nb0 + nb) * 1024 + lane * 16)
-                                    : (opx8)(op_t)0.0f;
-        prologue<KS_IN, WAVES>(net, wpack, smem + L::ring, wave, lane);
+        prologue_wait();
         MP_STAMP_AT(HID_RELU, 120, 2);
         run_net<NB, false, KS_IN, HID_RELU, WAVES>(net, wpack, bias_lds, smem + L::ring, Bcur, stage, out, wave, lane);
         MP_STAMP_AT(HID_RELU, 120, 3);
@@ -594,6 +601,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_background(const NetDesc net_imp
     const int n_pts = n_rays * NBG;
     const float ox = cam[0], oy = cam[1], oz = cam[2];
     for (int t = blockIdx.x; t * L::TILE < n_pts; t += gridDim.x) {
+        prologue_issue<KS_IN, WAVES>(net_imp, wp_imp, smem + L::ring, wave, lane);
         const int q = t * L::TILE + wave * L::PTS + lane;
         const int ray = q / NBG, s = q % NBG;
         float d[3] = {0.f, 0.f, 1.f};
@@ -629,16 +637,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_background(const NetDesc net_imp
         opx8 Bcur[KS_REG][NB];
         f32x4 out[NB];
         zero_b<NB>(Bcur);
-        prologue<KS_IN, WAVES>(net_imp, wp_imp, smem + L::ring, wave, lane);
+        prologue_wait();
         run_net<NB, false, KS_IN, HID_SOFTPLUS, WAVES>(net_imp, wp_imp, bias_lds0, smem + L::ring, Bcur, stage, out, wave,
                                                        lane);
+        // the colour net's first chunks: behind the last barrier of the network above the ring is free; their latency runs beside
+        // the density / view-direction staging below
+        prologue_issue<KS_IN, WAVES>(net_ren, wp_ren, smem + L::ring, wave, lane);
         if (lane < 16) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) scr[(nb * 16 + lane) * 4 + 3] = fabsf(out[nb][0]);  // AbsDensity (density.py:32-34)
         }
         // colour net: [PE_4(view dir) (27), frame code (hoisted), features (registers)]
         if (lane < L::PTS) stage_pe<3, 4, KS_IN>(stage + lane * in_stride(KS_IN), d);
-        prologue<KS_IN, WAVES>(net_ren, wp_ren, smem + L::ring, wave, lane);
+        prologue_wait();
         run_net<NB, false, KS_IN, HID_RELU, WAVES>(net_ren, wp_ren, bias_lds1, smem + L::ring, Bcur, stage, out, wave, lane);
         if (lane < 16) {
 #pragma unroll

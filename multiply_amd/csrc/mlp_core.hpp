@@ -720,7 +720,8 @@ __device__ __forceinline__ void pp_dma_piece(const char* src_chunk_uniform, unsi
     asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"
                  ::"s"(lds_chunk_base), "s"(piece_off_uniform), "v"(lane_off), "s"(src_chunk_uniform) : "memory");
 }
-template <int KS_IN>
+// PART: 0 = all of this wave's pieces, 1 = those of row block 0 only, 2 = those of row block 1 only (-DMP_DMA_SPLIT)
+template <int KS_IN, int PART = 0>
 __device__ __forceinline__ void pp_issue(const char* __restrict__ wpack, char* wring, int cn, int ring_slot,
                                          const ChunkMasks& cm, const DmaLanes<KS_IN>& d) {
     constexpr int CB = chunk_bytes(KS_IN);
@@ -741,7 +742,8 @@ __device__ __forceinline__ void pp_issue(const char* __restrict__ wpack, char* w
 #else
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            pp_dma_piece(src, d.reg[i], dst, (i / 2) * mb_bytes(KS_IN) + (wl + 4 * (i % 2)) * TILE_BYTES);
+            if (PART == 0 || i / 2 == PART - 1)
+                pp_dma_piece(src, d.reg[i], dst, (i / 2) * mb_bytes(KS_IN) + (wl + 4 * (i % 2)) * TILE_BYTES);
 #endif
     }
     if constexpr (KS_IN > 0) {
@@ -749,7 +751,8 @@ __device__ __forceinline__ void pp_issue(const char* __restrict__ wpack, char* w
 #pragma unroll
             for (int i = 0; i < (2 * KS_IN + 3) / 4; ++i) {
                 const unsigned k = wl + 4 * i;
-                if (k < 2 * KS_IN) pp_dma_piece(src, d.in[i], dst, (k / KS_IN) * mb_bytes(KS_IN) + (KS_REG + k % KS_IN) * TILE_BYTES);
+                if (k < 2 * KS_IN && (PART == 0 || k / KS_IN == PART - 1))
+                    pp_dma_piece(src, d.in[i], dst, (k / KS_IN) * mb_bytes(KS_IN) + (KS_REG + k % KS_IN) * TILE_BYTES);
             }
         }
     }
@@ -888,7 +891,13 @@ __device__ __forceinline__ void run_layer_pp(const NetDesc& net, const LayerDesc
                 else dma_wait_all();
             }
             if (late) {
-#ifdef MP_DMA_EARLY
+#if defined(MP_DMA_SPLIT)
+                // both halves of the workgroup issue: the late waves row block 1 of chunk ci + 3 here, the early waves row block 0 of
+                // chunk ci + 2 at the tail of their V phase (below)
+                if constexpr (!REV) dma_wait_all();
+                __syncthreads();
+                if (ci + 3 <= pp_last) pp_issue<KS_IN, 2>(wpack, wring, ci + 3, ring_pos, cm, dl);
+#elif defined(MP_DMA_EARLY)
                 __syncthreads();   // the late waves issue no DMA in this variant: nothing of theirs to wait for
 #else
                 // every DMA piece this wave issued (one whole M phase ago) has landed; every wave is done with chunk ci:
@@ -939,8 +948,13 @@ __device__ __forceinline__ void run_layer_pp(const NetDesc& net, const LayerDesc
                 if constexpr (HID == HID_SOFTPLUS_SAVE && HIDDEN) __builtin_amdgcn_s_waitcnt(0x0F70 | (SIG8 ? 1 : 2));
                 else if constexpr (!REV) dma_wait_all();
 #ifndef MP_EXP_NOLOAD
+#ifdef MP_DMA_SPLIT
+                if (ci >= 1 && ci + 2 <= pp_last)
+                    pp_issue<KS_IN, 1>(wpack, wring, ci + 2, ring_pos == 0 ? RING_SLOTS - 1 : ring_pos - 1, cm, dl);
+#else
                 if (ci >= 1 && ci + 2 <= pp_last)
                     pp_issue<KS_IN>(wpack, wring, ci + 2, ring_pos == 0 ? RING_SLOTS - 1 : ring_pos - 1, cm, dl);
+#endif
 #endif
 #endif
                 __syncthreads();   // default: the early waves issue no DMA: nothing to wait for (their stores need no wait)
@@ -1207,16 +1221,26 @@ constexpr bool PROLOGUE_THREE = false;
 #else
 constexpr bool PROLOGUE_THREE = true;
 #endif
+// Round 6: in two halves.  prologue_issue() goes to the HEAD of a tile, before the tile's inputs are fetched and encoded (the ring is
+// free there: every wave has passed the barrier behind the previous tile's last M phase), prologue_wait() behind them -- the first
+// chunks' DMA latency then runs beside the worklist -> position loads and the Fourier features instead of after them.
 template <int KS_IN, int WAVES, bool THREE = PROLOGUE_THREE>
-__device__ __forceinline__ void prologue(const NetDesc& net, const char* __restrict__ wpack, char* wring, int wave,
-                                         int lane) {
+__device__ __forceinline__ void prologue_issue(const NetDesc& net, const char* __restrict__ wpack, char* wring, int wave, int lane) {
     issue_chunk<KS_IN, WAVES>(wpack, wring, 0, wave, lane);
     if (net.total_chunks > 1) issue_chunk<KS_IN, WAVES>(wpack, wring, 1, wave, lane);
     if constexpr (THREE) {
         if (net.total_chunks > 2) issue_chunk<KS_IN, WAVES>(wpack, wring, 2, wave, lane);
     }
+}
+__device__ __forceinline__ void prologue_wait() {
     dma_wait_all();
     __syncthreads();
+}
+template <int KS_IN, int WAVES, bool THREE = PROLOGUE_THREE>
+__device__ __forceinline__ void prologue(const NetDesc& net, const char* __restrict__ wpack, char* wring, int wave,
+                                         int lane) {
+    prologue_issue<KS_IN, WAVES, THREE>(net, wpack, wring, wave, lane);
+    prologue_wait();
 }
 __device__ __forceinline__ void load_bias(const NetDesc& net, const float* __restrict__ bias, float* bias_lds) {
     for (int i = threadIdx.x; i < net.n_layers * BIAS_STRIDE; i += blockDim.x) bias_lds[i] = bias[i];

@@ -320,7 +320,9 @@ __device__ __forceinline__ void touch4(const f32x4& v) { asm volatile("" ::"v"(v
 // at the tail of their activation code -- where they otherwise wait at the barrier for the late waves, whose [barrier, DMA issue,
 // activation, products] chain is the chunk's critical path.  Behind barrier(ci - 1) slot (ci - 1) % 3 is free: chunk ci + 2 goes
 // there, and the issuing wave waits for it one iteration later (counted: everything but the prefetch loads just issued).
-template <class Epi, int MAXC, bool HAS_IN, bool EARLY_DMA = false>
+// DMA_MODE 2 (-DMP_DMA_SPLIT): both halves issue, NW = 8 piece dealing -- the late waves their pieces of chunk ci + 3 behind the barrier,
+// the early waves theirs of chunk ci + 2 at their tail.
+template <class Epi, int MAXC, bool HAS_IN, int DMA_MODE = 0>
 __device__ __forceinline__ void tf_layer(Ctx& cx, Epi& ep, int n_chunk, bool use_reg, bool use_in, BReg& Bcur, BReg& Bnext) {
     int npref = ep.prefetch(cx, 0);
     ep.rotate();
@@ -331,11 +333,14 @@ __device__ __forceinline__ void tf_layer(Ctx& cx, Epi& ep, int n_chunk, bool use
             ep.init(cx, c, acc);
             tf_mma<HAS_IN>(cx, use_reg, use_in, Bcur, acc);
             ep.touch();
+            constexpr bool EARLY_DMA = DMA_MODE != 0;
             if (cx.late) {
-                if constexpr (!EARLY_DMA) wait_vm_rt(npref);
+                if constexpr (DMA_MODE != 1) wait_vm_rt(npref);
                 __syncthreads();
-                if constexpr (!EARLY_DMA) {
+                if constexpr (DMA_MODE == 0) {
                     if (cx.ci + RING < cx.n_total) tf_issue<4>(cx, cx.ci + RING, cx.ring_pos, cx.wave - 4);
+                } else if constexpr (DMA_MODE == 2) {
+                    if (cx.ci + RING < cx.n_total) tf_issue<8>(cx, cx.ci + RING, cx.ring_pos, cx.wave);
                 }
             }
             npref = c + 1 < n_chunk ? ep.prefetch(cx, c + 1) : 0;
@@ -344,8 +349,10 @@ __device__ __forceinline__ void tf_layer(Ctx& cx, Epi& ep, int n_chunk, bool use
             if constexpr (EARLY_DMA) {
                 if (!cx.late) {
                     wait_vm_rt(npref);
-                    if (cx.ci >= 1 && cx.ci + RING - 1 < cx.n_total)
-                        tf_issue<4>(cx, cx.ci + RING - 1, cx.ring_pos == 0 ? RING - 1 : cx.ring_pos - 1, cx.wave);
+                    if (cx.ci >= 1 && cx.ci + RING - 1 < cx.n_total) {
+                        if constexpr (DMA_MODE == 2) tf_issue<8>(cx, cx.ci + RING - 1, cx.ring_pos == 0 ? RING - 1 : cx.ring_pos - 1, cx.wave);
+                        else tf_issue<4>(cx, cx.ci + RING - 1, cx.ring_pos == 0 ? RING - 1 : cx.ring_pos - 1, cx.wave);
+                    }
                 }
             }
             if (!cx.late) __syncthreads();
@@ -691,8 +698,10 @@ __global__ __launch_bounds__(TF_THREADS) void k_tf_sdf_val(TfValArgs a) {
             ep.linear = l == 8;
             ep.sdf_out = a.sdf_out;
             ep.id = id;
-#ifndef MP_DMA_LATE
-            tf_layer<EpiV, 8, true, true>(cx, ep, l == 8 ? 1 : 8, l > 0, l == 0 || l == 4, Bcur, Bnext);
+#if defined(MP_DMA_SPLIT)
+            tf_layer<EpiV, 8, true, 2>(cx, ep, l == 8 ? 1 : 8, l > 0, l == 0 || l == 4, Bcur, Bnext);
+#elif !defined(MP_DMA_LATE)
+            tf_layer<EpiV, 8, true, 1>(cx, ep, l == 8 ? 1 : 8, l > 0, l == 0 || l == 4, Bcur, Bnext);
 #else
             tf_layer<EpiV, 8, true>(cx, ep, l == 8 ? 1 : 8, l > 0, l == 0 || l == 4, Bcur, Bnext);
 #endif
