@@ -308,6 +308,31 @@ def train_cpu_baseline(model, gin, inp, tables, sc, n_samples, rays=512, iters=3
     oin["uv"] = inp["uv"][:, sel]
     tl = torch.mean(torch.square((inp["smpl_pose"] + 0.01) - inp["smpl_pose"])).reshape(())      # multiply.py:242-243
     names = [k for k, v in sd.items() if v.requires_grad]
+    # The SAMPLER of this iteration against the oracle's own (round 6): the gradient comparison below hands the device's depths to the
+    # oracle (`z_given`: the sampler runs without gradients in the reference, ray_sampler.py:86-87), which certifies the differentiable
+    # path only -- so the depths themselves are compared here: the oracle's ErrorBoundSampler on the same rays with the same recorded
+    # draws (fp32 network queries) vs the device's (sampler_sdf_mode, default near-fp32).
+    z_parity = {}
+    try:
+        t0 = time.time()
+        dirs_all, cam1 = O.get_camera_rays(oin["uv"][0], inp["pose"][0], inp["intrinsics"][0])
+        zmax, zsum, zcnt = 0.0, 0.0, 0
+        with torch.no_grad():
+            for n, p in enumerate(cx["persons"]):
+                so = oracle.servers[p].forward(inp["smpl_params"][0, p, 0], inp["smpl_trans"][0, p], inp["smpl_pose"][0, p],
+                                               inp["smpl_shape"][0, p])
+                cond = inp["smpl_pose"][0, p, 3:] / np.pi
+                fn = lambda pts, p=p, so=so, cond=cond: oracle.persons[p].sdf_func(pts, cond, so["smpl_tfs"], so["smpl_verts"],
+                                                                                   eval_mode=False)[0]
+                d = draws["person"][p]
+                z_or, _ = O.error_bound_sample(oracle.cfg, dirs_all[hit[n]], cam1[None].expand(len(hit[n]), -1), fn, oracle.beta().detach(),
+                                               dict(t_rand=d["t_rand"], u_final=d["u_final"], extra_idx=d["extra_idx"].long()))
+                e = (z_given[n] - z_or).abs()
+                zmax, zsum, zcnt = max(zmax, float(e.max())), zsum + float(e.sum()), zcnt + e.numel()
+        z_parity = {"parity_sampler_depth_max_abs": zmax, "parity_sampler_depth_mean_abs": zsum / max(zcnt, 1),
+                    "parity_sampler_seconds": round(time.time() - t0, 1), "sampler_sdf": model.resolved_sampler_sdf_mode(0)}
+    except Exception as ex:                                   # never lose the bench line to the extra check
+        z_parity = {"parity_sampler_depth_note": f"not computed: {type(ex).__name__}: {ex}"}
     times, parity = [], {}
     for i in range(iters + 1):                       # the first (cold: allocator, thread pool) is compared but not timed
         t0 = time.time()
@@ -322,6 +347,7 @@ def train_cpu_baseline(model, gin, inp, tables, sc, n_samples, rays=512, iters=3
         # no gradient is comparable: the oracle's loss is then taken without the term as well (and the event is recorded).
         guard_gpu, guard_or = float(lo_gpu["bce_loss"]) == 0.0, float(lo["bce_loss"]) == 0.0
         bce_note = None
+        loss_unadjusted = float(lo["loss"])
         if guard_gpu and not guard_or:
             lo = dict(lo)
             lo["loss"] = lo["loss"] - loss_fn.bce_weight * lo["bce_loss"]
@@ -354,7 +380,11 @@ def train_cpu_baseline(model, gin, inp, tables, sc, n_samples, rays=512, iters=3
             parity = {"parity_loss_abs": abs(float(lo_gpu["loss"]) - float(lo["loss"])), "loss_gpu": float(lo_gpu["loss"]),
                       "loss_oracle": float(lo["loss"]), "parity_grad_rel_worst": worst, "parity_grad_worst_tensor": worst_name,
                       "parity_grad_tensors": n_cmp, "parity_grad_tensors_below_1e-7": n_tiny,
-                      "parity_state_entries_without_gradient": n_nograd, "parity_forward_max_abs": fwd, "parity_note": bce_note}
+                      "parity_state_entries_without_gradient": n_nograd, "parity_forward_max_abs": fwd, "parity_note": bce_note,
+                      # structured form of the note (advisor, round 5): did the reference's NaN guard on the bce term fire on one side only?
+                      # `parity_loss_abs_unadjusted` is the difference of the two losses as they were, bce term included on the oracle's side
+                      "bce_guard": {"device": guard_gpu, "oracle": guard_or, "mismatch": guard_gpu != guard_or},
+                      "parity_loss_abs_unadjusted": abs(float(lo_gpu["loss"]) - loss_unadjusted), **z_parity}
         del gw
     dt = float(np.mean(times[1:]))
     threads, phys, name = host_cpu()

@@ -375,6 +375,9 @@ class Multiply(nn.Module):
             n_hit = both[:len(persons)]
             if any(both[len(persons):]):
                 import warnings
+                # counted (advisor, round 5): a regression of the device wrap -- e.g. its grid barrier giving up under GPU sharing --
+                # shows as a growing `hull_host_fallbacks` in `last_stats` / the bench line, not only as a warning
+                self.hull_host_fallbacks = getattr(self, "hull_host_fallbacks", 0) + 1
                 warnings.warn("device convex hull failed (degenerate vertex configuration): falling back to the host-side hull")
                 return self._setup(input, id, canonical_pose, _beta=_beta, host_hull=True)
         else:
@@ -624,7 +627,7 @@ class Multiply(nn.Module):
         rs = self.ray_sampler
         NZ = rs.N_samples + rs.N_samples_extra + 2
         S = NZ - 1
-        stats = {"n_hit": n_hit, "iters": [], "n_sdf_evals": [], "n_shaded": []}
+        stats = {"n_hit": n_hit, "iters": [], "n_sdf_evals": [], "n_shaded": [], "hull_host_fallbacks": getattr(self, "hull_host_fallbacks", 0)}
 
         for n, p in enumerate(persons):
             pp = per[p]

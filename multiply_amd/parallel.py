@@ -126,10 +126,13 @@ class GradientAllReduce:
         self.flat = torch.zeros(n, dtype=torch.float32, device=p0.device)
 
     def __call__(self):
-        """gradients -> flat buffer (one concat) -> all_reduce -> averaged gradients written back (one foreach copy)"""
+        """world > 1: gradients -> flat buffer (one concat) -> all_reduce -> averaged gradients written back (one foreach copy);
+        returns the flat buffer of AVERAGED gradients.  world == 1: nothing to average -- the parameters' .grad are final as they
+        are, nothing is copied (it cost ~40 zero fills of never-touched gradients + a 9 MB concat per iteration in the single-GPU
+        bench line) and None is returned: a caller that wants the flat vector (gradient norm, clipping) calls flat_gradients()."""
         world = dist.get_world_size() if dist.is_initialized() else 1
-        if world == 1:          # nothing to average: no flat copy either (it cost ~40 zero fills of never-touched gradients + a 9 MB
-            return self.flat    # concat per iteration in the single-GPU bench line)
+        if world == 1:
+            return None
         for p in self.params:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
@@ -139,6 +142,11 @@ class GradientAllReduce:
             self.flat.mul_(1.0 / world)
             torch._foreach_copy_([p.grad for p in self.params],
                                  [v.reshape(p.shape) for p, v in zip(self.params, self.flat.split(self.sizes))])
+        return self.flat
+
+    def flat_gradients(self):
+        """the current .grad of every parameter as ONE flat fp32 vector (zeros where a parameter has no gradient), at any world size"""
+        torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in self.params], out=self.flat)
         return self.flat
 
 

@@ -811,7 +811,9 @@ class ImplicitTrainFusedBG:
         lw8 = lins[8]
         _chk(L.mp_tf_bg_bwd(_p(fs.wpack), _p(lw8.W), _p(A), P, _p(dfeat), _p(dsdf), _p(lw8.dW), _p(lw8.db), st), "mp_tf_bg_bwd")
         lw0 = lins[0]
-        gemm_tn(off(A, self.o_dZ(0)), 256, off(A, self.o_IN), E, _p(lw0.dW), lw0.in_dim, 256, E, P, _p(lw0.db), P)
+        db0 = _zeros(256, device=dfeat.device)      # layer 0's bias gradient of THIS evaluation (see ImplicitTrain.backward)
+        gemm_tn(off(A, self.o_dZ(0)), 256, off(A, self.o_IN), E, _p(lw0.dW), lw0.in_dim, 256, E, P, _p(db0), P)
+        lw0.db.add_(db0)
         groups = []
         for l in range(1, 8):
             lw = lins[l]                                # (layer 3: 172 rows contracted as 256, see LinP)
@@ -820,9 +822,9 @@ class ImplicitTrainFusedBG:
                                    _p(lw.db_full), P))
         groups.append(tn_group(_p(dfeat), 256, off(A, self.o_X(8)), 256, off(lw8.dW, 256), 256, 256, 256, P, off(lw8.db, 1), P))
         ImplicitTrainFused._launch(groups)
-        _chk(L.mp_tr_hoist_bwd(_p(lw0.db), 256, lw0.in_dim, E, net.cond_dim, _p(self.cond), _p(lw0.dW), st), "mp_tr_hoist_bwd")
+        _chk(L.mp_tr_hoist_bwd(_p(db0), 256, lw0.in_dim, E, net.cond_dim, _p(self.cond), _p(lw0.dW), st), "mp_tr_hoist_bwd")
         dcode = _zeros(net.cond_dim, device=dfeat.device)
-        gemm_tn(_p(lw0.db), 1, off(lw0.W, E), lw0.in_dim, _p(dcode), net.cond_dim, 1, net.cond_dim, 256)
+        gemm_tn(_p(db0), 1, off(lw0.W, E), lw0.in_dim, _p(dcode), net.cond_dim, 1, net.cond_dim, 256)
         return dcode
 
     def params(self):
@@ -896,12 +898,14 @@ class RenderTrain:
             dZ = dZp
         lw0 = self.lins[0]
         o0 = lw0.out_dim
-        gemm_tn(_p(dZ), o0, _p(self.XA), self.na, _p(lw0.dW), lw0.in_dim, o0, self.na, n, _p(lw0.db), n)
+        db0 = _zeros(o0, device=dev)                  # this evaluation's own bias gradient (see ImplicitTrain.backward)
+        gemm_tn(_p(dZ), o0, _p(self.XA), self.na, _p(lw0.dW), lw0.in_dim, o0, self.na, n, _p(db0), n)
+        lw0.db.add_(db0)
         gemm_tn(_p(dZ), o0, self.feat_ptr, self.feat_ld, off(lw0.dW, self.c_feat), lw0.in_dim, o0, 256, n)
-        _chk(L.mp_tr_hoist_bwd(_p(lw0.db), o0, lw0.in_dim, self.c_h0, self.n_h, _p(self.hvec), _p(lw0.dW), hip.stream()),
+        _chk(L.mp_tr_hoist_bwd(_p(db0), o0, lw0.in_dim, self.c_h0, self.n_h, _p(self.hvec), _p(lw0.dW), hip.stream()),
              "mp_tr_hoist_bwd")
         dh = _zeros(self.n_h, device=dev)
-        gemm_tn(_p(lw0.db), 1, off(lw0.W, self.c_h0), lw0.in_dim, _p(dh), self.n_h, 1, self.n_h, o0)
+        gemm_tn(_p(db0), 1, off(lw0.W, self.c_h0), lw0.in_dim, _p(dh), self.n_h, 1, self.n_h, o0)
         # data gradients
         gemm_nt(_p(dZ), o0, _p(lw0.WT), o0, _p(dXA), self.na, n, self.na, o0)
         gemm_nt(_p(dZ), o0, off(lw0.WT, self.c_feat * o0), o0, dfeat_ptr, dfeat_ld, n, 256, o0, None, 0, accumulate=feat_accumulate)
@@ -1002,7 +1006,9 @@ class RenderTrainFused:
         H = lambda l: off(S, l * NL)
         dZ = lambda l: off(S, (4 + l) * NL)
         lw0 = lins[0]
-        gemm_tn(dZ(0), 256, _p(self.XA), 6, _p(lw0.dW), lw0.in_dim, 256, 6, n, _p(lw0.db), n)
+        db0 = _zeros(256, device=dev)                 # this evaluation's own bias gradient (see ImplicitTrain.backward)
+        gemm_tn(dZ(0), 256, _p(self.XA), 6, _p(lw0.dW), lw0.in_dim, 256, 6, n, _p(db0), n)
+        lw0.db.add_(db0)
         groups = tn_groups if tn_groups is not None else []
         groups.append(tn_group(dZ(0), 256, _p(self.feat), 256, off(lw0.dW, 14), lw0.in_dim, 256, 256, n))
         for l in range(1, 4):
@@ -1013,9 +1019,9 @@ class RenderTrainFused:
         lw4 = lins[4]
         gemm_tn(_p(dz4), 3, H(3), 256, _p(lw4.dW), 256, 3, 256, n, _p(lw4.db), n)
         # the hoisted pose embedding: dW_0[:, 6:14] += db_0 (x) pose8 ; d pose8 = W_0[:, 6:14]^T db_0 ; then lin_pose's own gradients
-        _chk(L.mp_tr_hoist_bwd(_p(lw0.db), 256, lw0.in_dim, 6, 8, _p(cs.pose8), _p(lw0.dW), st), "mp_tr_hoist_bwd")
+        _chk(L.mp_tr_hoist_bwd(_p(db0), 256, lw0.in_dim, 6, 8, _p(cs.pose8), _p(lw0.dW), st), "mp_tr_hoist_bwd")
         dh = _zeros(8, device=dev)
-        gemm_tn(_p(lw0.db), 1, off(lw0.W, 6), lw0.in_dim, _p(dh), 8, 1, 8, 256)
+        gemm_tn(_p(db0), 1, off(lw0.W, 6), lw0.in_dim, _p(dh), 8, 1, 8, 256)
         dlp_w = _zeros(8, 69, device=dev)
         _chk(L.mp_tr_hoist_bwd(_p(dh), 8, 69, 0, 69, _p(self.cond), _p(dlp_w), st), "mp_tr_hoist_bwd")
         self.extra_grads = [dlp_w, dh]
@@ -1585,6 +1591,11 @@ def forward_train(model, input, id=-1, cond_zero_shit=False, canonical_pose=Fals
     epoch = int(input["current_epoch"])
     if (model.smpl_surface_weight > 0 or model.zero_pose_weight > 0) and shard is not None:
         raise NotImplementedError("the smpl_surface / zero_pose regularisers (multiply.py:336-394) are not built for person-sharded training")
+    if model.zero_pose_weight > 0 and not (isinstance(id, int) and id == -1):
+        # the zero-pose term evaluates EVERY person's network (multiply.py:377-394); the adjoint sweep retires only the rendered
+        # persons' networks, so the other networks' weight gradients would be dropped while the loss value contains their terms
+        raise NotImplementedError("zero_pose_weight > 0 with a subset of the persons rendered (id != -1): the regulariser's gradients to "
+                                  "the networks that are not rendered are not collected")
     if shard is not None:                   # person-sharded: this rank evaluates persons {p : p % world == rank}
         assert id == -1, "person-sharded training renders all persons"
         id = [p for p in range(int(input["smpl_trans"].shape[1])) if p % shard[0] == shard[1]]
@@ -1651,5 +1662,6 @@ def forward_train(model, input, id=-1, cond_zero_shit=False, canonical_pose=Fals
         out["sam_mask"] = input["sam_mask"].squeeze()
     model._last_train = graph
     model.last_stats = {"n_hit": cx["n_hit"], "iters": [graph.fg[p]["iters"] for p in cx["persons"]],
-                        "n_sdf_evals": [graph.fg[p]["wcount"] for p in cx["persons"]]}
+                        "n_sdf_evals": [graph.fg[p]["wcount"] for p in cx["persons"]],
+                        "hull_host_fallbacks": getattr(model, "hull_host_fallbacks", 0)}
     return out

@@ -80,6 +80,20 @@ def _grad_worker(rank, world, port, q):
     q.put((rank, ok))
 
 
+def test_gradient_allreduce_at_world_size_one_copies_nothing_and_says_so():
+    """world == 1 (no process group): nothing to average -- __call__ returns None instead of a stale flat buffer, the gradients stay
+    where they are, and flat_gradients() builds the flat vector on request (zeros for parameters without a gradient)"""
+    torch.manual_seed(0)
+    net = torch.nn.Linear(4, 3)
+    unused = torch.nn.Parameter(torch.ones(2))
+    net(torch.ones(2, 4)).sum().backward()
+    ar = parallel.GradientAllReduce(list(net.parameters()) + [unused])
+    assert ar() is None and unused.grad is None
+    flat = ar.flat_gradients()
+    want = torch.cat([net.weight.grad.reshape(-1), net.bias.grad.reshape(-1), torch.zeros(2)])
+    assert torch.equal(flat, want)
+
+
 def test_two_rank_gradient_allreduce():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
