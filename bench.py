@@ -452,6 +452,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=8192, help="rays of the CPU oracle's render sample (~1 min per 1000 on the box's host)")
     ap.add_argument("--cpu-train-iters", type=int, default=2, help="timed oracle training iterations (one more, cold, is run first and discarded)")
+    ap.add_argument("--cpu-train-rays", type=int, default=512, help="rays of the CPU oracle's training iterations and of the device iteration "
+                    "they are compared with (default: the reference's 512 pixels per iteration; the test suite uses fewer)")
     ap.add_argument("--cpu-budget-s", type=float, default=330.0, help="wall-time guard of the CPU oracle's render sample: it stops at the "
                     "first 512-ray group boundary past this many seconds (once 4096 rays are done)")
     ap.add_argument("--persons", type=int, default=2, help="persons of the synthetic scene (BASELINE.json configs[3]: --persons 4 --samples 256)")
@@ -739,7 +741,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(model, inp, tables, sc, args.samples, n_rays=args.cpu_rays, budget_s=args.cpu_budget_s)
             if train is not None:
                 train["cpu_baseline"] = train_cpu_baseline(model, to_dev(inp), inp, tables, sc, args.samples,
-                                                           iters=args.cpu_train_iters)
+                                                           rays=args.cpu_train_rays, iters=args.cpu_train_iters)
         print(json.dumps(out))
     if dist:
         td.barrier()

@@ -28,7 +28,7 @@ def test_single_gpu_line_has_roofline_and_cpu_baseline():
     # into a driver timeout): the sample stops after the minimum number of rays -- here the whole small sample is below the 4 096-ray
     # floor, so it completes and says how many rays it did (round 6: checked in THIS run instead of a second 70 s bench run)
     d = _run(["--res", "64", "--steps", "2", "--warmup", "1", "--train-steps", "2", "--train-warmup", "1", "--cpu-rays", "128",
-              "--cpu-train-iters", "1", "--cpu-budget-s", "0"])
+              "--cpu-train-iters", "1", "--cpu-train-rays", "128", "--cpu-budget-s", "0"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -42,7 +42,9 @@ def test_single_gpu_line_has_roofline_and_cpu_baseline():
     t = d["train_iter"]
     assert t["ms_per_iter"] > 0 and t["rays_per_iter"] == 512 and t["cpu_baseline"]["value"] > 0 and 0 < t["roofline"]["frac"] < 1
     assert t["dtype"] == "bf16x3" and "dtype_note" in d and t["cpu_baseline"]["parity_grad_rel_worst"] < 2e-2
-    assert t["cpu_baseline"]["parity_loss_abs"] < 1e-4
+    assert t["cpu_baseline"]["parity_loss_abs"] < 1e-4 and t["cpu_baseline"]["rays"] == 128
+    # round 6: the sampler of that iteration against the oracle's own sampler (same draws), and the bce-guard flags
+    assert t["cpu_baseline"]["parity_sampler_depth_max_abs"] < 6e-3 and t["cpu_baseline"]["bce_guard"]["mismatch"] in (False, True)
 
 
 def test_gpus_flag_starts_the_ranks_and_reports_strong_scaling():

@@ -169,7 +169,7 @@ def test_forward_eval_box_cull_is_conservative():
 
 def test_forward_eval_four_persons_256_samples():
     """BASELINE.json configs[3] as a parity case: 4-person synthetic scene, N_samples = 256 (289 composited samples per ray
-    and person), own box cull, 26 x 26 = 676 rays (round 5: 1 024; round 6: the suite's time budget -- the oracle needs 75 ms per
+    and person), own box cull, 22 x 22 = 484 rays (round 5: 1 024; round 6: the suite's time budget -- the oracle needs 75 ms per
     ray here; 81 before round 5).  Same tolerances as the 2-person test."""
     import warnings
     warnings.filterwarnings("ignore")
@@ -177,7 +177,7 @@ def test_forward_eval_four_persons_256_samples():
     from multiply_amd.multiply import Multiply
     from multiply_amd.synthetic import make_scene, make_smpl_tables
     tables = make_smpl_tables(0)
-    sc = make_scene(4, seed=1, H=26, W=26)
+    sc = make_scene(4, seed=1, H=22, W=22)
     opt = load_config()
     opt.ray_sampler.N_samples = 256
     opt.ray_sampler.N_samples_eval = 256
@@ -193,8 +193,8 @@ def test_forward_eval_four_persons_256_samples():
     oracle = O.MultiplyOracle(sd, tables, sc["smpl_params"][0, :, 76:], O.SamplerCfg(N_samples=256, N_samples_eval=256))
     want = oracle.forward_eval(inp, hit)
     print("[info] hit rays per person", model.last_stats["n_hit"], "iterations", want["iters"])
-    assert got["acc_person_list"].shape == (676, 4)
-    assert all(n > 60 for n in model.last_stats["n_hit"]), model.last_stats["n_hit"]      # every person is actually rendered
+    assert got["acc_person_list"].shape == (484, 4)
+    assert all(n > 40 for n in model.last_stats["n_hit"]), model.last_stats["n_hit"]      # every person is actually rendered
     assert TOL.within(report("4p rgb_values", got["rgb_values"], want["rgb_values"]), TOL.EVAL["rgb_values"])
     assert TOL.within(report("4p acc_map", got["acc_map"], want["acc_map"]), TOL.EVAL["acc_map"])
     assert TOL.within(report("4p acc_person_list", got["acc_person_list"], want["acc_person_list"]), TOL.EVAL["acc_person_list"])
