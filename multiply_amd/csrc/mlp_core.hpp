@@ -717,8 +717,14 @@ __device__ __forceinline__ DmaLanes<KS_IN> dma_lanes(int wl, int lane) {
 }
 __device__ __forceinline__ void pp_dma_piece(const char* src_chunk_uniform, unsigned lane_off, unsigned lds_chunk_base,
                                              unsigned piece_off_uniform) {
+#ifdef MP_EXP_DMA1LANE   // ablation (timing only, results are wrong): the same instructions, ONE lane's 16 bytes instead of 1 KiB per piece
+    asm volatile("s_mov_b64 s[98:99], exec\n\ts_mov_b64 exec, 1\n\ts_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+                 "s_mov_b64 exec, s[98:99]"
+                 ::"s"(lds_chunk_base), "s"(piece_off_uniform), "v"(lane_off), "s"(src_chunk_uniform) : "memory", "s98", "s99");
+#else
     asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"
                  ::"s"(lds_chunk_base), "s"(piece_off_uniform), "v"(lane_off), "s"(src_chunk_uniform) : "memory");
+#endif
 }
 // PART: 0 = all of this wave's pieces, 1 = those of row block 0 only, 2 = those of row block 1 only (-DMP_DMA_SPLIT)
 template <int KS_IN, int PART = 0>
