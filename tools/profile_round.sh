@@ -23,7 +23,7 @@ python "$REPO/tools/pmc_traffic.py" /tmp/prof_fetch /tmp/prof_write > "$OUT/pmc_
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d /tmp/prof_sq1 -o run -- $ONE > /dev/null 2> "$OUT/pmc_sq1.log"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d /tmp/prof_sq2 -o run -- $ONE > /dev/null 2> "$OUT/pmc_sq2.log"
 {
-  for k in k_mlp_fwdsave k_mlp_grad k_mlp_color k_background k_mlp_sdf k_warp_inverse k_warp_jacobian k_sampler_bound k_sampler_resample k_composite; do
+  for k in k_mlp_fwdsave k_mlp_grad k_mlp_color k_background k_tf_sdf_val k_mlp_sdf k_warp_inverse k_warp_jacobian k_sampler_bound k_sampler_resample k_composite; do
     echo "== $k"
     python "$REPO/tools/pmc_kernel.py" /tmp/prof_sq1 "$k"
     python "$REPO/tools/pmc_kernel.py" /tmp/prof_sq2 "$k"
