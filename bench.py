@@ -636,13 +636,18 @@ def main():
                  "gpu_ms": {"forward+loss": tph[0], "backward": tph[1], "allreduce": tph[2], "adam": tph[3]},
                  "host_ms_per_iter": thost,
                  "hit_rays": tstats["n_hit"], "last_loss": tloss,
+                 # the foreground SDF net's per-point stash (csrc/tfuse.hip): 46 tensors of 256 values + the encoded inputs; since round 6
+                 # V(1..7) are stored as bfloat16 and U(0..6) as half (the weight-gradient contraction and the backward read 16 bits)
+                 "stash_bytes_per_point": {"allocated": 46 * 1024 + 3 * 39 * 4, "stored": (46 * 1024 - 7 * 512 - 7 * 512) + 3 * 39 * 4,
+                                           "note": "per sampled point and person: the three stash-bound kernels (k_tf_sdf_fwd / _bwd, "
+                                                   "k_gemm_tn_b3w) move these bytes once to three times per iteration"},
                  "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": train_peak, "flop_per_iter_this_rank": tflop,
                               "achieved": tflop / (tdt / args.train_steps) / 1e12,
                               "frac": tflop / (tdt / args.train_steps) / 1e12 / train_peak,
-                              "note": "algorithmic GEMM FLOP of the differentiable path (the f16 sampler queries are not counted) "
+                              "note": "algorithmic GEMM FLOP of the differentiable path (the sampler's queries are not counted) "
                                       "over the whole iteration's wall time; peak = " + train_peak_note + ".  The iteration is not "
                                       "matrix-bound: its three dominant kernels (k_tf_sdf_fwd / _bwd, k_gemm_tn_b3w: 5.1 of 9.4 ms) move "
-                                      "the SDF net's per-point stash at 2.8-4.3 TB/s (profiles/r05_train_pmc_traffic.txt)"}}
+                                      "the SDF net's per-point stash at 2.8-4.3 TB/s (profiles/r05_train_pmc_traffic.txt, r06_train_kernels.txt)"}}
 
     n_shaded = float(sum(int(w.sum()) for s_ in shaded for w in s_)) / args.steps          # per frame (this rank's share)
     n_sdf = float(sum(int(w[:-1].sum()) for s_ in sdf_evals for w in s_)) / args.steps
