@@ -636,11 +636,9 @@ def main():
                  "gpu_ms": {"forward+loss": tph[0], "backward": tph[1], "allreduce": tph[2], "adam": tph[3]},
                  "host_ms_per_iter": thost,
                  "hit_rays": tstats["n_hit"], "last_loss": tloss,
-                 # the foreground SDF net's per-point stash (csrc/tfuse.hip): 46 tensors of 256 values + the encoded inputs; since round 6
-                 # V(1..7) are stored as bfloat16 and U(0..6) as half (the weight-gradient contraction and the backward read 16 bits)
-                 "stash_bytes_per_point": {"allocated": 46 * 1024 + 3 * 39 * 4, "stored": (46 * 1024 - 7 * 512 - 7 * 512) + 3 * 39 * 4,
-                                           "note": "per sampled point and person: the three stash-bound kernels (k_tf_sdf_fwd / _bwd, "
-                                                   "k_gemm_tn_b3w) move these bytes once to three times per iteration"},
+                 # the foreground SDF net's per-point stash (csrc/tfuse.hip): 46 fp32 tensors of 256 values + the encoded inputs.  Round 6
+                 # built and measured 16-bit storage of V(l) / U(l) (profiles/r06_stash16_ab.txt): slower and not accurate enough -- reverted
+                 "stash_bytes_per_point": 46 * 1024 + 3 * 39 * 4,
                  "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": train_peak, "flop_per_iter_this_rank": tflop,
                               "achieved": tflop / (tdt / args.train_steps) / 1e12,
                               "frac": tflop / (tdt / args.train_steps) / 1e12 / train_peak,

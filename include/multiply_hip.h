@@ -323,9 +323,7 @@ typedef struct {
     const float* B;
     float* C;
     float* colsum;       /* may be NULL */
-    int lda, ldb, ldc, M, N, K, colsum_rows;
-    int flags;           /* bit 0 (round 6): the rows of A are stored as bfloat16 (lda in bfloat16 elements, A 8-byte aligned) -- the
-                            contraction-only operand V(l) of the layer-fused SDF kernels; wide form (M = N = 256) only */
+    int lda, ldb, ldc, M, N, K, colsum_rows, pad_;
 } MpTnGroup;
 int mp_gemm_tn_bf16x3_grouped(const MpTnGroup* groups, int n_groups, void* stream);
 /* Fourier features (embedders.py) of x [P][d_in] (d_in 3|4, L octaves) times `scale` into out[.][ld] at col0; fwd != 0 also

@@ -746,10 +746,6 @@ __global__ __launch_bounds__(NT_THREADS, 1) void k_gemm_tn_b3w(TnGroups T, int n
     const int tt = t & 255, mg = tt & 63, rb = tt >> 6;
     const float* src = (is_b ? G.B : G.A) + 4 * mg;
     const int ld = is_b ? G.ldb : G.lda;
-    // A stored as bfloat16 (MpTnGroup.flags bit 0; the forward kernel's contraction-only operand V(l)): 8 bytes per row and thread
-    // instead of 16; the value IS its own high part, the low part of the split is exactly zero
-    const bool a16 = !is_b && (G.flags & 1);
-    const __bf16* src16 = (const __bf16*)G.A + 4 * mg;
     float* colsum = G.colsum;
     const int colsum_rows = G.colsum_rows;
     const bool do_sum = colsum != nullptr && !is_b;
@@ -767,8 +763,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void k_gemm_tn_b3w(TnGroups T, int n
 #if MP_EXP_TNW & 2      // ablation: no global loads
                 rr[4 * h + e] = (f32x4){(float)r, 1.f, 2.f, 3.f};
 #else
-                if (a16) rr[4 * h + e] = r < r_end ? __builtin_convertvector(*(const bf16x4*)(src16 + (size_t)r * ld), f32x4) : (f32x4){0, 0, 0, 0};
-                else rr[4 * h + e] = r < r_end ? *(const f32x4*)(src + (size_t)r * ld) : (f32x4){0, 0, 0, 0};
+                rr[4 * h + e] = r < r_end ? *(const f32x4*)(src + (size_t)r * ld) : (f32x4){0, 0, 0, 0};
 #endif
             }
     };
@@ -1000,10 +995,9 @@ extern "C" int mp_gemm_tn_bf16x3_grouped(const MpTnGroup* groups, int n_groups, 
     int mt = 0, nt = 0;
     for (int i = 0; i < n_groups; ++i) {
         const MpTnGroup& g = groups[i];
-        if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.M % BM || g.N % BN || (g.lda & 3) || (g.ldb & 3) ||
-            ((size_t)g.A & ((g.flags & 1) ? 7 : 15)) || ((size_t)g.B & 15))
+        if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.M % BM || g.N % BN || (g.lda & 3) || (g.ldb & 3) || ((size_t)g.A & 15) ||
+            ((size_t)g.B & 15))
             return -2;
-        if ((g.flags & 1) && !(g.M == WT_ && g.N == WT_)) return -2;     // bfloat16 rows of A: the wide form only
         T.g[i] = g;
         work += (long long)(g.M / BM) * (g.N / BN) * g.K;
         mt = g.M / BM > mt ? g.M / BM : mt;
@@ -1014,9 +1008,6 @@ extern "C" int mp_gemm_tn_bf16x3_grouped(const MpTnGroup* groups, int n_groups, 
 #endif
     bool wide = true;
     for (int i = 0; i < n_groups; ++i) wide = wide && groups[i].M == WT_ && groups[i].N == WT_;
-    if (!wide)
-        for (int i = 0; i < n_groups; ++i)
-            if (groups[i].flags & 1) return -2;
     if (wide) {
         long long rows = (work / 4 + MP_TNW_WGS - 1) / MP_TNW_WGS;
         rows = (rows + BK - 1) / BK * BK;

@@ -33,16 +33,6 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
-// Round 6: two stash tensors of the SDF net in 16 bits (-DTF_STASH32 restores fp32): V(l), l >= 1 -- read by the weight-gradient
-// contraction only -- as bfloat16 (the high part the contraction's operand split would take anyway), and U(l) -- read back once, by the
-// backward's ascending sweep, as a factor of the second-order term dS = sigma'' U dV -- as IEEE half (2^-11 relative on that factor).
-// 7.5 of the 46 KiB per point the three stash-bound kernels move ("Training path").
-#ifdef TF_STASH32
-constexpr bool STASH16 = false;
-#else
-constexpr bool STASH16 = true;
-#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TF_WAVES = 8, TF_THREADS = 64 * TF_WAVES, TF_PTS = 16 * TF_WAVES;   // 128 points per workgroup
@@ -148,8 +138,7 @@ __global__ __launch_bounds__(512) void k_tf_pack(const float* const* __restrict_
 // ---- stash arena (floats), P points.  Every [P][256] tensor has P + 1 rows: row P is where the lanes of the last tile's missing
 // points store (unconditional stores, no select: a divergent branch around them makes hipcc's wait-count bookkeeping fall back
 // to vmcnt(0) at every chunk).  R1 = (P + 1) * 256:
-//   dZ(l) l = 0..7 at l R1 (backward)          V(l)  l = 0..7 at (8 + l) R1 (forward; round 6: l >= 1 as BFLOAT16 rows of 256 at
-//                                                    the same offsets -- only the weight-gradient contraction reads them, V(0) fp32)
+//   dZ(l) l = 0..7 at l R1 (backward)          V(l)  l = 0..7 at (8 + l) R1 (forward)
 //   X(l)  l = 1..8 at (15 + l) R1 (forward)    dT(l) l = 1..7 at (23 + l) R1 (backward)
 //   U(l)  l = 0..6 at (31 + l) R1: the gradient sweep's rows before the sigmoid factor
 //   dS(l) l = 0..7 at (38 + l) R1: sigma'' (.) U (.) dV between the backward's two sweeps
@@ -384,25 +373,6 @@ __device__ __forceinline__ f32x4 ld4g(const float* p) { return (f32x4){0.01f, 0.
 #else
 __device__ __forceinline__ f32x4 ld4g(const float* p) { return *(const f32x4*)p; }
 #endif
-__device__ __forceinline__ void st_h4(_Float16* p, h16x4 v) {
-#if TF_EXP & 1
-    if ((float)v[0] == 123.456f)
-#endif
-        *(h16x4*)p = v;
-}
-__device__ __forceinline__ h16x4 ld_h4(const _Float16* p) {
-#if TF_EXP & 16
-    return (h16x4){(_Float16)0.01f, (_Float16)0.02f, (_Float16)0.03f, (_Float16)0.04f};
-#else
-    return *(const h16x4*)p;
-#endif
-}
-__device__ __forceinline__ void st_bf4(__bf16* p, bf16x4 v) {
-#if TF_EXP & 1
-    if ((float)v[0] == 123.456f)
-#endif
-        *(bf16x4*)p = v;
-}
 __device__ __forceinline__ void st4g(float* p, f32x4 v) {
 #if TF_EXP & 1
     if (v[0] == 123.456f)
@@ -521,7 +491,6 @@ struct EpiB {
     float kx;
     float* uout;           // U_{l-1}
     float* vout;           // V_{l-1}
-    bool v16;              // vout rows are bfloat16 (V(l), l >= 1)
     bool final;            // the 39-row product with W_0^T: accumulators start from the Fourier rows of T_4, result -> G
     float* gout;           // [P][39]
     f32x4 px[2], nx[2];
@@ -567,25 +536,15 @@ struct EpiB {
             u[e] = acc[e >> 2][e & 3];
             v[e] = (1.0f - one_minus_sig(px[e >> 2][e & 3], kx)) * u[e];
         }
-        if constexpr (STASH16) {
-            _Float16* pu = (_Float16*)uout + cx.srow + 32 * c + 4 * cx.g;
-            st_h4(pu, __builtin_convertvector((f32x4){u[0], u[1], u[2], u[3]}, h16x4));
-            st_h4(pu + 16, __builtin_convertvector((f32x4){u[4], u[5], u[6], u[7]}, h16x4));
-        } else {
+        {
             float* pu = uout + cx.srow + 32 * c + 4 * cx.g;
+            float* pv = vout + cx.srow + 32 * c + 4 * cx.g;
             st4g(pu, (f32x4){u[0], u[1], u[2], u[3]});
             st4g((pu + 16), (f32x4){u[4], u[5], u[6], u[7]});
-        }
-        split8(v, Bn.h[c], Bn.l[c]);
-        if (v16 && STASH16) {      // V(l), l >= 1: only the weight-gradient contraction reads it -- the bfloat16 high part it would split off anyway
-            __bf16* pv = (__bf16*)vout + cx.srow + 32 * c + 4 * cx.g;
-            st_bf4(pv, __builtin_shufflevector(Bn.h[c], Bn.h[c], 0, 1, 2, 3));
-            st_bf4(pv + 16, __builtin_shufflevector(Bn.h[c], Bn.h[c], 4, 5, 6, 7));
-        } else {
-            float* pv = vout + cx.srow + 32 * c + 4 * cx.g;
             st4g(pv, (f32x4){v[0], v[1], v[2], v[3]});
             st4g((pv + 16), (f32x4){v[4], v[5], v[6], v[7]});
         }
+        split8(v, Bn.h[c], Bn.l[c]);
     }
 };
 
@@ -622,17 +581,12 @@ __global__ __launch_bounds__(TF_THREADS) void k_tf_sdf_fwd(TfArgs a) {
                 const float x = (float)Bcur.h[ks][e] + (float)Bcur.l[ks][e];
                 v[e] = (1.0f - one_minus_sig(x, K2)) * (e < 4 ? w0[e & 3] : w1[e & 3]);
             }
-            if constexpr (!STASH16) {
+            {
                 float* pv = vout + cx.srow + 32 * ks + 4 * cx.g;
                 st4g(pv, (f32x4){v[0], v[1], v[2], v[3]});
                 st4g((pv + 16), (f32x4){v[4], v[5], v[6], v[7]});
             }
             split8(v, Bcur.h[ks], Bcur.l[ks]);
-            if constexpr (STASH16) {
-                __bf16* pv = (__bf16*)vout + cx.srow + 32 * ks + 4 * cx.g;      // V(7): bfloat16 rows (see the stash layout)
-                st_bf4(pv, __builtin_shufflevector(Bcur.h[ks], Bcur.h[ks], 0, 1, 2, 3));
-                st_bf4(pv + 16, __builtin_shufflevector(Bcur.h[ks], Bcur.h[ks], 4, 5, 6, 7));
-            }
         }
     }
     // ---- gradient sweep
@@ -643,7 +597,6 @@ __global__ __launch_bounds__(TF_THREADS) void k_tf_sdf_fwd(TfArgs a) {
         ep.kx = l == 4 ? K2 / R2 : K2;
         ep.uout = a.arena + off_U(R1, l > 0 ? l - 1 : 0);
         ep.vout = a.arena + off_V(R1, l > 0 ? l - 1 : 0);
-        ep.v16 = l - 1 >= 1;
         ep.gout = a.arena + off_G(R1, a.P);
         tf_layer<EpiB, 10, false>(cx, ep, l == 4 ? 10 : (l == 0 ? 2 : 8), true, false, Bcur, Bnext);
     }
@@ -799,7 +752,6 @@ struct EpiC {
     float osc;
     bool top;
     f32x4 px[2], pu[2], nx[2], nu[2];
-    h16x4 puh[2], nuh[2];  // STASH16: the U rows as they are stored (IEEE half); converted where they are used
     __device__ __forceinline__ int prefetch(const Ctx& cx, int c) {
         const int col = 32 * c + 4 * cx.g;
         nx[0] = ld4g(xin + cx.row + col);
@@ -807,24 +759,14 @@ struct EpiC {
         if (top) {
             nu[0] = ld4g(uin + col);
             nu[1] = ld4g(uin + col + 16);
-        } else if constexpr (STASH16) {
-            nuh[0] = ld_h4((const _Float16*)uin + cx.row + col);
-            nuh[1] = ld_h4((const _Float16*)uin + cx.row + col + 16);
         } else {
             nu[0] = ld4g(uin + cx.row + col);
             nu[1] = ld4g(uin + cx.row + col + 16);
         }
         return 4;
     }
-    __device__ __forceinline__ void rotate() {
-        px[0] = nx[0]; px[1] = nx[1]; pu[0] = nu[0]; pu[1] = nu[1];
-        if constexpr (STASH16) { puh[0] = nuh[0]; puh[1] = nuh[1]; }
-    }
-    __device__ __forceinline__ void touch() {
-        touch4(px[0]); touch4(px[1]);
-        if (top || !STASH16) { touch4(pu[0]); touch4(pu[1]); }
-        else { asm volatile("" ::"v"(puh[0]), "v"(puh[1])); }
-    }
+    __device__ __forceinline__ void rotate() { px[0] = nx[0]; px[1] = nx[1]; pu[0] = nu[0]; pu[1] = nu[1]; }
+    __device__ __forceinline__ void touch() { touch4(px[0]); touch4(px[1]); touch4(pu[0]); touch4(pu[1]); }
     __device__ __forceinline__ void init(const Ctx&, int, f32x4 (&acc)[2]) {
         acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
         acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -836,8 +778,7 @@ struct EpiC {
             const float dv = acc[e >> 2][e & 3];
             const float q = one_minus_sig(px[e >> 2][e & 3], kx), s1 = 1.0f - q;
             du[e] = s1 * dv;
-            const float ue = (top || !STASH16) ? pu[e >> 2][e & 3] : (float)puh[e >> 2][e & 3];
-            ds[e] = 100.0f * s1 * q * ue * dv;
+            ds[e] = 100.0f * s1 * q * pu[e >> 2][e & 3] * dv;
             dt[e] = du[e] * osc;
         }
         {

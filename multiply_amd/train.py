@@ -65,14 +65,13 @@ def gemm_tn(A, lda, B, ldb, Cm, ldc, M, N, K, colsum=None, colsum_rows=0):
 class MpTnGroup(C.Structure):
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("colsum", C.c_void_p), ("lda", C.c_int),
                 ("ldb", C.c_int), ("ldc", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("colsum_rows", C.c_int),
-                ("flags", C.c_int)]
+                ("pad_", C.c_int)]
 
 
-def tn_group(A, lda, B, ldb, Cm, ldc, M, N, K, colsum=None, colsum_rows=0, a_bf16=False):
-    """one contraction of a grouped launch (mp_gemm_tn_bf16x3_grouped); pointers as returned by _p() / off().  a_bf16: the rows of A
-    are stored as bfloat16 (lda in bfloat16 elements; MpTnGroup.flags bit 0)"""
+def tn_group(A, lda, B, ldb, Cm, ldc, M, N, K, colsum=None, colsum_rows=0):
+    """one contraction of a grouped launch (mp_gemm_tn_bf16x3_grouped); pointers as returned by _p() / off()"""
     return MpTnGroup(A.value, B.value, Cm.value, colsum.value if colsum is not None else None, lda, ldb, ldc, M, N, K,
-                     colsum_rows, 1 if a_bf16 else 0)
+                     colsum_rows, 0)
 
 
 def gemm_tn_grouped(groups):
@@ -414,7 +413,7 @@ class ImplicitTrainRev:
 class MpWnDesc(C.Structure):
     _fields_ = [("v", C.c_void_p), ("g", C.c_void_p), ("W", C.c_void_p), ("WT", C.c_void_p), ("dW_off", C.c_longlong),
                 ("dv_off", C.c_longlong), ("dg_off", C.c_longlong), ("out_dim", C.c_int), ("in_dim", C.c_int), ("row0", C.c_int),
-                ("flags", C.c_int)]
+                ("pad_", C.c_int)]
 
 
 class LinP(LinW):
@@ -717,9 +716,7 @@ class ImplicitTrainFused(ImplicitTrainRev):
             rows = lw.dW_full.shape[0]
             groups.append(tn_group(off(A, self.o_dZ(l)), 256, off(A, self.o_X(l)), 256, _p(lw.dW_full), lw.in_dim, rows, lw.in_dim, P,
                                    _p(lw.db_full), P))
-            # V(l), l >= 1, is stored as bfloat16 rows by k_tf_sdf_fwd (round 6: nothing but this contraction reads it)
-            groups.append(tn_group(off(A, self.o_V(l)), 256, off(A, self.o_dT(l)), 256, _p(lw.dW_full), lw.in_dim, rows, lw.in_dim, P,
-                                   a_bf16=True))
+            groups.append(tn_group(off(A, self.o_V(l)), 256, off(A, self.o_dT(l)), 256, _p(lw.dW_full), lw.in_dim, rows, lw.in_dim, P))
         groups.append(tn_group(_p(dfeat), 256, off(A, self.o_X(8)), 256, off(lw8.dW, 256), 256, 256, 256, P, off(lw8.db, 1), P))
         if tn_groups is None:
             self._launch(groups)
