@@ -670,7 +670,7 @@ def main():
     traffic = None
     kernels = {"mlp_shade": ["k_mlp_fwdsave", "k_mlp_grad"] if model.shade_mode == "reverse" else ["k_mlp_shade"],
                "mlp_color": ["k_mlp_color"], "background": ["k_background"], "sampler_mlp_sdf": ["k_mlp_sdf"]}[dom]
-    pmc_file = next((os.path.join(REPO, "profiles", f) for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json")
+    pmc_file = next((os.path.join(REPO, "profiles", f) for f in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json")
                      if os.path.exists(os.path.join(REPO, "profiles", f))), None)
     traffic_note = None
     if pmc_file and args.res == 512 and args.samples == 128 and args.persons == 2 and world == 1:
