@@ -44,7 +44,9 @@ def test_single_gpu_line_has_roofline_and_cpu_baseline():
     assert t["dtype"] == "bf16x3" and "dtype_note" in d and t["cpu_baseline"]["parity_grad_rel_worst"] < 2e-2
     assert t["cpu_baseline"]["parity_loss_abs"] < 1e-4 and t["cpu_baseline"]["rays"] == 128
     # round 6: the sampler of that iteration against the oracle's own sampler (same draws), and the bce-guard flags
-    assert t["cpu_baseline"]["parity_sampler_depth_max_abs"] < 6e-3 and t["cpu_baseline"]["bce_guard"]["mismatch"] in (False, True)
+    tc = t["cpu_baseline"]
+    assert tc["parity_sampler_depth_mean_abs"] < 1.3e-4 and tc["parity_sampler_depth_rays_above_3e-3"] <= max(2, 0.01 * tc["parity_sampler_depth_rays"])
+    assert tc["bce_guard"]["mismatch"] in (False, True) and d["train_iter"]["stash_bytes_per_point"] > 46 * 1024
 
 
 def test_gpus_flag_starts_the_ranks_and_reports_strong_scaling():

@@ -44,7 +44,7 @@ EVAL_F16 = {                               # eval-mode Multiply.forward outputs,
 # `p999` and `mean`.
 _TIGHT = dict(bulk=3e-3, frac=5e-4, hard=2.5e-2, floor=1)
 EVAL = {
-    "rgb_values": (2e-4, 3e-5),
+    "rgb_values": (1e-3, 3e-5),             # 4.4e-5, 8.4e-6 over the suite's scenes; 3.5e-4 on the opt-in 16 384-ray run (profiles/r06_parity_16k.txt)
     "fg_rgb_values": Dist(2e-4, p999=2.5e-3, **_TIGHT),
     "acc_map": Dist(5e-4, p999=5e-3, **_TIGHT),
     "acc_person_list": Dist(3e-4, p999=5e-3, **_TIGHT),
