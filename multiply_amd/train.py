@@ -1372,8 +1372,10 @@ class TrainGraph:
         head of the backward sweep, before any person's weight-norm adjoint retires its accumulators."""
         m, cx, L, st = self.model, self.cx, hip.lib(), hip.stream()
         dev = cx["dev"]
-        if self.pose_grad:
-            raise NotImplementedError("smpl_surface / zero_pose with body-model inputs under optimisation: their pose adjoints are not built")
+        if self.pose_grad and m.smpl_surface_weight > 0:
+            # (the zero-pose term's pose adjoint -- it reaches the pose through the conditioning only -- is built, round 6; the surface
+            # term's needs the adjoint of the posed VERTICES through blend shapes and skinning, which mp_smpl_pose_bwd does not carry)
+            raise NotImplementedError("smpl_surface with body-model inputs under optimisation: the adjoint of the posed vertices is not built")
         ssl = torch.zeros(1, dtype=F32, device=dev)
         zpl = torch.zeros(1, dtype=F32, device=dev)
         for q in cx["persons"]:
@@ -1402,11 +1404,12 @@ class TrainGraph:
                     it0 = ImplicitTrain(net, pts, torch.zeros_like(cond), fwd=False, lins=lins)
                     d = it1.out - it0.out
                     zpl = zpl + d[:, 0].abs().mean() + d[:, 1:].abs().mean()
-                    self.reg_items.append(("zero", it1, it0, torch.sign(d)))
+                    self.reg_items.append(("zero", it1, it0, torch.sign(d), q))
         self.reg_losses = (ssl, zpl)
 
     def _regularisers_backward(self, d_ssl, d_zpl):
         dev = self.cx["dev"]
+        self.reg_dcond = {}             # person -> adjoint of its pose conditioning from the zero-pose term (pose optimisation)
         for item in self.reg_items:
             if item[0] == "surf":
                 _, it, mask, cnt = item
@@ -1416,15 +1419,18 @@ class TrainGraph:
                 dZ[:, 0] = d_ssl.reshape(()) * mask.to(F32) / cnt
                 it.backward(dZ)
             else:
-                _, it1, it0, sg = item
+                _, it1, it0, sg, q = item
                 if d_zpl is None:
                     continue
                 n = sg.shape[0]
                 dZ = torch.empty(n, 257, dtype=F32, device=dev)
                 dZ[:, 0] = sg[:, 0] * (d_zpl.reshape(()) / n)
                 dZ[:, 1:] = sg[:, 1:] * (d_zpl.reshape(()) / (n * 256))
-                it1.backward(dZ)
+                dcond = it1.backward(dZ)
                 it0.backward(-dZ)
+                if self.pose_grad and not self.cond_zero:
+                    # person q's conditioning = smpl_pose[q, 3:] / pi (multiply.py:270): the term's only path to the body-model inputs
+                    self.reg_dcond[q] = dcond if q not in self.reg_dcond else self.reg_dcond[q] + dcond
 
     # ---- backward -----------------------------------------------------------------------------------------------
     def backward(self, d_rgb_values, d_acc_map, d_acc_person, d_grad_theta, d_ssl=None, d_zpl=None):
@@ -1522,6 +1528,8 @@ class TrainGraph:
                      "mp_smpl_pose_bwd")
                 if not self.cond_zero:                                   # cond = smpl_pose[3:] / pi  (multiply.py:270)
                     dc = dcond + torch.mv(rt.lp_w.t(), rt.extra_grads[1])
+                    if p in getattr(self, "reg_dcond", {}):             # + the zero-pose regulariser's share (round 6)
+                        dc = dc + self.reg_dcond[p]
                     dprm[7:76] += dc / math.pi
                 self.pose_grads[p] = dprm
         if self.bg is not None:

@@ -452,6 +452,54 @@ def test_training_gradients_to_body_model_params():
         assert e < 5e-3, k
 
 
+def test_zero_pose_regulariser_reaches_the_pose_under_optimisation():
+    """zero_pose_weight > 0 while the body-model inputs are being optimised (round 6; the branch raised before): the term
+    reaches smpl_pose through the pose conditioning of the network evaluations (multiply.py:377-394, cond = pose[3:] / pi).
+    d loss / d smpl_pose against the oracle under torch autograd; the surface term in the same situation still refuses loudly."""
+    model, oracle, inp, gin, gt, loss_fn, train = _train_setup()
+    model.zero_pose_weight = loss_fn.zero_pose_weight = 0.5
+    torch.manual_seed(21)
+    with torch.no_grad():         # (see the test above: the geometric initialisation's conditioning columns are zero)
+        for net in model.foreground_implicit_network_list:
+            net.lin0.weight_v[:, 39:] += 0.05 * torch.randn_like(net.lin0.weight_v[:, 39:])
+    oracle.sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    for pp in oracle.persons:
+        pp.sd = oracle.sd
+    R = inp["uv"].shape[1]
+    hit = [torch.arange(R), torch.arange(R)]
+    gin["smpl_pose"] = gin["smpl_pose"].clone().requires_grad_(True)
+    gin["smpl_pose_last"] = gin["smpl_pose"].detach() + 0.01
+    out = model({**gin, "hit_index": hit, "current_epoch": 30})
+    lo = loss_fn(out, gt)
+    lo["loss"].backward()
+    torch.cuda.synchronize()
+    graph = model._last_train
+    assert float(out["zero_pose_loss"]) > 0
+    oin = dict(inp)
+    oin["smpl_pose"] = inp["smpl_pose"].clone().requires_grad_(True)
+    z_given = [graph.fg[p]["zfinal"].cpu() for p in range(2)]
+    want = oracle.forward_train(oin, hit, z_given, _cpu(graph.draws))
+    # (epoch 30: no temporal term -- the reference adds it from epoch 251 on, multiply.py:242-243)
+    want.update(fg_rgb_values_each_person_list=[], index_in_surface=graph_index_in_surface(out), epoch=30, temporal_loss=torch.zeros(1),
+                smpl_surface_loss=torch.zeros(1), sam_mask=gin["sam_mask"].squeeze().cpu())
+    lw = loss_fn(want, gt)
+    assert abs(float(out["zero_pose_loss"]) - float(want["zero_pose_loss"])) < 2e-5
+    # the regulariser's own share of the pose gradient (everything else is covered by the test above)
+    (g_all,) = torch.autograd.grad(lw["loss"], [oin["smpl_pose"]], retain_graph=True)
+    (g_zp,) = torch.autograd.grad(want["zero_pose_loss"].sum(), [oin["smpl_pose"]])
+    a = gin["smpl_pose"].grad.cpu()
+    e = (a - g_all).abs().max().item() / (g_all.abs().max().item() + 1e-12)
+    share = g_zp.abs().max().item() * 0.5 / (g_all.abs().max().item() + 1e-12)
+    print(f"[grad parity] d loss / d smpl_pose with the zero-pose term: rel-to-max err {e:.3e}; the term's share of the gradient {share:.2e}")
+    assert e < 5e-3 and share > 5 * e
+    model.smpl_surface_weight = 1.0
+    nv = model.smpl_server_list[0].verts_c.reshape(-1, 3).shape[0]
+    model.smpl_vertex_part = {"head": list(range(300)), "rightHand": [], "leftHand": [], "rightFoot": [], "leftFoot": [],
+                              "leftHandIndex1": [], "rightHandIndex1": []}
+    with pytest.raises(NotImplementedError):
+        model({**gin, "hit_index": hit, "current_epoch": 30})
+
+
 def test_forward_mode_and_reverse_mode_training_agree(monkeypatch):
     """The two hand-written differentiation schemes of the SDF net (reverse-over-reverse, default; forward-mode + reverse)
     are independent implementations: same draws -> same outputs and the same gradient for every parameter."""
