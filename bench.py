@@ -390,7 +390,7 @@ def train_cpu_baseline(model, gin, inp, tables, sc, n_samples, rays=512, iters=3
                       "bce_guard": {"device": guard_gpu, "oracle": guard_or, "mismatch": guard_gpu != guard_or},
                       "parity_loss_abs_unadjusted": abs(float(lo_gpu["loss"]) - loss_unadjusted), **z_parity}
         del gw
-    dt = float(np.mean(times[1:]))
+    dt = float(np.mean(times[1:])) if len(times) > 1 else float(times[0])     # iters = 0 (tests): the one compared iteration, cold
     threads, phys, name = host_cpu()
     return {"value": 1e3 * dt, "unit": "ms/train-iter", "cores": threads, "physical_cores": phys, "cpu_model": name,
             "kind": "port", "rays": rays, "iters": iters, "discarded_warmup_iters": 1, **parity,

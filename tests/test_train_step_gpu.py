@@ -198,8 +198,11 @@ def test_training_parity_at_the_benchmarked_workload():
     model, inp, tables, sc = bench.build_model(128)
     model.convergence_group = 512
     gin = bench.to_dev(inp)
-    res = bench.train_cpu_baseline(model, gin, inp, tables, sc, 128, rays=512, iters=1)
+    res = bench.train_cpu_baseline(model, gin, inp, tables, sc, 128, rays=512, iters=0)       # ONE oracle iteration: the compared one
     print("[parity] bench workload:", {k: v for k, v in res.items() if k.startswith(("parity", "loss_"))})
+    # round 6: the sampler of that iteration against the oracle's own sampler on the same draws (tests/tolerances.py Z_VALS_PRECISE)
+    assert res["parity_sampler_depth_mean_abs"] < TOL.Z_VALS_PRECISE["mean"]
+    assert res["parity_sampler_depth_rays_above_3e-3"] <= max(2, TOL.Z_VALS_PRECISE["frac"] * res["parity_sampler_depth_rays"])
     assert res["parity_grad_tensors"] >= 60
     assert res["parity_loss_abs"] < 1e-4 * max(1.0, abs(res["loss_oracle"]))
     assert res["parity_grad_rel_worst"] < TOL.TRAIN_GRAD_REL_RENDERING, res["parity_grad_worst_tensor"]
