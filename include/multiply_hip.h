@@ -24,8 +24,11 @@ extern "C" {
 #define MP_BIAS_STRIDE 288 /* floats per layer in a packed bias table */
 #define MP_SMPL_V 6890
 #define MP_SMPL_J 24
-#define MP_KNN_CLUSTER 64   /* vertices per nearest-neighbour cluster */
-#define MP_KNN_NC 108       /* clusters (108*64 = 6912 >= 6890, padded) */
+#ifndef MP_KNN_CLUSTER      /* (overridable for experiments: -DMP_KNN_CLUSTER=32 -DMP_KNN_NC=216 + the same two environment variables for hip.py) */
+#define MP_KNN_CLUSTER 32   /* vertices per nearest-neighbour cluster (a power of two <= 64).  Round 6: 32 x 216 instead of 64 x 108 -- the */
+#define MP_KNN_NC 216       /* clusters (216*32 = 6912 >= 6890, padded); <= 511.  cluster scan is wave-uniform, so finer clusters prune   */
+                            /* better: sampler warp -19 %, Jacobian -18 %, frame -1.4 ms; 16 x 431: another -0.4 ms, training +0.8 ms    */
+#endif
 
 enum { MP_ACT_NONE = 0, MP_ACT_SOFTPLUS = 1, MP_ACT_RELU = 2, MP_ACT_SIGMUL = 3 };
 
@@ -200,7 +203,7 @@ int mp_ray_cull(const float* dirs, const float* pose, const float* obb, int n_ra
 /* The same, refined for eval-mode rendering without changing a pixel: a ray that passes the box but stays further than the
  * outlier radius 0.1 (deformer.py:49) from every vertex on [near, far[r]] carries only sdf = 4 samples (multiply.py:142-143);
  * when 1 - exp(-sigma(4) (far - near)) is exactly 0 in fp32 its pixel is the background's, exactly like a ray outside the
- * box, and it is dropped here.  cbound [108][4] = the bounding spheres of the posed vertex clusters (mp_knn_build), far [R]
+ * box, and it is dropped here.  cbound [MP_KNN_NC][4] = the bounding spheres of the posed vertex clusters (mp_knn_build), far [R]
  * from mp_ray_setup, beta = device scalar (density), near_ = the sampler's near bound. */
 int mp_ray_cull_near(const float* dirs, const float* pose, const float* obb, const float* cbound, const float* far,
                      const float* beta, float near_, int n_rays, int group_size, int* hit_index, int* hit_count,
@@ -227,7 +230,7 @@ int mp_warp_inverse(const float* pts, const float* dirs, const float* pose, cons
                     void* stream);
 /* bin_work (optional, mode 0 with implicit samples only; mp_warp_bin_work_bytes(max_rays * n_s) bytes, 16-byte aligned): the
  * points are first grouped by their nearest vertex cluster, so that the 64 points of a wave open the same few clusters -- a
- * training batch's random pixels otherwise scatter every wave over the whole body (50 of 108 clusters opened per wave).  Results
+ * training batch's random pixels otherwise scatter every wave over the whole body (50 of the then 108 clusters opened per wave).  Results
  * are identical (they go out by point id); only the order of the worklist changes. */
 int mp_warp_bin_work_bytes(int n_points);
 /* The same for the final samples of the shading pass (z rows hold n_s+1 depths).  eval_mode: outliers get sdf 4 and are

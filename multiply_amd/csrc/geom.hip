@@ -192,8 +192,8 @@ __global__ __launch_bounds__(256) void k_smpl_verts(const float* __restrict__ po
 // ------------------------------------------------------------------------------------------------ KNN structure
 __global__ __launch_bounds__(64) void k_knn_build(const float* __restrict__ verts, const int* __restrict__ perm,
                                                   float4* __restrict__ vsorted, float4* __restrict__ cbound) {
-    const int c = blockIdx.x, l = threadIdx.x;
-    const int id = perm[c * CL + l];
+    const int c = blockIdx.x, l = threadIdx.x;          // one full wave per cluster; lanes >= CL (CL < 64) hold padding
+    const int id = l < CL ? perm[c * CL + l] : -1;
     float x = 0.f, y = 0.f, z = 0.f;
     if (id >= 0) { x = verts[3 * id]; y = verts[3 * id + 1]; z = verts[3 * id + 2]; }
     const float n = wave_sum(id >= 0 ? 1.f : 0.f);
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64) void k_knn_build(const float* __restrict__ vert
     float4 o;
     if (id >= 0) { o.x = x; o.y = y; o.z = z; o.w = __int_as_float(id); }
     else { o.x = 1e18f; o.y = 1e18f; o.z = 1e18f; o.w = __int_as_float(INT_MAX - 1); }
-    vsorted[c * CL + l] = o;
+    if (l < CL) vsorted[c * CL + l] = o;
     if (l == 0) cbound[c] = make_float4(cx, cy, cz, r * 1.00001f + 1e-7f);
 }
 
@@ -232,7 +232,7 @@ extern "C" int mp_geom_prof_read(unsigned long long* host16, int reset) {
 // Exact nearest vertex among the clustered set held in LDS (vs, cb), for the 64 points of one wave at once.
 // The wave's points are spatially coherent (neighbouring rays at the same sample index), so clusters are culled ONCE per
 // wave against the bounding box of its points: lane c tests clusters c and c+64 in parallel (two LDS reads instead of a
-// latency-bound loop over all 108 spheres), and only the surviving clusters are scanned vertex by vertex.
+// latency-bound loop over all the spheres), and only the surviving clusters are scanned vertex by vertex.
 //   cap2 (per lane): squared search radius; < 0 = idle lane.  A vertex within the cap, if any, is the exact nearest one
 //   (ties -> lowest vertex id, like an argmin over the original order: pytorch3d knn_points / deformer.py:39).
 //   Returns bi = INT_MAX when no vertex lies within the cap.
@@ -244,14 +244,15 @@ __device__ __forceinline__ void knn_capped(const float4* vs, const float4* cb, f
     const float lx = wave_min(on ? px : FLT_MAX), ly = wave_min(on ? py : FLT_MAX), lz = wave_min(on ? pz : FLT_MAX);
     const float hx = wave_max(on ? px : -FLT_MAX), hy = wave_max(on ? py : -FLT_MAX), hz = wave_max(on ? pz : -FLT_MAX);
     const float capr = sqrtf(wave_max(on ? cap2 : 0.0f));
-    unsigned long long cand[2];
+    constexpr int NH = (NC + 63) / 64;      // candidate masks: 64 clusters each
+    unsigned long long cand[NH];
     // the candidate sphere closest to the middle of the wave's points is scanned first: it usually holds the neighbour of
     // most lanes, and with that distance in hand the per-cluster bound below rejects most of the other candidates
     const float mx = 0.5f * (lx + hx), my = 0.5f * (ly + hy), mz = 0.5f * (lz + hz);
     float nearest = FLT_MAX;
     int nearest_c = -1;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NH; ++h) {
         const int c = lane + 64 * h;
         bool hit = false;
         if (c < NC) {
@@ -267,11 +268,16 @@ __device__ __forceinline__ void knn_capped(const float4* vs, const float4* cb, f
         cand[h] = __ballot(hit);
     }
     int first_c = -1;
-    if (cand[0] | cand[1]) {
+    unsigned long long any_c = 0;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) any_c |= cand[h];
+    if (any_c) {
         const float wm = wave_min(nearest);
         const unsigned long long who = __ballot(nearest_c >= 0 && nearest == wm);
         first_c = __shfl(nearest_c, __builtin_ctzll(who));
-        cand[first_c >> 6] &= ~(1ull << (first_c & 63));
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+            if (h == (first_c >> 6)) cand[h] &= ~(1ull << (first_c & 63));
     }
     // running minimum as ONE 64-bit key (distance bits << 32 | vertex id): distances are >= 0, so their bit patterns order
     // like the values, and a tie in distance falls through to the lower vertex id (the argmin order of the reference's
@@ -281,9 +287,10 @@ __device__ __forceinline__ void knn_capped(const float4* vs, const float4* cb, f
     const f32x2 PX = {px, px}, PY = {py, py}, PZ = {pz, pz};
     const unsigned long long gp1 = GP_T();
     GP_ADD(2, gp1 - gp0);
-    GP_ADD(4, __popcll(cand[0]) + __popcll(cand[1]));
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NH; ++h) GP_ADD(4, __popcll(cand[h]));
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
         unsigned long long m = cand[h];
         while (m || (h == 0 && first_c >= 0)) {
             int c;
@@ -315,7 +322,7 @@ __device__ __forceinline__ void knn_capped(const float4* vs, const float4* cb, f
 }
 
 // Unbounded exact search.  An upper bound of the nearest-vertex distance is cheap: every cluster's bounding sphere
-// contains at least one vertex, so d_nn <= min_c (|p - centre_c| + radius_c)  (108 broadcast LDS reads per lane).  With
+// contains at least one vertex, so d_nn <= min_c (|p - centre_c| + radius_c)  (NC broadcast LDS reads per lane).  With
 // that per-lane cap a single culled pass finds the exact neighbour of near and far points alike (the previous scheme,
 // growing a fixed cap geometrically, re-culled the clusters up to 7 times for the far samples of a training ray).
 // want: lane participates.
@@ -535,7 +542,7 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
 // ---- TRAINING: the points of a wave grouped by their nearest vertex cluster -----------------------------------------------------
 // A training batch is 512 RANDOM pixels: the 64 hit rays of a slab are scattered over the body's box, and most samples of a ray
 // lie in free space far from the surface, where many clusters are about equally far.  The cluster scan is wave-uniform (a
-// cluster is scanned when ANY lane may improve in it), so such a slab opened 50 of the 108 clusters (measured: 226 k cycles per
+// cluster is scanned when ANY lane may improve in it), so such a slab opened 50 of the (then 108) clusters (measured: 226 k cycles per
 // slab, 1.15 ms per iteration).  Which 64 points share a wave is the kernel's own business -- results go out by point id -- so
 // the points are first binned by the cluster whose bounding sphere is nearest (k_warp_bin: one atomic per point gives bin and
 // rank), laid out bin after bin (k_warp_binned: position, point id), and k_warp_inverse walks that array.
@@ -575,11 +582,11 @@ __global__ __launch_bounds__(1024) void k_warp_bin(const float* __restrict__ dir
             if (gap < best) { best = gap; bc = c; }
         }
         lrank = atomicAdd(&lcount[bc], 1);     // (LDS: the global counters see one add per workgroup and bin, not one per point --
-    }                                          //  60 k same-address atomics on 108 words took 110 us)
+    }                                          //  60 k same-address atomics on ~100 words took 110 us)
     __syncthreads();
     for (int c = threadIdx.x; c < NC; c += blockDim.x) lbase[c] = lcount[c] ? atomicAdd(&bincount[c], lcount[c]) : 0;
     __syncthreads();
-    if (on) binrank[i] = (bc << 24) | (lbase[bc] + lrank);
+    if (on) binrank[i] = (bc << 22) | (lbase[bc] + lrank);      // bin (< 512) | rank inside the bin (< 4 M points per launch); -1 = none
     else if (i < max_rays * n_s) binrank[i] = -1;
 }
 __global__ __launch_bounds__(256) void k_warp_binned(const float* __restrict__ dirs, const float* __restrict__ pose,
@@ -601,7 +608,7 @@ __global__ __launch_bounds__(256) void k_warp_binned(const float* __restrict__ d
     if (br < 0) return;
     float x, y, zz;
     warp_sample_point(dirs, pose, hit_index, z, z_stride, n_s, n_rays, nullptr, i, x, y, zz);
-    binned[start[br >> 24] + (br & 0xffffff)] = make_float4(x, y, zz, __int_as_float(i));
+    binned[start[br >> 22] + (br & 0x3fffff)] = make_float4(x, y, zz, __int_as_float(i));
 }
 
 // Points are addressed like in k_warp_inverse (slab = 64 neighbouring hit rays x one sample index, so the 64 canonical
@@ -1065,7 +1072,7 @@ extern "C" int mp_smpl_pose(const float* v_template, const float* shapedirs, con
 }
 
 extern "C" int mp_knn_build(const float* verts, const int* perm, float* vsorted, float* cbound, void* stream) {
-    hipLaunchKernelGGL(k_knn_build, dim3(NC), dim3(CL), 0, (hipStream_t)stream, verts, perm, (float4*)vsorted,
+    hipLaunchKernelGGL(k_knn_build, dim3(NC), dim3(64), 0, (hipStream_t)stream, verts, perm, (float4*)vsorted,
                        (float4*)cbound);
     return (int)hipGetLastError();
 }
@@ -1535,16 +1542,18 @@ extern "C" int mp_blend_table(const float* skin_w, const float* tfs, int n_verts
     return (int)hipGetLastError();
 }
 
-// bin_work (mp_warp_bin_work_bytes(max_rays * n_s) bytes, 16-byte aligned): [128] bin counts, [n] bin << 24 | rank, [n] float4
-extern "C" int mp_warp_bin_work_bytes(int n_points) { return 512 + 4 * ((n_points + 3) / 4 * 4) + 16 * n_points; }
+// bin_work (mp_warp_bin_work_bytes(max_rays * n_s) bytes, 16-byte aligned): [BIN_CNT] bin counts, [n] bin << 22 | rank, [n] float4
+constexpr int BIN_CNT = (NC + 127) / 128 * 128;      // bin counters at the head of the work buffer (a multiple of 512 bytes)
+static_assert(NC <= 511 && (CL & (CL - 1)) == 0 && CL <= 64 && NC * CL >= V, "cluster layout (include/multiply_hip.h)");
+extern "C" int mp_warp_bin_work_bytes(int n_points) { return 4 * BIN_CNT + 4 * ((n_points + 3) / 4 * 4) + 16 * n_points; }
 static void warp_bin(const float* dirs, const float* pose, const int* hit_index, const int* hit_count, const float* z, int z_stride,
                      int n_s, int max_rays, const float* cbound, const int* ray_active, const int* launch_active, void* bin_work,
                      hipStream_t st, const float4*& binned, const int*& bincount) {
     const int n = max_rays * n_s;
     int* cnt = (int*)bin_work;
-    int* binrank = cnt + 128;
-    float4* out = (float4*)((char*)bin_work + 512 + 4 * ((n + 3) / 4 * 4));
-    hipMemsetAsync(cnt, 0, 512, st);
+    int* binrank = cnt + BIN_CNT;
+    float4* out = (float4*)((char*)bin_work + 4 * BIN_CNT + 4 * ((n + 3) / 4 * 4));
+    hipMemsetAsync(cnt, 0, 4 * BIN_CNT, st);
     hipLaunchKernelGGL(k_warp_bin, dim3((n + 1023) / 1024), dim3(1024), 0, st, dirs, pose, hit_index, hit_count, z, z_stride, n_s, max_rays,
                        cbound, ray_active, launch_active, binrank, cnt);
     hipLaunchKernelGGL(k_warp_binned, dim3((n + 255) / 256), dim3(256), 0, st, dirs, pose, hit_index, hit_count, z, z_stride, n_s,

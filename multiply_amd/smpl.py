@@ -65,8 +65,8 @@ class SMPLDeviceTables:
 
 
 def knn_cluster_perm(verts_np):
-    """Static clustering for the exact nearest-vertex search: vertices are split kd-tree style into leaves of exactly 64
-    (the last one partial) so that clusters stay spatially compact under posing. Returns int32 [108*64], -1 = padding."""
+    """Static clustering for the exact nearest-vertex search: vertices are split kd-tree style into leaves of exactly KNN_CLUSTER
+    (32; the last one partial) so that clusters stay spatially compact under posing. Returns int32 [KNN_NC * KNN_CLUSTER], -1 = padding."""
     leaves = []
 
     def split(idx):
