@@ -411,6 +411,33 @@ __global__ void k_blend_table(const float* __restrict__ skin_w, const float* __r
 
 constexpr int WARP_THREADS = 1024;
 constexpr int WARP_LDS = NC * CL * 16 + NC * 16 + 32;
+// k_warp_inverse appends the ids of the points that need a network query to ONE list.  One returning atomicAdd per slab on that list's
+// counter was the kernel: 624 k same-address atomics per frame serialise in one L2 channel (shading launches 4.75 ms, 2.30 ms with the
+// atomic removed; profiles/r06_worklist_atomic.txt).  Every wave therefore stages ids in its own strip of LDS and reserves list space
+// once per WL_STAGE - 64 ids or more (~8 slabs).
+constexpr int WL_STAGE = 512;
+constexpr int WARP_INV_LDS = WARP_LDS + (WARP_THREADS / 64) * WL_STAGE * 4;
+
+// Which 64 (ray, sample) pairs share a wave of a rays-mode launch.  Rounds 1-5: 64 neighbouring rays x one sample index.  The per-point
+// outputs are addressed [ray][sample], so every store instruction of such a wave touches 64 cache lines; the shading launch (mode 2: xc,
+// flags, nearest-vertex index, and after it the Jacobian's 36 bytes per point) therefore takes MP_SLAB_RUN consecutive samples of 64 /
+// MP_SLAB_RUN neighbouring rays (round 6) -- runs share their lines, the points stay as compact in space (pixels of a tile row x a short
+// stretch of depth).  The sampler's launches (modes 0 / 1) write one value per point and measured slower that way: they keep 64 x 1.
+#ifndef MP_SLAB_RUN
+#define MP_SLAB_RUN 8
+#endif
+#ifndef MP_SLAB_RUN_SAMPLER
+#define MP_SLAB_RUN_SAMPLER 1
+#endif
+__host__ __device__ constexpr int slab_run(int mode) { return mode == 2 ? MP_SLAB_RUN : MP_SLAB_RUN_SAMPLER; }
+
+// one wave: reserve `staged` entries of the list and copy the wave's strip there (wave-private LDS: in order, no barrier)
+__device__ __forceinline__ void worklist_flush(const int* stage, int staged, int* __restrict__ worklist, int* __restrict__ work_count, int lane) {
+    int base = 0;
+    if (lane == 0) base = atomicAdd(work_count, staged);
+    base = __shfl(base, 0);
+    for (int i = lane; i < staged; i += 64) worklist[base + i] = stage[i];
+}
 
 // mode 0: all points -> xc + worklist; mode 1: eval, outliers get sdf 4 and are skipped;
 // mode 2: eval shading, outliers get sdf 4 and are skipped only when their alpha is exactly 0 in fp32
@@ -428,6 +455,8 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
     float4* vs = (float4*)smem;
     float4* cb = vs + NC * CL;
     float* box = (float*)(cb + NC);  // [6] conservative bounds of the vertex set (from the cluster spheres)
+    int* stage = (int*)(smem + WARP_LDS) + (threadIdx.x >> 6) * WL_STAGE;   // this wave's strip of list entries not yet written out
+    int staged = 0;
     load_knn_lds(vs, cb, vsorted, cbound);
     __syncthreads();
     if (threadIdx.x < 64) {
@@ -449,7 +478,8 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
         n_pts = 0;
         for (int c = 0; c < NC; ++c) n_pts += bincount[c];
     }
-    const int n_slab = rays ? ((n_rays + 63) / 64) * n_s : (n_pts + 63) / 64;
+    const int run = slab_run(mode), n_sr = (n_s + run - 1) / run, rpw = 64 / run;       // samples per run, runs per ray, rays per wave
+    const int n_slab = rays ? ((n_rays + rpw - 1) / rpw) * n_sr : (n_pts + 63) / 64;
     float cam[3] = {0.f, 0.f, 0.f};
     if (rays) { cam[0] = pose[3]; cam[1] = pose[7]; cam[2] = pose[11]; }
     const float cap2 = 0.0101f;  // eval only needs neighbours within the 0.1 outlier radius
@@ -459,8 +489,8 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
         const unsigned long long gs0 = GP_T();
         GP_ADD(0, 1);
         if (rays) {
-            const int k = (slab / n_s) * 64 + lane, s = slab % n_s;
-            if (k < n_rays && (!ray_active || ray_active[k])) {
+            const int rb = slab / n_sr, k = rb * rpw + lane / run, s = (slab - rb * n_sr) * run + lane % run;
+            if (k < n_rays && s < n_s && (!ray_active || ray_active[k])) {
                 const int r = hit_index[k];
                 const float t = z[(size_t)k * z_stride + s];
                 x = cam[0] + t * dirs[3 * r]; y = cam[1] + t * dirs[3 * r + 1]; zz = cam[2] + t * dirs[3 * r + 2];
@@ -523,10 +553,9 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
         if (worklist) {
             const unsigned long long m = __ballot(append);
             if (m) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(work_count, __popcll(m));
-                base = __shfl(base, 0);
-                if (append) worklist[base + __popcll(m & ((1ull << lane) - 1ull))] = pid;
+                if (append) stage[staged + __popcll(m & ((1ull << lane) - 1ull))] = pid;
+                staged += __popcll(m);
+                if (staged > WL_STAGE - 64) { worklist_flush(stage, staged, worklist, work_count, lane); staged = 0; }
             }
         }
 #ifdef MP_GEOM_PROF
@@ -536,6 +565,7 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
         GP_ADD(1, gs3 - gs0);
 #endif
     }
+    if (staged) worklist_flush(stage, staged, worklist, work_count, lane);
     GP_END();
 }
 
@@ -633,12 +663,13 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_jacobian(const float* __r
     GP_BEGIN();
     const bool rays = n_s > 0;
     const int n_rays = rays ? min(*hit_count, max_rays) : 0;
-    const int n_slab = rays ? ((n_rays + 63) / 64) * n_s : (n_pts + 63) / 64;
+    const int run = slab_run(2), n_sr = (n_s + run - 1) / run, rpw = 64 / run;          // (the shading launch's mapping, see k_warp_inverse)
+    const int n_slab = rays ? ((n_rays + rpw - 1) / rpw) * n_sr : (n_pts + 63) / 64;
     for (int slab = blockIdx.x * nw + wave; slab < n_slab; slab += gridDim.x * nw) {
         int id = -1;
         if (rays) {
-            const int k = (slab / n_s) * 64 + lane, s = slab % n_s;
-            if (k < n_rays && need[(size_t)k * n_s + s]) id = k * n_s + s;
+            const int rb = slab / n_sr, k = rb * rpw + lane / run, s = (slab - rb * n_sr) * run + lane % run;
+            if (k < n_rays && s < n_s && need[(size_t)k * n_s + s]) id = k * n_s + s;
         } else {
             const int i = slab * 64 + lane;
             if (i < n_pts) id = i;
@@ -1042,6 +1073,12 @@ __global__ __launch_bounds__(OBB_T) void k_obb_hull_pick(const double* __restric
         for (int k = 0; k < 3; ++k) obb[12 + k] = (float)(0.5 * (r_hi[k][0] - r_lo[k][0]) * (double)inflate);
         obb[15] = 0.0f;
     }
+}
+
+// waves of work in a rays-mode launch (the kernels' own (ray, sample) -> wave mapping)
+int ray_slabs(int max_rays, int n_s, int mode) {
+    const int run = slab_run(mode), rpw = 64 / run;
+    return ((max_rays + rpw - 1) / rpw) * ((n_s + run - 1) / run);
 }
 
 int warp_grid(int n_slab, int nw) {
@@ -1571,14 +1608,14 @@ extern "C" int mp_warp_inverse(const float* pts, const float* dirs, const float*
     // when pts != NULL, max_rays carries the number of explicit points and sdf_out may carry beta for mode 2 (unused)
     if (max_rays <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    MP_LDS_ATTR((k_warp_inverse), WARP_LDS);
-    const int n_slab = pts ? (max_rays + 63) / 64 : ((max_rays + 63) / 64) * n_s;
+    MP_LDS_ATTR((k_warp_inverse), WARP_INV_LDS);
+    const int n_slab = pts ? (max_rays + 63) / 64 : ray_slabs(max_rays, n_s, mode & 3);
     const int threads = warp_threads(n_slab), nw = threads / 64;
     const float4* binned = nullptr;
     const int* bincount = nullptr;
     if (bin_work && !pts && (mode & 3) == 0) warp_bin(dirs, pose, hit_index, hit_count, z, z_stride, n_s, max_rays, cbound, ray_active,
                                                       launch_active, bin_work, st, binned, bincount);
-    hipLaunchKernelGGL(k_warp_inverse, dim3(warp_grid(n_slab, nw)), dim3(threads), WARP_LDS, st, pts, dirs, pose,
+    hipLaunchKernelGGL(k_warp_inverse, dim3(warp_grid(n_slab, nw)), dim3(threads), WARP_INV_LDS, st, pts, dirs, pose,
                        hit_index, hit_count, z, z_stride, n_s, max_rays, pts ? max_rays : 0, vsorted, cbound,
                        (const float4*)blend_table, mode & 3, ray_active, (const float*)nullptr, launch_active, xc, outlier, (unsigned char*)nullptr, sdf_out,
                        worklist, work_count, (int*)nullptr, binned, bincount);
@@ -1594,14 +1631,14 @@ extern "C" int mp_warp_inverse_shade(const float* dirs, const float* pose, const
                                      void* stream) {
     if (max_rays <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    MP_LDS_ATTR((k_warp_inverse), WARP_LDS);
-    const int n_slab = ((max_rays + 63) / 64) * n_s;
+    MP_LDS_ATTR((k_warp_inverse), WARP_INV_LDS);
+    const int n_slab = ray_slabs(max_rays, n_s, eval_mode ? 2 : 0);
     const int threads = warp_threads(n_slab), nw = threads / 64;
     const float4* binned = nullptr;
     const int* bincount = nullptr;
     if (bin_work && !eval_mode) warp_bin(dirs, pose, hit_index, hit_count, z, z_stride, n_s, max_rays, cbound, nullptr, nullptr, bin_work,
                                          st, binned, bincount);
-    hipLaunchKernelGGL(k_warp_inverse, dim3(warp_grid(n_slab, nw)), dim3(threads), WARP_LDS, st,
+    hipLaunchKernelGGL(k_warp_inverse, dim3(warp_grid(n_slab, nw)), dim3(threads), WARP_INV_LDS, st,
                        (const float*)nullptr, dirs, pose, hit_index, hit_count, z, z_stride, n_s, max_rays, 0, vsorted,
                        cbound, (const float4*)blend_table, eval_mode ? 2 : 0, (const int*)nullptr, beta, (const int*)nullptr, xc, outlier,
                        need_flag, sdf_out, worklist, work_count, nn_index, binned, bincount);
@@ -1615,7 +1652,7 @@ extern "C" int mp_warp_jacobian(const float* xc, const unsigned char* need, cons
     if ((n_s > 0 ? max_rays : n_pts) <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     MP_LDS_ATTR((k_warp_jacobian), WARP_LDS);
-    const int n_slab = n_s > 0 ? ((max_rays + 63) / 64) * n_s : (n_pts + 63) / 64;
+    const int n_slab = n_s > 0 ? ray_slabs(max_rays, n_s, 2) : (n_pts + 63) / 64;
     const int threads = warp_threads(n_slab), nw = threads / 64;
     hipLaunchKernelGGL(k_warp_jacobian, dim3(warp_grid(n_slab, nw)), dim3(threads), WARP_LDS, st, xc, need, hit_count,
                        max_rays, n_s, n_pts, vsorted_c, cbound_c, (const float4*)blend_table, jinv, nn_index, seed, verts_c);
