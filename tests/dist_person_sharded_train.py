@@ -49,10 +49,15 @@ def main():
         ok = ok and d_loss <= 1e-6 * max(1.0, abs(float(loss1)))
         for k in ("rgb_values", "acc_map", "acc_person_list", "grad_theta", "points"):
             d = (torch.nan_to_num(out1[k].detach()) - torch.nan_to_num(out2[k].detach())).abs().max().item()
+            if not d < 1e-5:
+                print(f"[rank {rank}] epoch {epoch}: output {k} differs by {d:.3e}", flush=True)
             ok = ok and d < 1e-5
         if epoch < 250:
-            ok = ok and torch.equal(out1["index_off_surface"], out2["index_off_surface"]) \
+            same = torch.equal(out1["index_off_surface"], out2["index_off_surface"]) \
                 and torch.equal(out1["index_in_surface"], out2["index_in_surface"])
+            if not same:
+                print(f"[rank {rank}] epoch {epoch}: in / off-surface flags differ", flush=True)
+            ok = ok and same
         worst, n_cmp, n_none = 0.0, 0, 0
         for name, a in g1.items():
             b = g2[name]
@@ -66,6 +71,8 @@ def main():
             if a is None:
                 continue
             rel = (a - b).abs().max().item() / max(a.abs().max().item(), 1e-12)
+            if not rel < 2e-4:
+                print(f"[rank {rank}] epoch {epoch}: gradient of {name} differs by {rel:.3e} (relative to its maximum)", flush=True)
             worst, n_cmp = max(worst, rel), n_cmp + 1
         print(f"[rank {rank}] epoch {epoch}: {n_cmp} gradients compared, worst relative difference {worst:.2e}; "
               f"{n_none} remote-person tensors without gradient", flush=True)
