@@ -141,8 +141,9 @@ int mp_smpl_pose(const float* v_template, const float* shapedirs, const float* p
 
 /* Nearest-neighbour acceleration structure over one vertex set (exact K=1 search, replaces
  * pytorch3d.ops.knn_points, deformer.py:39): vertices gathered in cluster order + bounding spheres.
- *   perm [NC*64] vertex ids in cluster order (-1 = padding); vsorted [NC*64][4] = x,y,z,id-as-int-bits;
- *   cbound [NC][4] = centre, radius. */
+ *   perm [NC*CL] vertex ids in cluster order (-1 = padding); vsorted [NC*CL][4] = x,y,z,id-as-int-bits;
+ *   cbound [NC + NC / 2][4] = centre, radius of every cluster, then of every PAIR of clusters (2c, 2c + 1): the coarse granularity the
+ *   training-mode searches of mp_warp_inverse / mp_warp_inverse_shade run on; the other consumers read the first NC rows. */
 int mp_knn_build(const float* verts, const int* perm, float* vsorted, float* cbound, void* stream);
 
 /* Oriented box of the posed vertices inflated by `inflate` (multiply.py:208-214; PCA axes instead of trimesh's

@@ -11,6 +11,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 namespace {
 
 constexpr int V = MP_SMPL_V, NJ = MP_SMPL_J, NC = MP_KNN_NC, CL = MP_KNN_CLUSTER;
+constexpr int NCC = MP_KNN_NC / 2, CLC = 2 * MP_KNN_CLUSTER;      // the coarse granularity of the training searches: pairs of clusters (k_knn_build)
+static_assert(MP_KNN_NC % 2 == 0 && 2 * MP_KNN_CLUSTER <= 64, "coarse clusters = pairs of fine ones, one wave each");
+__host__ __device__ constexpr int mp_fine_clusters() { return MP_KNN_NC; }      // (where a local NC shadows the fine count)
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -190,13 +193,30 @@ __global__ __launch_bounds__(256) void k_smpl_verts(const float* __restrict__ po
 }
 
 // ------------------------------------------------------------------------------------------------ KNN structure
+// Blocks NC .. NC + NCC - 1 (round 6): the bounding sphere of the PAIR of clusters (2 cc, 2 cc + 1) -- consecutive kd leaves, siblings --
+// as cbound[NC + cc].  The training searches (every sample of a ray needs its exact neighbour however far away it is, so many
+// spheres are about equally near) run on these NCC = NC / 2 coarse clusters of 2 CL vertices: with the fine ones the training
+// warp cost +30 % (twice the sphere tests and per-cluster steps), the eval searches -19 % (profiles/r06_cluster_ab.txt).
 __global__ __launch_bounds__(64) void k_knn_build(const float* __restrict__ verts, const int* __restrict__ perm,
                                                   float4* __restrict__ vsorted, float4* __restrict__ cbound) {
-    const int c = blockIdx.x, l = threadIdx.x;          // one full wave per cluster; lanes >= CL (CL < 64) hold padding
+    const int l = threadIdx.x;
+    if (blockIdx.x >= NC) {
+        const int cc = blockIdx.x - NC;
+        const int id = l < 2 * CL ? perm[cc * 2 * CL + l] : -1;
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (id >= 0) { x = verts[3 * id]; y = verts[3 * id + 1]; z = verts[3 * id + 2]; }
+        const float n = fmaxf(wave_sum(id >= 0 ? 1.f : 0.f), 1.f);      // (an all-padding cluster: a zero sphere at the origin)
+        const float cx = wave_sum(x) / n, cy = wave_sum(y) / n, cz = wave_sum(z) / n;
+        const float dx = x - cx, dy = y - cy, dz = z - cz;
+        const float r = wave_max(id >= 0 ? sqrtf(dx * dx + dy * dy + dz * dz) : 0.f);
+        if (l == 0) cbound[NC + cc] = make_float4(cx, cy, cz, r * 1.00001f + 1e-7f);
+        return;
+    }
+    const int c = blockIdx.x;                           // one full wave per cluster; lanes >= CL (CL < 64) hold padding
     const int id = l < CL ? perm[c * CL + l] : -1;
     float x = 0.f, y = 0.f, z = 0.f;
     if (id >= 0) { x = verts[3 * id]; y = verts[3 * id + 1]; z = verts[3 * id + 2]; }
-    const float n = wave_sum(id >= 0 ? 1.f : 0.f);
+    const float n = fmaxf(wave_sum(id >= 0 ? 1.f : 0.f), 1.f);      // (an all-padding cluster: a zero sphere at the origin)
     const float cx = wave_sum(x) / n, cy = wave_sum(y) / n, cz = wave_sum(z) / n;
     const float dx = x - cx, dy = y - cy, dz = z - cz;
     const float r = wave_max(id >= 0 ? sqrtf(dx * dx + dy * dy + dz * dz) : 0.f);
@@ -213,10 +233,10 @@ __global__ __launch_bounds__(64) void k_knn_build(const float* __restrict__ vert
 #ifdef MP_GEOM_PROF
 __device__ unsigned long long g_geom_prof[16];
 #define GP_T() __builtin_readcyclecounter()
-__shared__ unsigned long long gp_lds[16][8];   // per-wave accumulators: one global atomic per wave and counter at exit
+__shared__ unsigned long long gp_lds[16][16];   // per-wave accumulators: one global atomic per wave and counter at exit
 #define GP_ADD(i, v) do { if ((threadIdx.x & 63) == 0) gp_lds[threadIdx.x >> 6][i] += (unsigned long long)(v); } while (0)
-#define GP_BEGIN() do { if ((threadIdx.x & 63) < 8) gp_lds[threadIdx.x >> 6][threadIdx.x & 63] = 0; } while (0)
-#define GP_END() do { if ((threadIdx.x & 63) < 8) atomicAdd(&g_geom_prof[threadIdx.x & 63], gp_lds[threadIdx.x >> 6][threadIdx.x & 63]); } while (0)
+#define GP_BEGIN() do { if ((threadIdx.x & 63) < 16) gp_lds[threadIdx.x >> 6][threadIdx.x & 63] = 0; } while (0)
+#define GP_END() do { if ((threadIdx.x & 63) < 16) atomicAdd(&g_geom_prof[threadIdx.x & 63], gp_lds[threadIdx.x >> 6][threadIdx.x & 63]); } while (0)
 extern "C" int mp_geom_prof_read(unsigned long long* host16, int reset) {
     hipError_t e = hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_geom_prof), sizeof(unsigned long long) * 16);
     if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_geom_prof), z, sizeof(z)); }
@@ -236,8 +256,14 @@ extern "C" int mp_geom_prof_read(unsigned long long* host16, int reset) {
 //   cap2 (per lane): squared search radius; < 0 = idle lane.  A vertex within the cap, if any, is the exact nearest one
 //   (ties -> lowest vertex id, like an argmin over the original order: pytorch3d knn_points / deformer.py:39).
 //   Returns bi = INT_MAX when no vertex lies within the cap.
+//   NC / CL: the granularity searched (the fine clusters, or pairs of them: cb = the coarse spheres, see k_knn_build).
+#ifndef MP_KNN_BP
+#define MP_KNN_BP 2      // vertex pairs read ahead in the cluster scan
+#endif
+template <int NCX = NC, int CLX = CL>
 __device__ __forceinline__ void knn_capped(const float4* vs, const float4* cb, float px, float py, float pz, float cap2,
                                            float& best, int& bi) {
+    constexpr int NC = NCX, CL = CLX;
     const int lane = threadIdx.x & 63;
     const bool on = cap2 >= 0.0f;
     const unsigned long long gp0 = GP_T();
@@ -282,7 +308,10 @@ __device__ __forceinline__ void knn_capped(const float4* vs, const float4* cb, f
     // running minimum as ONE 64-bit key (distance bits << 32 | vertex id): distances are >= 0, so their bit patterns order
     // like the values, and a tie in distance falls through to the lower vertex id (the argmin order of the reference's
     // brute-force search) -- one v_cmp_lt_u64 and two selects per vertex, no branch in the scan.  Lanes that are off
-    // hold key 0, which nothing undercuts.
+    // hold key 0, which nothing undercuts.  [Round 6 tried (distance, id) with a FLOAT compare + a wave-wide tie mask that
+    // repeats the search with these keys when a distance equals a running minimum: 14 instead of 16 VALU instructions per
+    // vertex pair, and SLOWER (training warp 64 -> 79 us, sampler warp 2.24 -> 2.34 ms): the compares then write scalar
+    // mask pairs (VOP3) that the selects read back behind wait states.  tests/test_geom_gpu.py holds the tie test it left.]
     unsigned long long key = on ? (((unsigned long long)__float_as_uint(cap2) << 32) | (unsigned)INT_MAX) : 0ull;
     const f32x2 PX = {px, px}, PY = {py, py}, PZ = {pz, pz};
     const unsigned long long gp1 = GP_T();
@@ -303,16 +332,34 @@ __device__ __forceinline__ void knn_capped(const float4* vs, const float4* cb, f
             GP_ADD(5, 1);
             // two vertices per step in packed fp32 (v_pk_add / v_pk_mul / v_pk_fma_f32): the cluster is stored as pairs
             // (xa xb ya yb)(za zb ida idb), see load_knn_lds
+            // The reads are software-pipelined by hand, KNN_BP pairs ahead (round 6): left to itself the compiler issued the two
+            // reads of a pair and waited for them at once -- hidden by the other waves of an eval launch, but a training launch has
+            // ONE wave per SIMD and paid the LDS latency 32 times per cluster (6.4 k cycles per 64 vertices, tools/geom_prof_train.py).
             const float4* cv = vs + c * CL;
-#pragma unroll 8
-            for (int k = 0; k < CL / 2; ++k) {
-                const float4 A = cv[2 * k], B = cv[2 * k + 1];
-                const f32x2 fx = PX - (f32x2){A.x, A.y}, fy = PY - (f32x2){A.z, A.w}, fz = PZ - (f32x2){B.x, B.y};
-                const f32x2 d2 = __builtin_elementwise_fma(fz, fz, __builtin_elementwise_fma(fy, fy, fx * fx));
-                const unsigned long long ka = ((unsigned long long)__float_as_uint(d2.x) << 32) | __float_as_uint(B.z);
-                const unsigned long long kb = ((unsigned long long)__float_as_uint(d2.y) << 32) | __float_as_uint(B.w);
-                key = ka < key ? ka : key;
-                key = kb < key ? kb : key;
+            constexpr int BP = MP_KNN_BP;
+            static_assert((CL / 2) % BP == 0, "pairs per block");
+            float4 A[BP], B[BP], An[BP], Bn[BP];
+#pragma unroll
+            for (int j = 0; j < BP; ++j) { A[j] = cv[2 * j]; B[j] = cv[2 * j + 1]; }
+#pragma unroll
+            for (int k0 = 0; k0 < CL / 2; k0 += BP) {
+                if (k0 + BP < CL / 2) {
+#pragma unroll
+                    for (int j = 0; j < BP; ++j) { An[j] = cv[2 * (k0 + BP + j)]; Bn[j] = cv[2 * (k0 + BP + j) + 1]; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < BP; ++j) {
+                    const f32x2 fx = PX - (f32x2){A[j].x, A[j].y}, fy = PY - (f32x2){A[j].z, A[j].w}, fz = PZ - (f32x2){B[j].x, B[j].y};
+                    const f32x2 d2 = __builtin_elementwise_fma(fz, fz, __builtin_elementwise_fma(fy, fy, fx * fx));
+                    const unsigned long long ka = ((unsigned long long)__float_as_uint(d2.x) << 32) | __float_as_uint(B[j].z);
+                    const unsigned long long kb = ((unsigned long long)__float_as_uint(d2.y) << 32) | __float_as_uint(B[j].w);
+                    key = ka < key ? ka : key;
+                    key = kb < key ? kb : key;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < BP; ++j) { A[j] = An[j]; B[j] = Bn[j]; }
             }
         }
     }
@@ -326,9 +373,10 @@ __device__ __forceinline__ void knn_capped(const float4* vs, const float4* cb, f
 // that per-lane cap a single culled pass finds the exact neighbour of near and far points alike (the previous scheme,
 // growing a fixed cap geometrically, re-culled the clusters up to 7 times for the far samples of a training ray).
 // want: lane participates.
-template <bool NEAR_FIRST>
+template <bool NEAR_FIRST, int NCX = NC, int CLX = CL>
 __device__ __forceinline__ void knn_unbounded(const float4* vs, const float4* cb, float px, float py, float pz, bool want,
                                               float& best, int& bi) {
+    constexpr int NC = NCX, CL = CLX;
     best = -1.0f;
     bi = INT_MAX;
     bool todo = want;
@@ -336,7 +384,7 @@ __device__ __forceinline__ void knn_unbounded(const float4* vs, const float4* cb
         float cap = 0.0064f;      // (0.08)^2, then (0.16)^2, (0.32)^2
         for (int round = 0; round < 3 && __any(todo); ++round) {
             float b2; int i2;
-            knn_capped(vs, cb, px, py, pz, todo ? cap : -1.0f, b2, i2);
+            knn_capped<NC, CL>(vs, cb, px, py, pz, todo ? cap : -1.0f, b2, i2);
             if (todo && i2 != INT_MAX) { best = b2; bi = i2; todo = false; }
             cap *= 4.0f;
         }
@@ -349,7 +397,7 @@ __device__ __forceinline__ void knn_unbounded(const float4* vs, const float4* cb
             ub = fminf(ub, sqrtf(ex * ex + ey * ey + ez * ez) + b.w);
         }
         float b2; int i2;
-        knn_capped(vs, cb, px, py, pz, todo ? ub * ub * 1.0005f + 1e-12f : -1.0f, b2, i2);
+        knn_capped<NC, CL>(vs, cb, px, py, pz, todo ? ub * ub * 1.0005f + 1e-12f : -1.0f, b2, i2);
         if (todo) { best = b2; bi = i2; }
     }
 }
@@ -410,7 +458,7 @@ __global__ void k_blend_table(const float* __restrict__ skin_w, const float* __r
 }
 
 constexpr int WARP_THREADS = 1024;
-constexpr int WARP_LDS = NC * CL * 16 + NC * 16 + 32;
+constexpr int WARP_LDS = NC * CL * 16 + (NC + NCC) * 16 + 32;      // vertices, fine + coarse spheres, box
 // k_warp_inverse appends the ids of the points that need a network query to ONE list.  One returning atomicAdd per slab on that list's
 // counter was the kernel: 624 k same-address atomics per frame serialise in one L2 channel (shading launches 4.75 ms, 2.30 ms with the
 // atomic removed; profiles/r06_worklist_atomic.txt).  Every wave therefore stages ids in its own strip of LDS and reserves list space
@@ -454,10 +502,12 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
     if (launch_active && *launch_active == 0) return;  // no ray of this launch is still being sampled
     float4* vs = (float4*)smem;
     float4* cb = vs + NC * CL;
-    float* box = (float*)(cb + NC);  // [6] conservative bounds of the vertex set (from the cluster spheres)
+    float4* cbc = cb + NC;           // the coarse spheres (training searches)
+    float* box = (float*)(cbc + NCC);  // [6] conservative bounds of the vertex set (from the cluster spheres)
     int* stage = (int*)(smem + WARP_LDS) + (threadIdx.x >> 6) * WL_STAGE;   // this wave's strip of list entries not yet written out
     int staged = 0;
     load_knn_lds(vs, cb, vsorted, cbound);
+    if (mode == 0) for (int i = threadIdx.x; i < NCC; i += blockDim.x) cbc[i] = ((const float4*)cbound)[NC + i];
     __syncthreads();
     if (threadIdx.x < 64) {
         float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
@@ -476,7 +526,7 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
     const int n_rays = rays ? min(*hit_count, max_rays) : 0;
     if (binned) {          // the points in the order of k_warp_bin / k_warp_binned: n_pts = how many there are
         n_pts = 0;
-        for (int c = 0; c < NC; ++c) n_pts += bincount[c];
+        for (int c = 0; c < NCC; ++c) n_pts += bincount[c];
     }
     const int run = slab_run(mode), n_sr = (n_s + run - 1) / run, rpw = 64 / run;       // samples per run, runs per ray, rays per wave
     const int n_slab = rays ? ((n_rays + rpw - 1) / rpw) * n_sr : (n_pts + 63) / 64;
@@ -514,7 +564,7 @@ __global__ __launch_bounds__(WARP_THREADS) void k_warp_inverse(
         const unsigned long long gs1 = GP_T();
         GP_ADD(6, gs1 - gs0);
 #endif
-        if (mode == 0) knn_unbounded<false>(vs, cb, x, y, zz, pid >= 0, best, bi);
+        if (mode == 0) knn_unbounded<false, NCC, CLC>(vs, cbc, x, y, zz, pid >= 0, best, bi);
         else if (__any(pid >= 0 && near_box))
             knn_capped(vs, cb, x, y, zz, (pid >= 0 && near_box) ? cap2 : -1.0f, best, bi);  // idle lanes open no cluster
         bool append = false, need_far = false, need = false, is_out = false;
@@ -594,9 +644,10 @@ __global__ __launch_bounds__(1024) void k_warp_bin(const float* __restrict__ dir
                                                    const int* __restrict__ launch_active, int* __restrict__ binrank,
                                                    int* __restrict__ bincount) {
     if (launch_active && *launch_active == 0) return;
+    constexpr int NC = NCC;                    // bins = the coarse clusters the binned walk searches
     __shared__ float4 cb[NC];
     __shared__ int lcount[NC], lbase[NC];      // this workgroup's histogram, then its base rank in every bin
-    for (int i = threadIdx.x; i < NC; i += blockDim.x) { cb[i] = ((const float4*)cbound)[i]; lcount[i] = 0; }
+    for (int i = threadIdx.x; i < NC; i += blockDim.x) { cb[i] = ((const float4*)cbound)[mp_fine_clusters() + i]; lcount[i] = 0; }
     __syncthreads();
     const int n_rays = min(*hit_count, max_rays);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -625,6 +676,7 @@ __global__ __launch_bounds__(256) void k_warp_binned(const float* __restrict__ d
                                                      const int* __restrict__ launch_active, const int* __restrict__ binrank,
                                                      const int* __restrict__ bincount, float4* __restrict__ binned) {
     if (launch_active && *launch_active == 0) return;
+    constexpr int NC = NCC;
     __shared__ int start[NC];
     if (threadIdx.x == 0) {
         int a = 0;
@@ -1109,7 +1161,7 @@ extern "C" int mp_smpl_pose(const float* v_template, const float* shapedirs, con
 }
 
 extern "C" int mp_knn_build(const float* verts, const int* perm, float* vsorted, float* cbound, void* stream) {
-    hipLaunchKernelGGL(k_knn_build, dim3(NC), dim3(64), 0, (hipStream_t)stream, verts, perm, (float4*)vsorted,
+    hipLaunchKernelGGL(k_knn_build, dim3(NC + NCC), dim3(64), 0, (hipStream_t)stream, verts, perm, (float4*)vsorted,
                        (float4*)cbound);
     return (int)hipGetLastError();
 }
@@ -1580,7 +1632,7 @@ extern "C" int mp_blend_table(const float* skin_w, const float* tfs, int n_verts
 }
 
 // bin_work (mp_warp_bin_work_bytes(max_rays * n_s) bytes, 16-byte aligned): [BIN_CNT] bin counts, [n] bin << 22 | rank, [n] float4
-constexpr int BIN_CNT = (NC + 127) / 128 * 128;      // bin counters at the head of the work buffer (a multiple of 512 bytes)
+constexpr int BIN_CNT = (NCC + 127) / 128 * 128;      // bin counters at the head of the work buffer (a multiple of 512 bytes)
 static_assert(NC <= 511 && (CL & (CL - 1)) == 0 && CL <= 64 && NC * CL >= V, "cluster layout (include/multiply_hip.h)");
 extern "C" int mp_warp_bin_work_bytes(int n_points) { return 4 * BIN_CNT + 4 * ((n_points + 3) / 4 * 4) + 16 * n_points; }
 static void warp_bin(const float* dirs, const float* pose, const int* hit_index, const int* hit_count, const float* z, int z_stride,

@@ -31,7 +31,7 @@ class SMPLDeformer(nn.Module):
         dev = self.smpl_verts.device
         self.knn_perm = torch.from_numpy(knn_cluster_perm(self.smpl_verts[0].cpu().numpy())).to(dev)
         self.vsorted_c = torch.empty(hip.KNN_NC * hip.KNN_CLUSTER, 4, dtype=torch.float32, device=dev)
-        self.cbound_c = torch.empty(hip.KNN_NC, 4, dtype=torch.float32, device=dev)
+        self.cbound_c = torch.empty(hip.KNN_CB_ROWS, 4, dtype=torch.float32, device=dev)
         hip.check(hip.lib().mp_knn_build(hip.ptr(self.smpl_verts[0].contiguous()), hip.ptr(self.knn_perm),
                                          hip.ptr(self.vsorted_c), hip.ptr(self.cbound_c), hip.stream()), "mp_knn_build")
 
@@ -56,7 +56,7 @@ class SMPLDeformer(nn.Module):
                       "mp_skinning")
             return out, outl.bool()
         vs = torch.empty(hip.KNN_NC * hip.KNN_CLUSTER, 4, dtype=torch.float32, device=dev)
-        cb = torch.empty(hip.KNN_NC, 4, dtype=torch.float32, device=dev)
+        cb = torch.empty(hip.KNN_CB_ROWS, 4, dtype=torch.float32, device=dev)
         hip.check(L.mp_knn_build(hip.ptr(verts), hip.ptr(self.knn_perm), hip.ptr(vs), hip.ptr(cb), hip.stream()),
                   "mp_knn_build")
         xc = torch.empty(n, 3, dtype=torch.float32, device=dev)

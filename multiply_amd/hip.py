@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("MP_LIB_PATH", os.path.join(_HERE, "libmultiply_hip.so
 MAX_LAYERS, MAX_CHUNKS, BIAS_STRIDE = 10, 9, 288
 ACT_NONE, ACT_SOFTPLUS, ACT_RELU, ACT_SIGMUL = 0, 1, 2, 3
 KNN_CLUSTER, KNN_NC = int(os.environ.get("MP_KNN_CLUSTER", 32)), int(os.environ.get("MP_KNN_NC", 216))   # = include/multiply_hip.h
+KNN_CB_ROWS = KNN_NC + KNN_NC // 2      # mp_knn_build's sphere table: the clusters, then the pairs of clusters the training searches use
 
 
 class MpLayer(C.Structure):

@@ -303,7 +303,7 @@ class Multiply(nn.Module):
             server.pose_into(prm, verts, tfs, jnts)
             d = self.deformer_list[p]
             vsorted = torch.empty(hip.KNN_NC * hip.KNN_CLUSTER, 4, **f32)
-            cbound = torch.empty(hip.KNN_NC, 4, **f32)
+            cbound = torch.empty(hip.KNN_CB_ROWS, 4, **f32)
             hip.check(L.mp_knn_build(hip.ptr(verts), hip.ptr(d.knn_perm), hip.ptr(vsorted), hip.ptr(cbound), st),
                       "mp_knn_build")
             btab = torch.empty(NUM_VERTS, 12, **f32)        # per-vertex inverse blended transform of this pose
@@ -595,7 +595,7 @@ class Multiply(nn.Module):
         tfs = smpl_tfs.detach().to(dev).float().reshape(24, 16).contiguous()
         d = self.deformer_list[person_id]
         vsorted = torch.empty(hip.KNN_NC * hip.KNN_CLUSTER, 4, **f32)
-        cbound = torch.empty(hip.KNN_NC, 4, **f32)
+        cbound = torch.empty(hip.KNN_CB_ROWS, 4, **f32)
         hip.check(L.mp_knn_build(hip.ptr(verts), hip.ptr(d.knn_perm), hip.ptr(vsorted), hip.ptr(cbound), st), "mp_knn_build")
         btab = torch.empty(verts.shape[0], 12, **f32)
         hip.check(L.mp_blend_table(hip.ptr(self.smpl_server_list[person_id].tables.lbs_weights), hip.ptr(tfs), verts.shape[0],

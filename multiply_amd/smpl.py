@@ -65,27 +65,31 @@ class SMPLDeviceTables:
 
 
 def knn_cluster_perm(verts_np):
-    """Static clustering for the exact nearest-vertex search: vertices are split kd-tree style into leaves of exactly KNN_CLUSTER
-    (32; the last one partial) so that clusters stay spatially compact under posing. Returns int32 [KNN_NC * KNN_CLUSTER], -1 = padding."""
+    """Static clustering for the exact nearest-vertex search: vertices are split kd-tree style into leaves of exactly 2 KNN_CLUSTER
+    (the last one partial) so that clusters stay spatially compact under posing, and every leaf once more into two halves of at most
+    KNN_CLUSTER (32): the fine clusters the eval searches scan; the leaves themselves -- the pairs (2c, 2c + 1) -- are the coarse
+    clusters of the training searches (csrc/geom.hip k_knn_build).  Returns int32 [KNN_NC * KNN_CLUSTER], -1 = padding."""
+    CL = hip.KNN_CLUSTER
     leaves = []
 
     def split(idx):
-        if len(idx) <= hip.KNN_CLUSTER:
-            leaves.append(idx)
-            return
         pts = verts_np[idx]
         axis = int(np.argmax(pts.max(0) - pts.min(0)))
         order = idx[np.argsort(pts[:, axis], kind="stable")]
-        nleaf = -(-len(idx) // hip.KNN_CLUSTER)
-        nl = (nleaf // 2) * hip.KNN_CLUSTER
+        if len(idx) <= 2 * CL:
+            leaves.append(order[:CL])
+            leaves.append(order[CL:])
+            return
+        nleaf = -(-len(idx) // (2 * CL))
+        nl = (nleaf // 2) * 2 * CL
         split(order[:nl])
         split(order[nl:])
 
     split(np.arange(verts_np.shape[0]))
-    assert len(leaves) <= hip.KNN_NC
-    perm = -np.ones(hip.KNN_NC * hip.KNN_CLUSTER, dtype=np.int32)
+    assert len(leaves) <= hip.KNN_NC and hip.KNN_NC % 2 == 0
+    perm = -np.ones(hip.KNN_NC * CL, dtype=np.int32)
     for c, l in enumerate(leaves):
-        perm[c * hip.KNN_CLUSTER:c * hip.KNN_CLUSTER + len(l)] = l
+        perm[c * CL:c * CL + len(l)] = l
     return perm
 
 

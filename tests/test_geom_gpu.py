@@ -62,6 +62,63 @@ def test_deformer_inverse_and_jacobian(server, smpl_tables):
     assert err("J^-1", jinv, J.inverse()) < 5e-5
 
 
+def test_nearest_vertex_ties_resolve_to_the_lowest_id_in_every_search_mode():
+    """deformer.py:39 (knn_points, K = 1) is an argmin over the vertices in their original order: of several vertices at EXACTLY the
+    same fp32 distance the lowest id wins.  A vertex set on a coarse dyadic lattice (many exact duplicates and mirror pairs; all the
+    arithmetic is exact in fp32, so the brute-force reference does not depend on the order of its operations) drives the training search
+    (mode 0: unbounded, coarse clusters), the eval search (mode 1: 0.1 cap, fine clusters) and the seeded canonical search of the
+    Jacobian kernel through the C ABI.  The blend table is built so that x_c reveals which vertex was taken (x_c.x = x.x + id)."""
+    import ctypes as C
+    from multiply_amd import hip
+    from multiply_amd.smpl import knn_cluster_perm
+    L = hip.lib()
+    rng = np.random.RandomState(7)
+    V = 6890
+    verts = (rng.randint(-8, 9, (V, 3)) / 8.0).astype(np.float32)                 # 17^3 = 4913 lattice sites for 6890 vertices
+    n = 20000
+    base = verts[rng.randint(0, V, n)]
+    x = (base + rng.randint(-2, 3, (n, 3)) / 32.0).astype(np.float32)              # within 0.11 of a vertex: eval's capped search finds it
+    x[:4000] = (rng.randint(-40, 41, (4000, 3)) / 16.0).astype(np.float32)         # and points far outside (unbounded search only)
+    dev = "cuda"
+    vt, xt = torch.from_numpy(verts).to(dev), torch.from_numpy(x).to(dev)
+    d2 = ((xt[:, None, :] - vt[None, :, :]) ** 2).sum(-1)                          # exact
+    dmin = d2.min(1, keepdim=True).values
+    ids = torch.arange(V, device=dev)[None, :].expand_as(d2)
+    want = torch.where(d2 == dmin, ids, torch.full_like(ids, V)).min(1).values
+    n_tied = int(((d2 == dmin).sum(1) > 1).sum())
+    assert n_tied > 2000                                                            # the case under test is well populated
+    perm = torch.from_numpy(knn_cluster_perm(verts)).to(dev)
+    vs = torch.empty(hip.KNN_NC * hip.KNN_CLUSTER, 4, dtype=torch.float32, device=dev)
+    cb = torch.empty(hip.KNN_CB_ROWS, 4, dtype=torch.float32, device=dev)
+    hip.check(L.mp_knn_build(hip.ptr(vt), hip.ptr(perm), hip.ptr(vs), hip.ptr(cb), hip.stream()), "mp_knn_build")
+    btab = torch.zeros(V, 3, 4, dtype=torch.float32, device=dev)                   # x_c = I (x - c): I = identity, c = (-id, 0, 0)
+    btab[:, 0, 0] = btab[:, 1, 1] = btab[:, 2, 2] = 1.0
+    btab[:, 0, 3] = -torch.arange(V, device=dev, dtype=torch.float32)
+    for mode in (0, 1):
+        xc = torch.full((n, 3), float("nan"), dtype=torch.float32, device=dev)
+        outl = torch.empty(n, dtype=torch.uint8, device=dev)
+        sdf = torch.zeros(n, dtype=torch.float32, device=dev)
+        hip.check(L.mp_warp_inverse(hip.ptr(xt), None, None, None, None, None, 0, 1, n, hip.ptr(vs), hip.ptr(cb), hip.ptr(btab),
+                                    mode, None, None, hip.ptr(xc), hip.ptr(outl), hip.ptr(sdf), None, None, None, hip.stream()),
+                  "mp_warp_inverse")
+        torch.cuda.synchronize()
+        got = (xc[:, 0] - xt[:, 0]).round().long()
+        inside = outl == 0 if mode == 1 else torch.ones(n, dtype=torch.bool, device=dev)
+        want_out = dmin[:, 0].clamp(max=4.0).sqrt() > 0.1                           # deformer.py:41-49
+        assert torch.equal(outl.bool(), want_out), f"mode {mode}: outlier flags"
+        assert int(inside.sum()) > 10000
+        bad = (got != want) & inside
+        assert not bool(bad.any()), f"mode {mode}: {int(bad.sum())} of {int(inside.sum())} points took another vertex than the lowest id at the minimum distance"
+    # the seeded search of the Jacobian kernel (explicit points): seed = any vertex at the minimum distance, not the lowest id
+    seed = torch.where(d2 == dmin, ids, torch.full_like(ids, -1)).max(1).values.int()
+    jinv = torch.empty(n, 9, dtype=torch.float32, device=dev)
+    nn = torch.empty(n, dtype=torch.int32, device=dev)
+    hip.check(L.mp_warp_jacobian(hip.ptr(xt), None, None, 0, 0, n, hip.ptr(vs), hip.ptr(cb), hip.ptr(btab), hip.ptr(jinv), hip.ptr(nn),
+                                 hip.ptr(seed), hip.ptr(vt), hip.stream()), "mp_warp_jacobian")
+    torch.cuda.synchronize()
+    assert torch.equal(nn.long(), want)
+
+
 def test_rays(golden):
     import ctypes as C
     from multiply_amd import hip
