@@ -75,7 +75,7 @@ def main():
                 print(f"[rank {rank}] epoch {epoch}: gradient of {name} differs by {rel:.3e} (relative to its maximum)", flush=True)
             worst, n_cmp = max(worst, rel), n_cmp + 1
         print(f"[rank {rank}] epoch {epoch}: {n_cmp} gradients compared, worst relative difference {worst:.2e}; "
-              f"{n_none} remote-person tensors without gradient", flush=True)
+              f"{n_none} remote-person tensors without gradient; host-hull fall-backs so far {getattr(model, 'hull_host_fallbacks', 0)}", flush=True)
         ok = ok and worst < 2e-4 and n_cmp > 20 and n_none > 20
     flag = torch.tensor([1.0 if ok else 0.0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
