@@ -8,6 +8,8 @@ import sys
 
 import pytest
 
+from tests import tolerances as TOL
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -45,7 +47,7 @@ def test_single_gpu_line_has_roofline_and_cpu_baseline():
     assert t["cpu_baseline"]["parity_loss_abs"] < 1e-4 and t["cpu_baseline"]["rays"] == 128
     # round 6: the sampler of that iteration against the oracle's own sampler (same draws), and the bce-guard flags
     tc = t["cpu_baseline"]
-    assert tc["parity_sampler_depth_mean_abs"] < 1.3e-4 and tc["parity_sampler_depth_rays_above_3e-3"] <= max(2, 0.01 * tc["parity_sampler_depth_rays"])
+    assert tc["parity_sampler_depth_mean_abs"] < 1.3e-4 and tc["parity_sampler_depth_rays_above_3e-3"] <= max(TOL.TRAIN_DEPTH_RAYS["floor"], TOL.TRAIN_DEPTH_RAYS["frac"] * tc["parity_sampler_depth_rays"])
     assert tc["bce_guard"]["mismatch"] in (False, True) and d["train_iter"]["stash_bytes_per_point"] > 46 * 1024
 
 

@@ -202,7 +202,7 @@ def test_training_parity_at_the_benchmarked_workload():
     print("[parity] bench workload:", {k: v for k, v in res.items() if k.startswith(("parity", "loss_"))})
     # round 6: the sampler of that iteration against the oracle's own sampler on the same draws (tests/tolerances.py Z_VALS_PRECISE)
     assert res["parity_sampler_depth_mean_abs"] < TOL.Z_VALS_PRECISE["mean"]
-    assert res["parity_sampler_depth_rays_above_3e-3"] <= max(2, TOL.Z_VALS_PRECISE["frac"] * res["parity_sampler_depth_rays"])
+    assert res["parity_sampler_depth_rays_above_3e-3"] <= max(TOL.TRAIN_DEPTH_RAYS["floor"], TOL.TRAIN_DEPTH_RAYS["frac"] * res["parity_sampler_depth_rays"])
     assert res["parity_grad_tensors"] >= 60
     assert res["parity_loss_abs"] < 1e-4 * max(1.0, abs(res["loss_oracle"]))
     assert res["parity_grad_rel_worst"] < TOL.TRAIN_GRAD_REL_RENDERING, res["parity_grad_worst_tensor"]

@@ -78,6 +78,10 @@ Z_VALS_F16 = (5e-2, 3e-4)                   # sampler depths with the f16 sample
 Z_VALS = (5e-3, 1e-5)                       # the default (near-fp32) sampler's depths on the small scenes; measured 4.5e-4, 2.1e-6
 TRAIN_Z_VALS = (6e-3, 3e-5)                 # training-mode depths (stratified / random draws), default sampler; measured 1.2e-3, 6.5e-6
 TRAIN_Z_VALS_PRECISE = TRAIN_Z_VALS
+# the device's training-mode sampler against the ORACLE'S OWN sampler on the same draws (bench.py parity_sampler_depth_*): rays with a depth
+# off by more than 3e-3 (flat stretches of a CDF).  The device's depths are the same bits on every run (profiles/r06_determinism.txt); the
+# oracle's move with the host it runs on: measured 5, 5, 6 and 9 of 787 rays on four boxes (512-ray iteration), 2 and 4 of ~190 (128 rays).
+TRAIN_DEPTH_RAYS = dict(frac=0.03, floor=6)
 TRAIN_Z_VALS_F16 = (0.15, 1e-3)             # the same with sampler_sdf_mode = 'f16'; measured 3e-2, 2e-4
 MLP = {                                     # the fused MLP kernels on random points vs the fp32 oracle: max |err|
     "fg_sdf": 5e-3, "fg_feat": 7e-3,        # 9.8e-4, 1.4e-3
