@@ -108,18 +108,33 @@ def test_no_device_fails_loudly():
 
 
 def test_cluster_perm_partitions_all_vertices(smpl_tables):
+    """the static cluster order of the exact nearest-vertex search (smpl.knn_cluster_perm): every vertex once; fine clusters of at most
+    MP_KNN_CLUSTER vertices, none empty; the PAIRS (2c, 2c + 1) -- the coarse clusters of the training searches (csrc/geom.hip
+    k_knn_build) -- are the kd leaves, full except the last; both granularities spatially compact; the constants equal the header's"""
+    from multiply_amd import hip
     from multiply_amd.smpl import knn_cluster_perm
-    perm = knn_cluster_perm(np.asarray(smpl_tables["v_template"], dtype=np.float32))
-    assert perm.shape == (108 * 64,)
+    hdr = open(os.path.join(REPO, "include", "multiply_hip.h")).read()
+    CL, NC = (int(re.search(r"#define %s (\d+)" % k, hdr).group(1)) for k in ("MP_KNN_CLUSTER", "MP_KNN_NC"))
+    assert (CL, NC) == (hip.KNN_CLUSTER, hip.KNN_NC) and hip.KNN_CB_ROWS == NC + NC // 2 and NC % 2 == 0 and 2 * CL <= 64
+    v = np.asarray(smpl_tables["v_template"], dtype=np.float32)
+    perm = knn_cluster_perm(v)
+    assert perm.shape == (NC * CL,) and NC * CL >= 6890
     assert sorted(perm[perm >= 0].tolist()) == list(range(6890))
-    v = np.asarray(smpl_tables["v_template"])
-    # clusters are spatially compact: mean cluster radius far below the body size
-    rad = []
-    for c in range(108):
-        ids = perm[c * 64:(c + 1) * 64]
-        ids = ids[ids >= 0]
-        rad.append(np.linalg.norm(v[ids] - v[ids].mean(0), axis=1).max())
-    assert np.mean(rad) < 0.15
+
+    def radii(size):
+        out, counts = [], []
+        for c in range(NC * CL // size):
+            ids = perm[c * size:(c + 1) * size]
+            ids = ids[ids >= 0]
+            counts.append(len(ids))
+            out.append(np.linalg.norm(v[ids] - v[ids].mean(0), axis=1).max() if len(ids) else 0.0)
+        return np.asarray(out), np.asarray(counts)
+    r_fine, n_fine = radii(CL)
+    r_pair, n_pair = radii(2 * CL)
+    assert n_fine.min() >= 1 and n_fine.max() == CL
+    assert (n_pair[:-1] == 2 * CL).all() and 1 <= n_pair[-1] <= 2 * CL          # full kd leaves, the last one partial
+    # clusters are spatially compact: mean cluster radius far below the body size, the halves tighter than the leaves
+    assert np.mean(r_pair) < 0.15 and np.mean(r_fine) < 0.8 * np.mean(r_pair)
 
 
 def test_docs_quote_the_current_number_of_entry_points():
